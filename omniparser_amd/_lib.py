@@ -1,0 +1,161 @@
+"""ctypes binding of libomni_amd.so (include/omni_amd.h).
+
+There is NO CPU fallback: if the shared object is missing, cannot be built, or does not export a
+symbol the header declares, importing the product path fails loudly.
+"""
+import ctypes
+from ctypes import c_char_p, c_float, c_int, c_int32, c_void_p, POINTER, Structure
+
+from . import build as _build
+
+# op kinds / enums (mirror include/omni_amd.h)
+F32, F16 = 0, 1
+ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
+OP_CONV, OP_AVGPOOL2, OP_MAXPOOL, OP_RESIZE_NEAREST, OP_LETTERBOX, OP_DETECT_DECODE, OP_NMS = 1, 2, 3, 4, 5, 6, 7
+OP_DWCONV3, OP_LAYERNORM = 8, 9
+CAND_BYTES = 32
+
+EXPORTS = [
+    "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
+    "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
+    "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time",
+]
+
+
+class OmniOp(Structure):
+    _fields_ = [
+        ("kind", c_int32),
+        ("dtype", c_int32),
+        ("p", c_void_p * 8),
+        ("i", c_int32 * 32),
+        ("f", c_float * 8),
+    ]
+
+
+class OmniError(RuntimeError):
+    pass
+
+
+_lib = None
+
+
+def lib():
+    global _lib
+    if _lib is not None:
+        return _lib
+    path = _build.ensure_built()
+    L = ctypes.CDLL(str(path))
+    missing = [s for s in EXPORTS if not hasattr(L, s)]
+    if missing:
+        raise OmniError(f"{path} does not export {missing}")
+    L.omni_last_error.restype = c_char_p
+    L.omni_abi_version.restype = c_int
+    L.omni_device_count.restype = c_int
+    L.omni_op_launch.argtypes = [POINTER(OmniOp), c_void_p]
+    L.omni_op_launch.restype = c_int
+    L.omni_plan_create.argtypes = [POINTER(OmniOp), c_int, POINTER(c_void_p)]
+    L.omni_plan_create.restype = c_int
+    for name in ("omni_plan_run", "omni_plan_capture", "omni_plan_replay"):
+        fn = getattr(L, name)
+        fn.argtypes = [c_void_p, c_void_p]
+        fn.restype = c_int
+    L.omni_plan_num_ops.argtypes = [c_void_p]
+    L.omni_plan_num_ops.restype = c_int
+    L.omni_plan_destroy.argtypes = [c_void_p]
+    L.omni_plan_destroy.restype = None
+    L.omni_resample_coeffs.argtypes = [c_int, c_int, c_int, POINTER(c_int32), POINTER(c_int32)]
+    L.omni_resample_coeffs.restype = c_int
+    L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
+    L.omni_plan_time.restype = c_int
+    if L.omni_abi_version() != 1:
+        raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
+    _lib = L
+    return L
+
+
+def check(rc: int):
+    if rc != 0:
+        raise OmniError(f"libomni_amd error {rc}: {lib().omni_last_error().decode()}")
+
+
+def make_op(kind, dtype, p=(), i=None, f=None) -> OmniOp:
+    """p: sequence of ints/None (device addresses); i/f: dict slot -> value."""
+    op = OmniOp()
+    op.kind = kind
+    op.dtype = dtype
+    for k, v in enumerate(p):
+        op.p[k] = v if v else None
+    for k, v in (i or {}).items():
+        op.i[k] = int(v)
+    for k, v in (f or {}).items():
+        op.f[k] = float(v)
+    return op
+
+
+def launch(op: OmniOp, stream=None):
+    check(lib().omni_op_launch(ctypes.byref(op), _stream_ptr(stream)))
+
+
+def _stream_ptr(stream):
+    if stream is None:
+        import torch
+        if torch.cuda.is_available():
+            return c_void_p(torch.cuda.current_stream().cuda_stream)
+        return None
+    if isinstance(stream, int):
+        return c_void_p(stream)
+    return c_void_p(stream.cuda_stream)
+
+
+class Plan:
+    """Immutable op list executed by the C++ plan executor (eager or hipGraph replay)."""
+
+    def __init__(self, ops):
+        self.ops = list(ops)
+        arr = (OmniOp * len(self.ops))(*self.ops)
+        h = c_void_p()
+        check(lib().omni_plan_create(arr, len(self.ops), ctypes.byref(h)))
+        self._h = h
+        self.captured = False
+
+    def run(self, stream=None):
+        check(lib().omni_plan_run(self._h, _stream_ptr(stream)))
+
+    def capture(self, stream):
+        check(lib().omni_plan_capture(self._h, _stream_ptr(stream)))
+        self.captured = True
+
+    def replay(self, stream=None):
+        check(lib().omni_plan_replay(self._h, _stream_ptr(stream)))
+
+    def time(self, iters, stream=None) -> float:
+        ms = c_float()
+        check(lib().omni_plan_time(self._h, _stream_ptr(stream), iters, ctypes.byref(ms)))
+        return ms.value
+
+    def __len__(self):
+        return len(self.ops)
+
+    def __del__(self):
+        try:
+            if self._h:
+                lib().omni_plan_destroy(self._h)
+                self._h = None
+        except Exception:
+            pass
+
+
+def resample_coeffs(in_size: int, out_size: int, filt: int):
+    """(bounds int32[out,2], coef int32[out,ksize]) — Pillow's fixed-point tables."""
+    import numpy as np
+    k = lib().omni_resample_coeffs(in_size, out_size, filt, None, None)
+    if k <= 0:
+        check(k)
+    bounds = np.zeros((out_size, 2), dtype=np.int32)
+    coef = np.zeros((out_size, k), dtype=np.int32)
+    rc = lib().omni_resample_coeffs(
+        in_size, out_size, filt,
+        bounds.ctypes.data_as(POINTER(c_int32)), coef.ctypes.data_as(POINTER(c_int32)))
+    if rc <= 0:
+        check(rc)
+    return bounds, coef

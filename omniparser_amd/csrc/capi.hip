@@ -1,0 +1,198 @@
+// C ABI of libomni_amd.so: error channel, single-op dispatch, the plan executor
+// (eager replay or hipGraph replay of an immutable op list) and the host-side
+// Pillow coefficient generator.  See include/omni_amd.h for the contract.
+#include "omni_internal.h"
+
+#include <math.h>
+#include <stdarg.h>
+#include <stdlib.h>
+#include <string.h>
+#include <vector>
+
+static thread_local char g_err[512] = "";
+
+void omni_set_error(const char* fmt, ...) {
+  va_list ap;
+  va_start(ap, fmt);
+  vsnprintf(g_err, sizeof(g_err), fmt, ap);
+  va_end(ap);
+}
+
+extern "C" const char* omni_last_error(void) { return g_err; }
+extern "C" int omni_abi_version(void) { return OMNI_ABI_VERSION; }
+
+extern "C" int omni_device_count(void) {
+  int n = 0;
+  hipError_t e = hipGetDeviceCount(&n);
+  if (e != hipSuccess) {
+    omni_set_error("hipGetDeviceCount: %s", hipGetErrorString(e));
+    return OMNI_E_NODEV;
+  }
+  return n;
+}
+
+static int dispatch(const omni_op_t* op, hipStream_t s) {
+  switch (op->kind) {
+    case OMNI_OP_CONV: return omni_launch_conv(op, s);
+    case OMNI_OP_AVGPOOL2: return omni_launch_avgpool2(op, s);
+    case OMNI_OP_MAXPOOL: return omni_launch_maxpool(op, s);
+    case OMNI_OP_RESIZE_NEAREST: return omni_launch_resize_nearest(op, s);
+    case OMNI_OP_LETTERBOX: return omni_launch_letterbox(op, s);
+    case OMNI_OP_DETECT_DECODE: return omni_launch_detect_decode(op, s);
+    case OMNI_OP_NMS: return omni_launch_nms(op, s);
+    default:
+      omni_set_error("unknown op kind %d", op->kind);
+      return OMNI_E_ARG;
+  }
+}
+
+extern "C" int omni_op_launch(const omni_op_t* op, void* stream) {
+  if (!op) { omni_set_error("omni_op_launch: null op"); return OMNI_E_ARG; }
+  return dispatch(op, (hipStream_t)stream);
+}
+
+struct omni_plan {
+  std::vector<omni_op_t> ops;
+  hipGraph_t graph = nullptr;
+  hipGraphExec_t exec = nullptr;
+};
+
+extern "C" int omni_plan_create(const omni_op_t* ops, int n_ops, omni_plan_t** out) {
+  if (!ops || n_ops <= 0 || !out) { omni_set_error("omni_plan_create: bad arguments"); return OMNI_E_ARG; }
+  for (int i = 0; i < n_ops; ++i) {
+    if (ops[i].kind <= 0 || ops[i].kind >= OMNI_OP__COUNT) {
+      omni_set_error("omni_plan_create: op %d has unknown kind %d", i, ops[i].kind);
+      return OMNI_E_ARG;
+    }
+  }
+  omni_plan* p = new omni_plan();
+  p->ops.assign(ops, ops + n_ops);
+  *out = p;
+  return OMNI_OK;
+}
+
+extern "C" int omni_plan_num_ops(const omni_plan_t* plan) { return plan ? (int)plan->ops.size() : 0; }
+
+extern "C" int omni_plan_run(omni_plan_t* plan, void* stream) {
+  if (!plan) { omni_set_error("omni_plan_run: null plan"); return OMNI_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  for (size_t i = 0; i < plan->ops.size(); ++i) {
+    int rc = dispatch(&plan->ops[i], s);
+    if (rc) {
+      char prev[400];
+      strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;
+      omni_set_error("plan op %zu (kind %d): %s", i, plan->ops[i].kind, prev);
+      return rc;
+    }
+  }
+  return OMNI_OK;
+}
+
+extern "C" int omni_plan_capture(omni_plan_t* plan, void* stream) {
+  if (!plan) { omni_set_error("omni_plan_capture: null plan"); return OMNI_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  if (!s) { omni_set_error("omni_plan_capture: needs a non-default stream"); return OMNI_E_ARG; }
+  if (plan->exec) { hipGraphExecDestroy(plan->exec); plan->exec = nullptr; }
+  if (plan->graph) { hipGraphDestroy(plan->graph); plan->graph = nullptr; }
+  OMNI_HIP_CHECK(hipStreamBeginCapture(s, hipStreamCaptureModeThreadLocal));
+  int rc = omni_plan_run(plan, s);
+  hipGraph_t g = nullptr;
+  hipError_t e = hipStreamEndCapture(s, &g);
+  if (rc) { if (g) hipGraphDestroy(g); return rc; }
+  if (e != hipSuccess) { omni_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return OMNI_E_HIP; }
+  plan->graph = g;
+  OMNI_HIP_CHECK(hipGraphInstantiate(&plan->exec, plan->graph, nullptr, nullptr, 0));
+  return OMNI_OK;
+}
+
+extern "C" int omni_plan_replay(omni_plan_t* plan, void* stream) {
+  if (!plan) { omni_set_error("omni_plan_replay: null plan"); return OMNI_E_ARG; }
+  if (!plan->exec) return omni_plan_run(plan, stream);
+  OMNI_HIP_CHECK(hipGraphLaunch(plan->exec, (hipStream_t)stream));
+  return OMNI_OK;
+}
+
+extern "C" void omni_plan_destroy(omni_plan_t* plan) {
+  if (!plan) return;
+  if (plan->exec) hipGraphExecDestroy(plan->exec);
+  if (plan->graph) hipGraphDestroy(plan->graph);
+  delete plan;
+}
+
+extern "C" int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms) {
+  if (!plan || iters <= 0 || !ms) { omni_set_error("omni_plan_time: bad arguments"); return OMNI_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  hipEvent_t e0, e1;
+  OMNI_HIP_CHECK(hipEventCreate(&e0));
+  OMNI_HIP_CHECK(hipEventCreate(&e1));
+  OMNI_HIP_CHECK(hipEventRecord(e0, s));
+  int rc = OMNI_OK;
+  for (int i = 0; i < iters && rc == OMNI_OK; ++i) rc = omni_plan_replay(plan, stream);
+  hipEventRecord(e1, s);
+  hipEventSynchronize(e1);
+  float t = 0.f;
+  hipEventElapsedTime(&t, e0, e1);
+  hipEventDestroy(e0);
+  hipEventDestroy(e1);
+  if (rc) return rc;
+  *ms = t / iters;
+  return OMNI_OK;
+}
+
+// ---------------------------------------------------------------------------------------------
+// Pillow precompute_coeffs + normalize_coeffs_8bpc (host, double precision).
+static double sinc_filter(double x) {
+  if (x == 0.0) return 1.0;
+  x = x * M_PI;
+  return sin(x) / x;
+}
+static double lanczos_filter(double x) {
+  if (-3.0 <= x && x < 3.0) return sinc_filter(x) * sinc_filter(x / 3);
+  return 0.0;
+}
+static double bicubic_filter(double x) {
+  const double a = -0.5;
+  if (x < 0.0) x = -x;
+  if (x < 1.0) return ((a + 2.0) * x - (a + 3.0)) * x * x + 1;
+  if (x < 2.0) return (((x - 5) * x + 8) * x - 4) * a;
+  return 0.0;
+}
+
+extern "C" int omni_resample_coeffs(int in_size, int out_size, int filter, int32_t* h_bounds, int32_t* h_coef) {
+  if (in_size <= 0 || out_size <= 0 || (filter != 0 && filter != 1)) {
+    omni_set_error("omni_resample_coeffs: bad arguments");
+    return OMNI_E_ARG;
+  }
+  double (*f)(double) = filter == 0 ? lanczos_filter : bicubic_filter;
+  double fsupport = filter == 0 ? 3.0 : 2.0;
+  double scale = (double)in_size / out_size;
+  double filterscale = scale < 1.0 ? 1.0 : scale;
+  double support = fsupport * filterscale;
+  int ksize = (int)ceil(support) * 2 + 1;
+  if (!h_bounds || !h_coef) return ksize;
+  std::vector<double> k(ksize);
+  for (int xx = 0; xx < out_size; ++xx) {
+    double center = (xx + 0.5) * scale;
+    double ww = 0.0;
+    double ss = 1.0 / filterscale;
+    int xmin = (int)(center - support + 0.5);
+    if (xmin < 0) xmin = 0;
+    int xmax = (int)(center + support + 0.5);
+    if (xmax > in_size) xmax = in_size;
+    xmax -= xmin;
+    for (int x = 0; x < xmax; ++x) {
+      double w = f((x + xmin - center + 0.5) * ss);
+      k[x] = w;
+      ww += w;
+    }
+    for (int x = 0; x < xmax; ++x)
+      if (ww != 0.0) k[x] /= ww;
+    for (int x = 0; x < ksize; ++x) {
+      double v = x < xmax ? k[x] : 0.0;
+      h_coef[(size_t)xx * ksize + x] = v < 0 ? (int)(-0.5 + v * (1 << 22)) : (int)(0.5 + v * (1 << 22));
+    }
+    h_bounds[xx * 2 + 0] = xmin;
+    h_bounds[xx * 2 + 1] = xmax;
+  }
+  return ksize;
+}

@@ -1,0 +1,145 @@
+"""ORACLE (test infrastructure; only tests/, __graft_entry__.smoke() and bench.py's cpu_baseline leg
+may import this).
+
+CPU fp32 restatement of the reference detector adapter, ref:util/yolov9.py:52-136, plus a pure-torch
+restatement of torchvision.ops.batched_nms / nms (torchvision is absent here and is unpinned in
+ref:requirements.txt:3 — algorithm restated from its published CPU source).
+
+Pinning: the reference has no tests for this path ("parity unpinned" by its own fixtures).  This
+restatement is pinned instead against the reference's literal YOLOv9Detector class executed from
+/root/reference under dependency shims (tests/golden/gen_golden.py, fixtures in tests/golden/).
+"""
+from contextlib import nullcontext
+
+import numpy as np
+import torch
+from PIL import Image
+
+STRIDES = (8, 16, 32)
+
+
+# ------------------------------------------------------------------ torchvision.ops restatement
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
+    """torchvision nms_kernel_impl (CPU): stable descending sort, greedy, strict `>`."""
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    b = boxes.detach().cpu().numpy().astype(np.float32)
+    x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
+    areas = ((x2 - x1) * (y2 - y1)).astype(np.float32)
+    order = torch.sort(scores.detach().cpu(), stable=True, descending=True).indices.numpy()
+    n = len(order)
+    suppressed = np.zeros(n, dtype=bool)
+    keep = []
+    thr = np.float32(iou_threshold)
+    zero = np.float32(0)
+    for _i in range(n):
+        i = order[_i]
+        if suppressed[i]:
+            continue
+        keep.append(i)
+        rest = order[_i + 1:]
+        xx1 = np.maximum(x1[i], x1[rest])
+        yy1 = np.maximum(y1[i], y1[rest])
+        xx2 = np.minimum(x2[i], x2[rest])
+        yy2 = np.minimum(y2[i], y2[rest])
+        w = np.maximum(zero, xx2 - xx1)
+        h = np.maximum(zero, yy2 - yy1)
+        inter = (w * h).astype(np.float32)
+        with np.errstate(divide="ignore", invalid="ignore"):
+            ovr = inter / ((areas[i] + areas[rest]).astype(np.float32) - inter)
+        suppressed[rest[ovr > thr]] = True
+    return torch.as_tensor(np.asarray(keep, dtype=np.int64))
+
+
+def batched_nms(boxes, scores, idxs, iou_threshold):
+    """torchvision.ops.batched_nms with the CPU dispatch threshold (numel > 4000 -> per-class loop)."""
+    if boxes.numel() > 4000:
+        keep_mask = torch.zeros_like(scores, dtype=torch.bool)
+        for class_id in torch.unique(idxs):
+            curr = torch.where(idxs == class_id)[0]
+            k = nms(boxes[curr], scores[curr], iou_threshold)
+            keep_mask[curr[k]] = True
+        keep_indices = torch.where(keep_mask)[0]
+        return keep_indices[scores[keep_indices].sort(descending=True, stable=True)[1]]
+    if boxes.numel() == 0:
+        return torch.empty((0,), dtype=torch.int64)
+    max_coordinate = boxes.max()
+    offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
+    return nms(boxes + offsets[:, None], scores, iou_threshold)
+
+
+# ------------------------------------------------------------------ ref:util/yolov9.py restated
+def normalize_image_size(image_size):
+    """ref:util/yolov9.py:52-62."""
+    if isinstance(image_size, int):
+        width = height = image_size
+    elif len(image_size) == 2:
+        height, width = image_size
+    else:
+        raise ValueError(f"Expected one or two image dimensions, got {image_size}")
+    return ((int(width) + 31) // 32) * 32, ((int(height) + 31) // 32) * 32
+
+
+def load_image(source):
+    """ref:util/yolov9.py:64-71."""
+    if isinstance(source, Image.Image):
+        return source.convert("RGB")
+    if isinstance(source, np.ndarray):
+        return Image.fromarray(source).convert("RGB")
+    with Image.open(source) as image:
+        return image.convert("RGB")
+
+
+def letterbox_geometry(image_width, image_height, image_size):
+    """scale / resized dims / pads exactly as ref:util/yolov9.py:74-80."""
+    tw, th = normalize_image_size(image_size)
+    scale = min(tw / image_width, th / image_height)
+    rw, rh = int(image_width * scale), int(image_height * scale)
+    return tw, th, scale, rw, rh, (tw - rw) // 2, (th - rh) // 2
+
+
+def preprocess(image: Image.Image, image_size):
+    """ref:util/yolov9.py:73-87 (PIL LANCZOS letterbox, /255)."""
+    tw, th, scale, rw, rh, pad_left, pad_top = letterbox_geometry(image.width, image.height, image_size)
+    resized = image.resize((rw, rh), Image.Resampling.LANCZOS)
+    padded = Image.new("RGB", (tw, th), (114, 114, 114))
+    padded.paste(resized, (pad_left, pad_top))
+    arr = np.asarray(padded, dtype=np.float32).transpose(2, 0, 1) / 255.0
+    return torch.from_numpy(arr).unsqueeze(0), scale, pad_left, pad_top
+
+
+def decode(outputs):
+    """ref:util/yolov9.py:89-108."""
+    class_logits, decoded = [], []
+    for oi, stride in zip(range(0, len(outputs), 2), STRIDES):
+        logits, dist = outputs[oi:oi + 2]
+        bsz, _, h, w = logits.shape
+        logits = logits.permute(0, 2, 3, 1).reshape(bsz, -1, logits.shape[1])
+        dist = dist.permute(0, 2, 3, 1).reshape(bsz, -1, 4) * stride
+        gy, gx = torch.meshgrid(torch.arange(h), torch.arange(w), indexing="ij")
+        anchors = (torch.stack((gx, gy), dim=-1).reshape(-1, 2) + 0.5) * stride
+        lt, rb = dist.chunk(2, dim=-1)
+        decoded.append(torch.cat((anchors - lt, anchors + rb), dim=-1))
+        class_logits.append(logits)
+    return torch.cat(class_logits, dim=1).sigmoid(), torch.cat(decoded, dim=1)
+
+
+@torch.inference_mode()
+def predict(model, source, conf=0.25, imgsz=640, iou=0.7, max_det=300, return_debug=False):
+    """ref:util/yolov9.py:115-136.  Returns (boxes[K,4], scores[K], class_ids[K])."""
+    image = load_image(source)
+    x, scale, pad_left, pad_top = preprocess(image, imgsz)
+    class_scores, boxes = decode(model(x))
+    scores, class_ids = class_scores[0].max(dim=-1)
+    valid = scores > conf
+    scores, class_ids, boxes = scores[valid], class_ids[valid], boxes[0][valid]
+    boxes[:, [0, 2]] = (boxes[:, [0, 2]] - pad_left) / scale
+    boxes[:, [1, 3]] = (boxes[:, [1, 3]] - pad_top) / scale
+    cand = (boxes.clone(), scores.clone(), class_ids.clone())
+    keep = batched_nms(boxes, scores, class_ids, iou)[:max_det]
+    boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
+    boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, image.width)
+    boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, image.height)
+    if return_debug:
+        return boxes, scores, class_ids, {"input": x, "cand": cand, "valid": valid, "keep": keep}
+    return boxes, scores, class_ids
