@@ -167,14 +167,20 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       for (int j = 0; j < TN; ++j)
         bv[j] = *reinterpret_cast<const u32x4*>(ldsB + b_rd + j * 32 * ROWB + kk * 32);
       if constexpr (sizeof(T) == 4) {
+        f32x4 af[TM], bf[TN];
 #pragma unroll
-        for (int e = 0; e < 4; ++e)
+        for (int i = 0; i < TM; ++i) af[i] = __builtin_bit_cast(f32x4, av[i]);
 #pragma unroll
-          for (int i = 0; i < TM; ++i)
+        for (int j = 0; j < TN; ++j) bf[j] = __builtin_bit_cast(f32x4, bv[j]);
 #pragma unroll
-            for (int j = 0; j < TN; ++j)
-              acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(
-                  __builtin_bit_cast(float, av[i][e]), __builtin_bit_cast(float, bv[j][e]), acc[i][j], 0, 0, 0);
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j) {
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].x, bf[j].x, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].y, bf[j].y, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].z, bf[j].z, acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(af[i].w, bf[j].w, acc[i][j], 0, 0, 0);
+          }
       } else {
 #pragma unroll
         for (int i = 0; i < TM; ++i)

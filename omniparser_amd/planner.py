@@ -94,7 +94,8 @@ class PlanBuilder:
             assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
         b = None
         if bias is not None:
-            b = self.upload(bias.detach().float())
+            b = bias if bias.device == self.device and bias.dtype == torch.float32 else self.upload(bias.detach().float())
+            self.keep.append(b)
             assert b.numel() == cout
         op = L.make_op(
             L.OP_CONV, self.dtype,
@@ -105,6 +106,7 @@ class PlanBuilder:
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0},
             f={0: scale})
         self.ops.append(op)
+        self.keep.append(w_packed)
         M = x.B * Ho * Wo
         esz = 4 if self.dtype == L.F32 else 2
         self.flops += 2 * M * cout * k * k * x.C

@@ -25,14 +25,30 @@ KEYMAP_HOOK = None   # optional callable(state_dict) -> state_dict with the nami
 
 
 class YoloV9EGraph:
-    def __init__(self, state_dict: Dict[str, torch.Tensor], pb: PlanBuilder, B: int, TH: int, TW: int):
+    def __init__(self, state_dict: Dict[str, torch.Tensor], pb: PlanBuilder, B: int, TH: int, TW: int,
+                 wcache: Dict = None):
         if KEYMAP_HOOK is not None:
             state_dict = KEYMAP_HOOK(state_dict)
-        self.sd = {k: v.detach().float().cpu() for k, v in state_dict.items()}
+        self.sd = state_dict
         self.pb = pb
         self.B, self.TH, self.TW = B, TH, TW
         self.nc = self.sd["head.cv3.0.2.weight"].shape[0]
-        self._wcache = {}
+        # packed device weights are shared by every plan built for this detector
+        self.wcache = wcache if wcache is not None else {}
+
+    def packed(self, key, make, cin_pad=None):
+        """(packed weight on device, f32 bias on device) for `key`, built once via make() -> (W, b)."""
+        ck = (key, self.pb.dtype, cin_pad, str(self.pb.device))
+        if ck not in self.wcache:
+            w, b = make()
+            wp = self.pb.pack_weight(w.float(), cin_pad)
+            bp = self.pb.upload(b.detach().float()) if b is not None else None
+            self.wcache[ck] = (wp, bp)
+        return self.wcache[ck]
+
+    def conv(self, key, make, x, out, k, s=1, act=L.ACT_SILU, res=None, cin_pad=None):
+        wp, bp = self.packed(key, make, cin_pad)
+        return self.pb.conv(x, wp, bp, out, k, s, act=act, res=res)
 
     # ------------------------------------------------------------ weight transforms
     def fold(self, prefix):
@@ -68,28 +84,27 @@ class YoloV9EGraph:
 
     # ------------------------------------------------------------ blocks
     def conv_bn(self, prefix, x: View, out: View = None, k=1, s=1, res: View = None, cin_pad=None) -> View:
-        w, b = self.fold(prefix)
         if out is None:
             p = k // 2
-            out = self.pb.alloc(x.B, (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, w.shape[0])
-        wp = self.pb.pack_weight(w, cin_pad)
-        return self.pb.conv(x, wp, b, out, k, s, act=L.ACT_SILU, res=res)
+            out = self.pb.alloc(x.B, (x.H + 2 * p - k) // s + 1, (x.W + 2 * p - k) // s + 1, self.cout(prefix))
+        return self.conv(prefix, lambda: self.fold(prefix), x, out, k, s, res=res, cin_pad=cin_pad)
 
     def repncsp(self, prefix, x: View, out: View, n=2) -> View:
         pb = self.pb
-        w1, b1 = self.fold(prefix + ".cv1")
-        w2, b2 = self.fold(prefix + ".cv2")
-        c_ = w1.shape[0]
+        c_ = self.cout(prefix + ".cv1")
         cat = pb.alloc(x.B, x.H, x.W, 2 * c_)
-        pb.conv(x, pb.pack_weight(torch.cat([w1, w2], 0)), torch.cat([b1, b2], 0), cat, 1, act=L.ACT_SILU)
+
+        def merged():
+            w1, b1 = self.fold(prefix + ".cv1")
+            w2, b2 = self.fold(prefix + ".cv2")
+            return torch.cat([w1, w2], 0), torch.cat([b1, b2], 0)
+        self.conv(prefix + ".cv1|cv2", merged, x, cat, 1)
         cur = cat.slice(0, c_)
         tmp_a = pb.alloc(x.B, x.H, x.W, c_)
         for i in range(n):
-            wr, br = self.fold_rep(f"{prefix}.m.{i}.cv1")
-            pb.conv(cur, pb.pack_weight(wr), br, tmp_a, 3, act=L.ACT_SILU)
+            self.conv(f"{prefix}.m.{i}.cv1", lambda i=i: self.fold_rep(f"{prefix}.m.{i}.cv1"), cur, tmp_a, 3)
             dst = cat.slice(0, c_) if i == n - 1 else pb.alloc(x.B, x.H, x.W, c_)
-            wc, bc = self.fold(f"{prefix}.m.{i}.cv2")
-            pb.conv(tmp_a, pb.pack_weight(wc), bc, dst, 3, act=L.ACT_SILU, res=cur)
+            self.conv(f"{prefix}.m.{i}.cv2", lambda i=i: self.fold(f"{prefix}.m.{i}.cv2"), tmp_a, dst, 3, res=cur)
             cur = dst
         return self.conv_bn(prefix + ".cv3", cat, out, 1)
 
@@ -139,10 +154,10 @@ class YoloV9EGraph:
 
     def cblinear(self, prefix, x: View, splits: List[int]) -> List[View]:
         pb = self.pb
-        w, b = self.sd[prefix + ".conv.weight"], self.sd[prefix + ".conv.bias"]
-        assert w.shape[0] == sum(splits)
-        buf = pb.alloc(x.B, x.H, x.W, w.shape[0])
-        pb.conv(x, pb.pack_weight(w), b, buf, 1, act=L.ACT_NONE)
+        assert self.cout(prefix) == sum(splits)
+        buf = pb.alloc(x.B, x.H, x.W, sum(splits))
+        self.conv(prefix, lambda: (self.sd[prefix + ".conv.weight"], self.sd[prefix + ".conv.bias"]), x, buf, 1,
+                  act=L.ACT_NONE)
         views, off = [], 0
         for c in splits:
             views.append(buf.slice(off, c))
@@ -219,26 +234,33 @@ class YoloV9EGraph:
         # heads: merged 3x3 stems, block-diagonal grouped convs
         outs = []
         for i, f in enumerate((p3, n4, n5)):
-            wb, bb = self.fold(f"head.cv2.{i}.0")
-            wc, bc = self.fold(f"head.cv3.{i}.0")
-            cb, cc = wb.shape[0], wc.shape[0]
+            cb, cc = self.cout(f"head.cv2.{i}.0"), self.cout(f"head.cv3.{i}.0")
             stem = pb.alloc(B, f.H, f.W, cb + cc)
-            pb.conv(f, pb.pack_weight(torch.cat([wb, wc], 0)), torch.cat([bb, bc], 0), stem, 3, act=L.ACT_SILU)
-            # box branch
-            w, bias = self.fold(f"head.cv2.{i}.1")
-            groups = cb // sd[f"head.cv2.{i}.1.conv.weight"].shape[1]
+
+            def stem_w(i=i):
+                wb, bb = self.fold(f"head.cv2.{i}.0")
+                wc, bc = self.fold(f"head.cv3.{i}.0")
+                return torch.cat([wb, wc], 0), torch.cat([bb, bc], 0)
+            self.conv(f"head.stem.{i}", stem_w, f, stem, 3)
+
+            # box branch (groups=4 convs expanded to block-diagonal dense)
+            def box1(i=i, cb=cb):
+                w, bias = self.fold(f"head.cv2.{i}.1")
+                return self.dense_from_groups(w, cb // w.shape[1]), bias
+
+            def box2(i=i, cb=cb):
+                w = sd[f"head.cv2.{i}.2.weight"]
+                return self.dense_from_groups(w, cb // w.shape[1]), sd[f"head.cv2.{i}.2.bias"]
             t = pb.alloc(B, f.H, f.W, cb)
-            pb.conv(stem.slice(0, cb), pb.pack_weight(self.dense_from_groups(w, groups)), bias, t, 3, act=L.ACT_SILU)
-            w = sd[f"head.cv2.{i}.2.weight"]
-            g2 = cb // w.shape[1]
-            box = pb.alloc(B, f.H, f.W, w.shape[0])
-            pb.conv(t, pb.pack_weight(self.dense_from_groups(w, g2)), sd[f"head.cv2.{i}.2.bias"], box, 1)
+            self.conv(f"head.cv2.{i}.1", box1, stem.slice(0, cb), t, 3)
+            box = pb.alloc(B, f.H, f.W, sd[f"head.cv2.{i}.2.weight"].shape[0])
+            self.conv(f"head.cv2.{i}.2", box2, t, box, 1, act=L.ACT_NONE)
             # class branch
             t2 = pb.alloc(B, f.H, f.W, cc)
-            w, bias = self.fold(f"head.cv3.{i}.1")
-            pb.conv(stem.slice(cb, cc), pb.pack_weight(w), bias, t2, 3, act=L.ACT_SILU)
+            self.conv(f"head.cv3.{i}.1", lambda i=i: self.fold(f"head.cv3.{i}.1"), stem.slice(cb, cc), t2, 3)
             cls = pb.alloc(B, f.H, f.W, self.nc)
-            pb.conv(t2, pb.pack_weight(sd[f"head.cv3.{i}.2.weight"]), sd[f"head.cv3.{i}.2.bias"], cls, 1)
+            self.conv(f"head.cv3.{i}.2", lambda i=i: (sd[f"head.cv3.{i}.2.weight"], sd[f"head.cv3.{i}.2.bias"]),
+                      t2, cls, 1, act=L.ACT_NONE)
             outs.append((cls, box))
         self.debug = {"a1": a1, "a3": a3, "a9": a9, "b28": b28, "p5": p5, "p4": p4, "p3": p3, "n4": n4, "n5": n5}
         return outs

@@ -1,0 +1,426 @@
+"""GPU parity checks shared by the pytest `gpu` tests and tools/gpu_selftest.py.
+
+Every check drives the HIP kernels through the C ABI (omni_op_launch / plans) and compares with a
+CPU reference: plain torch fp32 ops for kernels, oracle/ for the reference's own functions.
+Each check returns a dict of metrics and raises AssertionError on failure.
+"""
+import math
+
+import numpy as np
+import torch
+import torch.nn.functional as F
+
+from omniparser_amd import _lib as L
+from omniparser_amd.planner import PlanBuilder, View
+
+DEV = "cuda"
+
+
+def _sync():
+    torch.cuda.synchronize()
+
+
+def _nhwc(t_nchw, dtype, ld=None, coff=0):
+    """place an NCHW cpu tensor into a (possibly wider) NHWC cuda buffer, return View."""
+    B, C, H, W = t_nchw.shape
+    ld = ld or C
+    buf = torch.randn(B, H, W, ld).to(dtype)   # garbage elsewhere: catches wrong-slice reads
+    buf[..., coff:coff + C] = t_nchw.permute(0, 2, 3, 1).to(dtype)
+    return View(buf.to(DEV), coff, C)
+
+
+def rel_err(a, b):
+    return ((a - b).abs().max() / b.abs().max().clamp_min(1e-12)).item()
+
+
+# ------------------------------------------------------------------------------------------ conv
+CONV_CASES = [
+    # B, H, W, Cin, Cout, k, s, in_ld, in_off, out_ld, out_off, res, act
+    (1, 20, 24, 64, 64, 1, 1, 64, 0, 64, 0, False, L.ACT_SILU),
+    (2, 17, 23, 32, 96, 3, 1, 64, 32, 128, 32, True, L.ACT_SILU),
+    (1, 40, 40, 128, 256, 3, 2, 128, 0, 256, 0, False, L.ACT_SILU),
+    (1, 33, 31, 8, 40, 3, 2, 8, 0, 40, 0, False, L.ACT_NONE),          # generic (unaligned Cin) path
+    (1, 80, 80, 256, 320, 3, 1, 256, 0, 320, 0, False, L.ACT_SILU),     # 128x128 tiles
+    (1, 20, 20, 1024, 1024, 1, 1, 1024, 0, 1024, 0, False, L.ACT_GELU), # small M, large K
+    (1, 9, 9, 256, 1, 1, 1, 256, 0, 1, 0, False, L.ACT_NONE),            # Cout = 1 (class head)
+    (3, 12, 12, 64, 64, 3, 1, 192, 64, 64, 0, True, L.ACT_NONE),
+]
+
+
+def check_conv(dtype=L.F32, seed=0, cases=None):
+    g = torch.Generator().manual_seed(seed)
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    V = 4 if dtype == L.F32 else 8
+    worst = 0.0
+    details = []
+    for case in (cases or CONV_CASES):
+        B, H, W, Cin, Cout, k, s, ild, ioff, old, ooff, use_res, act = case
+        if Cin % V or ild % V or ioff % V:
+            continue
+        p = k // 2
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        b = torch.randn(Cout, generator=g)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+        xq, wq = x.to(tdt).float(), w.to(tdt).float()
+        resq = res.to(tdt).float() if use_res else None
+        ref = F.conv2d(xq.double(), wq.double(), b.double(), stride=s, padding=p)
+        if act == L.ACT_SILU:
+            ref = F.silu(ref)
+        elif act == L.ACT_GELU:
+            ref = F.gelu(ref)
+        if use_res:
+            ref = ref + resq.double()
+        pb = PlanBuilder(DEV, dtype)
+        xv = _nhwc(x, tdt, ild, ioff)
+        ov = View(torch.full((B, Ho, Wo, old), 7.0, dtype=tdt, device=DEV), ooff, Cout)
+        rv = _nhwc(res, tdt, Cout + V, V) if use_res else None
+        wp = pb.pack_weight(w)
+        pb.conv(xv, wp, b, ov, k, s, act=act, res=rv)
+        L.launch(pb.ops[0])
+        _sync()
+        got = ov.torch().cpu().double()
+        e = rel_err(got, ref)
+        # untouched channels of the output buffer must keep their fill value
+        full = ov.t.float().cpu()
+        mask = torch.ones(old, dtype=torch.bool); mask[ooff:ooff + Cout] = False
+        assert (full[..., mask] == 7.0).all(), f"conv wrote outside its channel slice: {case}"
+        tol = 2e-5 if dtype == L.F32 else 4e-3
+        details.append((case, e))
+        assert e < tol, f"conv case {case}: rel err {e:.3e} >= {tol}"
+        worst = max(worst, e)
+    return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), e) for c, e in details]}
+
+
+def check_mfma_layout():
+    """A = I-like probe with asymmetric W: catches transposed / permuted MFMA fragment maps."""
+    out = {}
+    for dtype in (L.F32, L.F16):
+        tdt = torch.float32 if dtype == L.F32 else torch.float16
+        Cin, Cout, H, W = 64, 96, 8, 16
+        x = torch.zeros(1, Cin, H, W)
+        for m in range(H * W):
+            x[0, m % Cin, m // W, m % W] = 1.0 + (m // Cin)      # row m selects channel m%Cin
+        w = (torch.arange(Cout).view(-1, 1) * 100 + torch.arange(Cin).view(1, -1)).float().view(Cout, Cin, 1, 1) / 64.0
+        ref = F.conv2d(x.to(tdt).float(), w.to(tdt).float())
+        pb = PlanBuilder(DEV, dtype)
+        xv = _nhwc(x, tdt)
+        ov = pb.alloc(1, H, W, Cout)
+        pb.conv(xv, pb.pack_weight(w), None, ov, 1)
+        L.launch(pb.ops[0]); _sync()
+        e = (ov.torch().cpu() - ref).abs().max().item()
+        assert e < (1e-4 if dtype == L.F32 else 0.5), f"MFMA layout probe failed for dtype {dtype}: {e}"
+        out[f"dtype{dtype}"] = e
+    return out
+
+
+# ------------------------------------------------------------------------------------------ pools
+def check_pools(dtype=L.F32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    V = 4 if dtype == L.F32 else 8
+    res = {}
+    x = torch.randn(2, 4 * V, 13, 18, generator=g).to(tdt).float()
+    pb = PlanBuilder(DEV, dtype)
+    xv = _nhwc(x, tdt, 6 * V, V)
+    # avgpool on a channel sub-slice
+    sub = xv.slice(V, 2 * V)
+    o1 = pb.alloc(2, 12, 17, 2 * V)
+    pb.avgpool2(sub, o1)
+    o2 = pb.alloc(2, 7, 9, 3 * V, zero=True)
+    pb.maxpool(xv.slice(0, 2 * V), o2.slice(V, 2 * V), 3, 2, 1)
+    o3 = pb.alloc(2, 13, 18, 4 * V)
+    pb.maxpool(xv, o3, 5, 1, 2)
+    o4 = pb.alloc(2, 26, 36, 4 * V)
+    pb.resize_nearest(xv, o4)
+    o5 = pb.alloc(2, 52, 72, 4 * V, zero=True)
+    o5.t.fill_(1.0)
+    pb.resize_nearest(xv, o5, accumulate=True)          # 4x: generic floor(dst*scale) path
+    o6 = pb.alloc(2, 13, 18, 4 * V)
+    pb.resize_nearest(xv, o6)                            # identity
+    for op in pb.ops:
+        L.launch(op)
+    _sync()
+    tol = 1e-6 if dtype == L.F32 else 2e-3
+    r1 = F.avg_pool2d(x[:, V:3 * V], 2, 1, 0, False, True)
+    res["avgpool"] = (o1.torch().cpu() - r1).abs().max().item()
+    r2 = F.max_pool2d(x[:, :2 * V], 3, 2, 1)
+    res["maxpool3"] = (o2.slice(V, 2 * V).torch().cpu() - r2).abs().max().item()
+    assert (o2.t[..., :V] == 0).all()
+    res["maxpool5"] = (o3.torch().cpu() - F.max_pool2d(x, 5, 1, 2)).abs().max().item()
+    res["up2"] = (o4.torch().cpu() - F.interpolate(x, size=(26, 36), mode="nearest")).abs().max().item()
+    res["up4acc"] = (o5.torch().cpu() - (1.0 + F.interpolate(x, size=(52, 72), mode="nearest"))).abs().max().item()
+    res["ident"] = (o6.torch().cpu() - x).abs().max().item()
+    for k, v in res.items():
+        assert v <= tol, f"pool op {k}: err {v}"
+    return res
+
+
+# ------------------------------------------------------------------------------------------ letterbox
+def check_letterbox(dtype=L.F32, sizes=((1920, 1080, 640), (1919, 1079, 640), (640, 480, (480, 640)), (1920, 1080, (1080, 1920)),
+                                        (300, 900, 640))):
+    """byte-exact vs PIL LANCZOS letterbox (ref:util/yolov9.py:73-87)."""
+    from PIL import Image
+    from oracle import detector_ref as D
+    out = {}
+    rng = np.random.default_rng(0)
+    V = 4 if dtype == L.F32 else 8
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    for (iw, ih, imgsz) in sizes:
+        img = rng.integers(0, 256, size=(ih, iw, 3), dtype=np.uint8)
+        # add structure (edges) so ringing / clipping paths are exercised
+        img[ih // 4:ih // 2, iw // 4:iw // 2] = 255
+        img[ih // 2:, : iw // 3] = 0
+        ref, scale, pl, pt = D.preprocess(Image.fromarray(img), imgsz)
+        tw, th, scale, rw, rh, pad_left, pad_top = D.letterbox_geometry(iw, ih, imgsz)
+        need_h, need_v = int(rw != iw), int(rh != ih)
+        dimg = torch.from_numpy(img).to(DEV)
+        tmp = torch.zeros((ih, rw, 3), dtype=torch.uint8, device=DEV)
+        y = torch.zeros((1, th, tw, V), dtype=tdt, device=DEV)
+        keep = []
+        def up(a):
+            t = torch.from_numpy(a).to(DEV); keep.append(t); return t
+        xb = xk = yb = yk = None; kx = ky = 0
+        if need_h:
+            b, k = L.resample_coeffs(iw, rw, 0); xb, xk, kx = up(b), up(k), k.shape[1]
+        if need_v:
+            b, k = L.resample_coeffs(ih, rh, 0); yb, yk, ky = up(b), up(k), k.shape[1]
+        op = L.make_op(L.OP_LETTERBOX, dtype,
+                       p=[dimg.data_ptr(), tmp.data_ptr(), xb.data_ptr() if need_h else None,
+                          xk.data_ptr() if need_h else None, y.data_ptr(),
+                          yb.data_ptr() if need_v else None, yk.data_ptr() if need_v else None],
+                       i={0: ih, 1: iw, 2: rh, 3: rw, 4: kx, 5: ky, 6: th, 7: tw, 8: pad_left, 9: pad_top,
+                          10: need_h, 11: need_v, 12: 0, 13: V})
+        L.launch(op); _sync()
+        got = y[0, :, :, :3].float().cpu().permute(2, 0, 1)
+        if dtype == L.F32:
+            nbad = int((got != ref[0]).sum())
+        else:
+            nbad = int(((got - ref[0]).abs() > 1e-3).sum())
+        assert (y[..., 3:] == 0).all()
+        out[f"{iw}x{ih}->{imgsz}"] = nbad
+        assert nbad == 0, f"letterbox {iw}x{ih}->{imgsz}: {nbad} differing values"
+    return out
+
+
+# ------------------------------------------------------------------------------------------ decode + nms
+def _run_post(heads_cpu, nc, th, tw, conf, iou, max_det, iw, ih, scale, pad_left, pad_top, dtype=L.F32):
+    """heads_cpu: list of (cls [1,nc,h,w], boxlogits [1,64,h,w]) fp32 CPU tensors."""
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    esz = 4 if dtype == L.F32 else 2
+    views = []
+    for cls, box in heads_cpu:
+        views.append((_nhwc(cls, tdt), _nhwc(box, tdt)))
+    A = sum((th // s) * (tw // s) for s in (8, 16, 32))
+    cand = torch.zeros(A * L.CAND_BYTES, dtype=torch.uint8, device=DEV)
+    count = torch.zeros(1, dtype=torch.int32, device=DEV)
+    srt = torch.zeros((A + 1) * L.CAND_BYTES, dtype=torch.uint8, device=DEV)
+    mask = torch.empty(A * ((A + 63) // 64), dtype=torch.int64, device=DEV)
+    ob = torch.zeros(max_det, 4, device=DEV); osc = torch.zeros(max_det, device=DEV)
+    oc = torch.zeros(max_det, dtype=torch.int32, device=DEV); on = torch.zeros(1, dtype=torch.int32, device=DEV)
+    op1 = L.make_op(L.OP_DETECT_DECODE, dtype,
+                    p=[views[0][0].ptr, views[1][0].ptr, views[2][0].ptr, views[0][1].ptr, views[1][1].ptr,
+                       views[2][1].ptr, cand.data_ptr(), count.data_ptr()],
+                    i={0: nc, 1: th, 2: tw, 3: nc, 4: nc, 5: nc, 6: 64, 7: 64, 8: 64, 9: A, 10: pad_left, 11: pad_top,
+                       12: 0}, f={0: conf, 1: scale})
+    op2 = L.make_op(L.OP_NMS, dtype,
+                    p=[cand.data_ptr(), count.data_ptr(), srt.data_ptr(), mask.data_ptr(), ob.data_ptr(),
+                       osc.data_ptr(), oc.data_ptr(), on.data_ptr()],
+                    i={0: A, 1: max_det, 2: iw, 3: ih}, f={0: iou})
+    L.launch(op1); L.launch(op2); _sync()
+    k = int(on.item()); n = int(count.item())
+    return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long(), n
+
+
+def _oracle_post(heads_cpu, conf, iou, max_det, iw, ih, scale, pad_left, pad_top):
+    from oracle import detector_ref as D
+    from oracle.yolov9e_ref import DetectHead
+    proj = torch.arange(16, dtype=torch.float32)
+    outs = []
+    for cls, box in heads_cpu:
+        b, _, h, w = box.shape
+        dist = (box.view(b, 4, 16, h, w).softmax(2) * proj.view(1, 1, -1, 1, 1)).sum(2)
+        outs += [cls, dist]
+    class_scores, boxes = D.decode(outs)
+    scores, class_ids = class_scores[0].max(dim=-1)
+    valid = scores > conf
+    scores, class_ids, boxes = scores[valid], class_ids[valid], boxes[0][valid]
+    boxes[:, [0, 2]] = (boxes[:, [0, 2]] - pad_left) / scale
+    boxes[:, [1, 3]] = (boxes[:, [1, 3]] - pad_top) / scale
+    keep = D.batched_nms(boxes, scores, class_ids, iou)[:max_det]
+    boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
+    boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, iw)
+    boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, ih)
+    return boxes, scores, class_ids, int(valid.sum())
+
+
+def box_iou_pairs(a, b):
+    x1 = torch.maximum(a[:, 0], b[:, 0]); y1 = torch.maximum(a[:, 1], b[:, 1])
+    x2 = torch.minimum(a[:, 2], b[:, 2]); y2 = torch.minimum(a[:, 3], b[:, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return inter / (aa + ab - inter).clamp_min(1e-12)
+
+
+def check_post(seed=0, nc=1, th=160, tw=192, frac=0.08, conf=0.05, iou=0.1, max_det=300, spread=1.0):
+    """random head tensors -> GPU decode+NMS vs oracle restatement of ref:util/yolov9.py:89-136."""
+    g = torch.Generator().manual_seed(seed)
+    heads = []
+    for s in (8, 16, 32):
+        h, w = th // s, tw // s
+        cls = torch.randn(1, nc, h, w, generator=g) * 1.5
+        box = torch.randn(1, 64, h, w, generator=g) * spread
+        heads.append((cls, box))
+    # shift so ~frac of anchors pass
+    allmax = torch.cat([c.flatten(2).max(1).values.flatten() for c, _ in heads])
+    q = torch.quantile(allmax, 1 - frac).item()
+    shift = math.log(conf / (1 - conf)) - q
+    heads = [(c + shift, b) for c, b in heads]
+    iw, ih = 1000, 700
+    scale = min(tw / iw, th / ih)
+    rw, rh = int(iw * scale), int(ih * scale)
+    pad_left, pad_top = (tw - rw) // 2, (th - rh) // 2
+    gb, gs, gc, n_gpu = _run_post(heads, nc, th, tw, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
+    rb, rs, rc, n_ref = _oracle_post(heads, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
+    assert n_gpu == n_ref, f"candidate count {n_gpu} != {n_ref}"
+    assert len(gb) == len(rb), f"kept {len(gb)} != {len(rb)}"
+    assert (gc == rc).all(), "class ids differ"
+    assert torch.allclose(gs, rs, rtol=0, atol=2e-7), f"scores differ {(gs - rs).abs().max()}"
+    miou = box_iou_pairs(gb, rb).min().item() if len(gb) else 1.0
+    assert miou >= 0.999, f"min IoU {miou}"
+    return {"candidates": n_gpu, "kept": len(gb), "min_iou": miou,
+            "max_box_abs_diff": (gb - rb).abs().max().item() if len(gb) else 0.0,
+            "bitwise_boxes": bool((gb == rb).all())}
+
+
+def check_nms_known_answers():
+    """hand-built cases through the NMS kernel only (N tier of SURVEY 7.5)."""
+    from oracle import detector_ref as D
+    res = {}
+
+    def run(boxes, scores, cls, iou, max_det=300, iw=10000, ih=10000):
+        n = len(scores)
+        cap = max(n, 1)
+        rec = np.zeros((cap + 1, 8), dtype=np.float32)
+        rec[:n, 0:4] = boxes
+        rec[:n, 4] = scores
+        rec_i = rec.view(np.int32)
+        rec_i[:n, 5] = cls
+        rec_i[:n, 6] = np.arange(n)
+        cand = torch.from_numpy(rec[:cap].copy()).to(DEV)
+        count = torch.tensor([n], dtype=torch.int32, device=DEV)
+        srt = torch.zeros((cap + 1) * 8, dtype=torch.float32, device=DEV)
+        mask = torch.empty(cap * ((cap + 63) // 64), dtype=torch.int64, device=DEV)
+        ob = torch.zeros(max_det, 4, device=DEV); osc = torch.zeros(max_det, device=DEV)
+        oc = torch.zeros(max_det, dtype=torch.int32, device=DEV); on = torch.zeros(1, dtype=torch.int32, device=DEV)
+        op = L.make_op(L.OP_NMS, L.F32, p=[cand.data_ptr(), count.data_ptr(), srt.data_ptr(), mask.data_ptr(),
+                                           ob.data_ptr(), osc.data_ptr(), oc.data_ptr(), on.data_ptr()],
+                       i={0: cap, 1: max_det, 2: iw, 3: ih}, f={0: iou})
+        L.launch(op); _sync()
+        k = int(on.item())
+        return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long()
+
+    def ref(boxes, scores, cls, iou, max_det=300, iw=10000, ih=10000):
+        b = torch.tensor(boxes, dtype=torch.float32).view(-1, 4); s = torch.tensor(scores, dtype=torch.float32)
+        c = torch.tensor(cls, dtype=torch.int64)
+        keep = D.batched_nms(b, s, c, iou)[:max_det]
+        b = b[keep].clone()
+        b[:, [0, 2]] = b[:, [0, 2]].clamp(0, iw); b[:, [1, 3]] = b[:, [1, 3]].clamp(0, ih)
+        return b, s[keep], c[keep]
+
+    cases = {}
+    # ties in score -> stable (index) order
+    cases["ties"] = ([[0, 0, 10, 10], [100, 100, 110, 110], [200, 200, 210, 210], [0, 0, 10, 10]], [0.5, 0.5, 0.5, 0.5], [0, 0, 0, 0], 0.5)
+    # IoU exactly at threshold: [0,0,10,10] vs [0,0,10,5] -> IoU 0.5 -> NOT suppressed (strict >)
+    cases["strict_threshold"] = ([[0, 0, 10, 10], [0, 0, 10, 5]], [0.9, 0.8], [0, 0], 0.5)
+    # zero-area boxes
+    cases["zero_area"] = ([[5, 5, 5, 5], [5, 5, 5, 5], [0, 0, 10, 10]], [0.9, 0.8, 0.7], [0, 0, 0], 0.1)
+    # two classes overlapping fully: both survive
+    cases["two_classes"] = ([[0, 0, 10, 10], [0, 0, 10, 10], [1, 1, 9, 9]], [0.9, 0.8, 0.7], [0, 1, 0], 0.1)
+    # boxes outside the image: clamp after NMS
+    cases["outside"] = ([[-50, -20, 30, 40], [9990, 9990, 10050, 10020], [-45, -18, 28, 38]], [0.9, 0.8, 0.7], [0, 0, 0], 0.3)
+    for name, (b, s, c, iou) in cases.items():
+        gb, gs, gc = run(np.asarray(b, dtype=np.float32), np.asarray(s, dtype=np.float32), np.asarray(c), iou)
+        rb, rs, rc = ref(b, s, c, iou)
+        assert len(gb) == len(rb) and (gb == rb).all() and (gs == rs).all() and (gc == rc).all(), \
+            f"NMS known-answer '{name}' mismatch: gpu {gb.tolist()} ref {rb.tolist()}"
+        res[name] = len(gb)
+    # random clouds: N > 300 keeps, N > 1000 (per-class dispatch), multi-class, many blocks
+    rng = np.random.default_rng(0)
+    for name, n, ncls, iou, extent in (("rand_500_trick", 500, 3, 0.1, 2000), ("rand_1500_vanilla", 1500, 3, 0.3, 6000),
+                                       ("rand_5000_dense", 5000, 1, 0.5, 3000), ("rand_700_keepall", 700, 2, 0.9, 50000)):
+        xy = rng.uniform(0, extent, size=(n, 2)).astype(np.float32)
+        wh = rng.uniform(5, 120, size=(n, 2)).astype(np.float32)
+        b = np.concatenate([xy, xy + wh], 1).astype(np.float32)
+        s = rng.uniform(0.05, 1.0, size=n).astype(np.float32)
+        s[rng.integers(0, n, size=n // 10)] = 0.5          # score ties
+        c = rng.integers(0, ncls, size=n)
+        gb, gs, gc = run(b, s, c, iou, iw=extent, ih=extent)
+        rb, rs, rc = ref(b, s, c, iou, iw=extent, ih=extent)
+        assert len(gb) == len(rb), f"{name}: kept {len(gb)} vs {len(rb)}"
+        assert (gb == rb).all() and (gs == rs).all() and (gc == rc).all(), f"{name}: keep-list differs"
+        res[name] = len(gb)
+    return res
+
+
+# ------------------------------------------------------------------------------------------ whole detector
+def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, precision="f32", conf=0.05, iou=0.1,
+                   with_f64=True, iw=1920, ih=1080):
+    """GPU detector (ref:util/yolov9.py API) vs oracle.detector_ref.predict on the same TorchScript blob."""
+    import copy
+    from PIL import Image
+    from oracle import detector_ref as D
+    from omniparser_amd.synth import synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob
+    blob_path = ensure_blob(seed=seed, nc=nc, width=width)
+    cpu_model = torch.jit.load(str(blob_path), map_location="cpu").eval()
+    det = YOLOv9Detector(model_path=blob_path, device="cuda", precision=precision)
+    out = {"images": []}
+    for s in image_seeds:
+        img = synthetic_screenshot(s, iw, ih)
+        pil = Image.fromarray(img)
+        rb, rs, rc, dbg = D.predict(cpu_model, pil, conf=conf, imgsz=imgsz, iou=iou, return_debug=True)
+        res = det.predict(pil, conf=conf, imgsz=imgsz, iou=iou)[0]
+        gb, gs, gc = res.boxes.xyxy.cpu(), res.boxes.conf.cpu(), res.boxes.cls.cpu()
+        dp = det.get_plan(iw, ih, imgsz, conf, iou, 300)
+        # network-level comparison (cls logits + DFL distances)
+        with torch.inference_mode():
+            ref_out = cpu_model(dbg["input"])
+        proj = torch.arange(16, dtype=torch.float32)
+        errs, noise = [], []
+        ref64 = None
+        if with_f64:
+            from oracle.yolov9e_ref import YOLOv9E
+            m64 = YOLOv9E(nc=nc, width=width).double()
+            m64.load_state_dict({k: v.double() for k, v in cpu_model.state_dict().items()}, strict=False)
+            m64.eval()
+            with torch.inference_mode():
+                ref64 = m64(dbg["input"].double())
+        for i, (cls, box) in enumerate(dp.heads):
+            c = cls.torch().cpu()
+            bl = box.torch().cpu()
+            b, _, h, w = bl.shape
+            d = (bl.view(b, 4, 16, h, w).softmax(2) * proj.view(1, 1, -1, 1, 1)).sum(2)
+            errs.append(((c - ref_out[2 * i]).abs().max().item(), (d - ref_out[2 * i + 1]).abs().max().item()))
+            if ref64 is not None:
+                noise.append(((ref_out[2 * i].double() - ref64[2 * i]).abs().max().item(),
+                              (ref_out[2 * i + 1].double() - ref64[2 * i + 1]).abs().max().item(),
+                              (c.double() - ref64[2 * i]).abs().max().item()))
+        # input tensor parity (letterbox)
+        xin = dp.x.t[0, :, :, :3].float().cpu().permute(2, 0, 1)
+        in_bad = int((xin != dbg["input"][0]).sum()) if precision == "f32" else int(((xin - dbg["input"][0]).abs() > 1e-3).sum())
+        rec = {"seed": s, "n_ref": len(rb), "n_gpu": len(gb), "input_mismatch": in_bad, "head_err(cls,dist)": errs,
+               "oracle_noise(cls,dist,gpu_vs_f64)": noise, "cand_ref": int(dbg["valid"].sum())}
+        if len(rb) == len(gb) and len(rb) > 0:
+            rec["min_iou"] = box_iou_pairs(gb, rb).min().item()
+            rec["max_score_diff"] = (gs - rs).abs().max().item()
+            rec["cls_equal"] = bool((gc == rc).all())
+        else:
+            # order-free matching for diagnostics
+            rec["min_iou"] = None
+        out["images"].append(rec)
+    out["ops"] = dp.n_ops
+    out["net_gflop"] = dp.net_flops / 1e9
+    return out, det

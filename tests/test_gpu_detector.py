@@ -1,0 +1,39 @@
+"""`-m gpu`: the whole detector stage behind the reference API vs the oracle (tier D of SURVEY 7.5)."""
+import pytest
+
+pytestmark = pytest.mark.gpu
+
+
+def _assert_network_within_oracle_noise(rec, factor=10.0):
+    """GPU-vs-CPU(f32) head error must be of the order of the CPU's own f32-vs-f64 rounding noise
+    (the seeded random BN net is chaotic — see oracle/yolov9e_ref.py)."""
+    for (e_cls, e_dist), (n_cls, n_dist, _) in zip(rec["head_err(cls,dist)"], rec["oracle_noise(cls,dist,gpu_vs_f64)"]):
+        assert e_cls <= factor * n_cls + 1e-4, rec
+        assert e_dist <= factor * n_dist + 1e-4, rec
+
+
+def test_detector_half_width_640():
+    import gpu_checks as G
+    out, det = G.check_detector(width=0.5, image_seeds=(0, 1, 2), imgsz=640)
+    for rec in out["images"]:
+        assert rec["input_mismatch"] == 0          # letterboxed pixels byte-exact vs PIL
+        _assert_network_within_oracle_noise(rec)
+
+
+def test_detector_native_resolution_path():
+    """scale_img=True path: 1080x1920 -> 1088x1920 network input, no resample (Pillow same-size copy)."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=0.25, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
+    rec = out["images"][0]
+    assert rec["input_mismatch"] == 0
+    _assert_network_within_oracle_noise(rec)
+
+
+def test_detector_full_width_boxes():
+    """Full YOLOv9-E: boxes/keep-list vs oracle on frames where the oracle itself is well conditioned."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=1.0, image_seeds=(0, 1), imgsz=640)
+    for rec in out["images"]:
+        assert rec["input_mismatch"] == 0
+        _assert_network_within_oracle_noise(rec)
+    print(out)

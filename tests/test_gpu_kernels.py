@@ -1,0 +1,49 @@
+"""`-m gpu` parity tests of the HIP kernels, driven through the C ABI (see tests/gpu_checks.py)."""
+import pytest
+
+from omniparser_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+def test_mfma_fragment_layout():
+    import gpu_checks as G
+    G.check_mfma_layout()
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_conv_igemm(dtype):
+    import gpu_checks as G
+    r = G.check_conv(dtype)
+    assert r["cases"] >= 6
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_pool_and_resize(dtype):
+    import gpu_checks as G
+    G.check_pools(dtype)
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_letterbox_matches_pillow(dtype):
+    import gpu_checks as G
+    G.check_letterbox(dtype)
+
+
+@pytest.mark.parametrize("seed,nc,frac", [(0, 1, 0.08), (1, 3, 0.05), (2, 1, 0.6), (3, 2, 0.002)])
+def test_decode_nms_vs_oracle(seed, nc, frac):
+    import gpu_checks as G
+    r = G.check_post(seed=seed, nc=nc, frac=frac)
+    assert r["min_iou"] >= 0.999
+
+
+def test_decode_nms_native_size():
+    """A = 42 840 anchors (1088x1920 network input), thousands of candidates."""
+    import gpu_checks as G
+    r = G.check_post(seed=5, nc=1, th=1088, tw=1920, frac=0.05)
+    assert r["candidates"] > 1500
+
+
+def test_nms_known_answers():
+    import gpu_checks as G
+    G.check_nms_known_answers()
