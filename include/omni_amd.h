@@ -65,7 +65,7 @@ enum {
    *  p3 residual [M,ldr] or NULL   p4 y [B,Ho,Wo,ldo]
    *  i0 B i1 H i2 W i3 Cin i4 ldi i5 in_coff i6 KH i7 KW i8 stride i9 pad i10 Ho i11 Wo
    *  i12 Cout i13 ldo i14 out_coff i15 act i16 ldr i17 res_coff
-   *  i18 accumulate-into-y flag (y += result, applied before act)   f0 output scale (0 => 1) */
+   *  p5 optional split-K workspace (f32), i19 its size in KiB   f0 output scale (0 => 1) */
   OMNI_OP_CONV = 1,
   /* avg_pool2d(k=2,s=1,p=0) (ADown, ref blob T1).  p0 x, p4 y.
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */

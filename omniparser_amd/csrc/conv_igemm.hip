@@ -19,7 +19,10 @@
 //   * K order inside a slice is permuted for the f32 path (lane-half h supplies k = 4h..4h+3 of
 //     each 8-wide group): A and W use the same permutation so the contraction is unchanged while
 //     one ds_read_b128 feeds four MFMAs.
-//   * next slice is prefetched into registers while the current one is multiplied.
+//   * two LDS stages, one barrier per K slice; the next slice's global loads are issued before the
+//     MFMAs of the current one and written to the other stage after them.
+//   * split-K (f32 partials in a caller-provided workspace + a fixed-order reduce kernel that applies
+//     bias/act/residual) fills the 256 CUs when M*Cout is small (P4/P5 layers at batch 1).
 //   * concat / chunk are zero-copy: in_coff/ldi and out_coff/ldo address channel slices.
 #include "omni_internal.h"
 
@@ -30,6 +33,8 @@ struct ConvArgs {
   int B, H, W, Cin, ldi, in_coff, KH, KW, stride, pad, Ho, Wo;
   int Cout, ldo, out_coff, act, ldr, res_coff;
   int M, K, ktiles, cin_tiles;
+  int splits, kt_per_split;
+  float* ws; long long ws_bytes;
   float scale;
 };
 
@@ -44,19 +49,20 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-template <typename T, int BM, int BN, bool ALIGNED>
+template <typename T, int BM, int BN, int RB, bool ALIGNED>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int V = ElemTraits<T>::kVec;   // elements per 16-byte vector
-  constexpr int BKE = 4 * V;               // elements per 64-byte K slice
-  constexpr int ROWB = 80;                 // padded LDS row (bytes)
-  constexpr int A_IT = BM / 64;
-  constexpr int B_IT = BN / 64;
+  constexpr int VPR = RB / 16;             // 16-byte vectors per K-slice row
+  constexpr int BKE = VPR * V;             // elements per K slice
+  constexpr int ROWB = RB + 16;            // padded LDS row (bytes): conflict-free ds_read_b128
+  constexpr int RPP = 256 / VPR;           // tile rows staged per pass of the 256 threads
+  constexpr int A_IT = BM / RPP;
+  constexpr int B_IT = BN / RPP;
   constexpr int TM = BM / 64;              // 32x32 tiles per wave along M
   constexpr int TN = BN / 64;
+  constexpr int STAGE = (BM + BN) * ROWB;
 
-  __shared__ __attribute__((aligned(16))) unsigned char lds[(BM + BN) * ROWB];
-  unsigned char* ldsA = lds;
-  unsigned char* ldsB = lds + BM * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x;
   const int lane = tid & 63;
@@ -64,8 +70,12 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int wm = wave >> 1, wn = wave & 1;
   const int m0 = blockIdx.x * BM;
   const int n0 = blockIdx.y * BN;
-  const int vec = tid & 3;
-  const int r0 = tid >> 2;
+  const int vec = tid % VPR;
+  const int r0 = tid / VPR;
+
+  // split-K: this block owns K slices [kt0, kt1)
+  const int kt0 = blockIdx.z * a.kt_per_split;
+  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
 
   const T* __restrict__ X = reinterpret_cast<const T*>(a.x);
   const T* __restrict__ Wt = reinterpret_cast<const T*>(a.w);
@@ -75,7 +85,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   bool a_ok[A_IT];
 #pragma unroll
   for (int it = 0; it < A_IT; ++it) {
-    int m = m0 + r0 + it * 64;
+    int m = m0 + r0 + it * RPP;
     a_ok[it] = m < a.M;
     int mm = a_ok[it] ? m : 0;
     int wo = mm % a.Wo;
@@ -90,7 +100,7 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   bool b_ok[B_IT];
 #pragma unroll
   for (int it = 0; it < B_IT; ++it) {
-    int n = n0 + r0 + it * 64;
+    int n = n0 + r0 + it * RPP;
     b_ok[it] = n < a.Cout;
     b_ptr[it] = Wt + (long long)(b_ok[it] ? n : 0) * a.K;
   }
@@ -134,6 +144,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
       }
     }
   };
+  auto store_tile = [&](int stage) {
+    unsigned char* sA = lds + stage * STAGE;
+    unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it)
+      *reinterpret_cast<u32x4*>(sA + (r0 + it * RPP) * ROWB + vec * 16) = ra[it];
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -143,29 +163,28 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  load_tile(0);
   const int a_rd = (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
-  const int b_rd = (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_rd = BM * ROWB + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
 
-  for (int kt = 0; kt < a.ktiles; ++kt) {
+  if (kt0 < kt1) {
+    load_tile(kt0);
+    store_tile(0);
+  }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);          // global loads in flight under the MFMAs below
+    const unsigned char* st = lds + cur * STAGE;
 #pragma unroll
-    for (int it = 0; it < A_IT; ++it)
-      *reinterpret_cast<u32x4*>(ldsA + (r0 + it * 64) * ROWB + vec * 16) = ra[it];
-#pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      *reinterpret_cast<u32x4*>(ldsB + (r0 + it * 64) * ROWB + vec * 16) = rb[it];
-    __syncthreads();
-    if (kt + 1 < a.ktiles) load_tile(kt + 1);
-
-#pragma unroll
-    for (int kk = 0; kk < 2; ++kk) {
+    for (int kk = 0; kk < RB / 32; ++kk) {
       u32x4 av[TM], bv[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i)
-        av[i] = *reinterpret_cast<const u32x4*>(ldsA + a_rd + i * 32 * ROWB + kk * 32);
+        av[i] = *reinterpret_cast<const u32x4*>(st + a_rd + i * 32 * ROWB + kk * 32);
 #pragma unroll
       for (int j = 0; j < TN; ++j)
-        bv[j] = *reinterpret_cast<const u32x4*>(ldsB + b_rd + j * 32 * ROWB + kk * 32);
+        bv[j] = *reinterpret_cast<const u32x4*>(st + b_rd + j * 32 * ROWB + kk * 32);
       if constexpr (sizeof(T) == 4) {
         f32x4 af[TM], bf[TN];
 #pragma unroll
@@ -190,10 +209,31 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
                 __builtin_bit_cast(f16x8, av[i]), __builtin_bit_cast(f16x8, bv[j]), acc[i][j], 0, 0, 0);
       }
     }
+    if (more) store_tile(cur ^ 1);        // other stage: last read two iterations ago (barrier below orders it)
     __syncthreads();
+    cur ^= 1;
   }
 
   // epilogue: C/D layout of 32x32 MFMA: col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5)
+  if (a.splits > 1) {
+    // raw f32 partial sums -> workspace [split][M][Cout]; bias/act/residual happen in the reduce kernel
+    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (n >= a.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m < a.M) P[(long long)m * a.Cout + n] = acc[i][j][e];
+        }
+      }
+    }
+    return;
+  }
   T* __restrict__ Y = reinterpret_cast<T*>(a.y);
   const T* __restrict__ R = reinterpret_cast<const T*>(a.res);
   const float scale = a.scale;
@@ -220,31 +260,84 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   }
 }
 
-template <typename T, int BM, int BN>
+// split-K second pass: y = act(sum_z partial[z] + bias) (+ residual); fixed summation order.
+template <typename T>
+__global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
+  long long total = (long long)a.M * a.Cout;
+  long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= total) return;
+  int n = (int)(idx % a.Cout);
+  long long m = idx / a.Cout;
+  float v = 0.0f;
+  for (int z = 0; z < a.splits; ++z) v += a.ws[(long long)z * total + idx];
+  v += a.bias ? a.bias[n] : 0.0f;
+  if (a.scale != 0.0f) v *= a.scale;
+  v = act_apply(v, a.act);
+  if (a.res) v += ElemTraits<T>::to_f32(reinterpret_cast<const T*>(a.res)[m * a.ldr + a.res_coff + n]);
+  reinterpret_cast<T*>(a.y)[m * a.ldo + a.out_coff + n] = ElemTraits<T>::from_f32(v);
+}
+
+template <typename T, int BM, int BN, int RB>
 void launch_cfg(const ConvArgs& a, bool aligned, hipStream_t s) {
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, 1);
+  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.splits);
   if (aligned)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, true>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, false>), grid, dim3(256), 0, s, a);
+  if (a.splits > 1) {
+    long long total = (long long)a.M * a.Cout;
+    hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
+}
+
+struct ConvCfg { int bm, bn, rb, splits, kt_per_split, ktiles, cin_tiles; bool aligned; };
+
+// Tile / split-K choice.  MI355X has 256 CUs x 4 SIMDs; the f32 MFMA path hides its LDS + global
+// latency only with >= 3-4 waves per SIMD, i.e. >= ~1024 four-wave workgroups in flight, so small-M
+// layers (P4/P5 at batch 1: M = 1600 / 400) are split along K.
+template <typename T>
+ConvCfg choose_cfg(const ConvArgs& a) {
+  constexpr int V = ElemTraits<T>::kVec;
+  ConvCfg c;
+  c.rb = (a.Cin % (8 * V) == 0) ? 128 : 64;
+  int bke = (c.rb / 16) * V;
+  c.aligned = (a.Cin % bke) == 0;
+  c.cin_tiles = c.aligned ? a.Cin / bke : 1;
+  c.ktiles = (a.K + bke - 1) / bke;
+  c.bn = a.Cout > 64 ? 128 : 64;
+  c.bm = 128;
+  auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
+  if (blocks(c.bm, c.bn) < 1024 && c.bn == 128) c.bn = 64;
+  if (blocks(c.bm, c.bn) < 1024) c.bm = 64;
+  long long nb = blocks(c.bm, c.bn);
+  c.splits = 1;
+  if (nb < 768 && a.ws) {
+    int want = (int)((1024 + nb - 1) / nb);
+    int maxs = c.ktiles / 4;                 // keep >= 4 K slices per split
+    if (maxs > 32) maxs = 32;
+    long long cap = a.ws_bytes / ((long long)a.M * a.Cout * 4);
+    if (maxs > cap) maxs = (int)cap;
+    c.splits = want < maxs ? want : maxs;
+    if (c.splits < 2) c.splits = 1;
+  }
+  c.kt_per_split = (c.ktiles + c.splits - 1) / c.splits;
+  c.splits = (c.ktiles + c.kt_per_split - 1) / c.kt_per_split;   // no empty splits
+  return c;
 }
 
 template <typename T>
 void launch_typed(ConvArgs& a, hipStream_t s) {
-  constexpr int V = ElemTraits<T>::kVec;
-  constexpr int BKE = 4 * V;
-  bool aligned = (a.Cin % BKE) == 0;
-  a.cin_tiles = aligned ? a.Cin / BKE : 1;
-  a.ktiles = (a.K + BKE - 1) / BKE;
-  // tile choice: biggest tile that still yields >= ~2 workgroups per CU (256 CUs)
-  int bn = a.Cout > 64 ? 128 : 64;
-  int bm = 128;
-  auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
-  if (blocks(bm, bn) < 512 && bn == 128) bn = 64;
-  if (blocks(bm, bn) < 512) bm = 64;
-  if (bm == 128 && bn == 128) launch_cfg<T, 128, 128>(a, aligned, s);
-  else if (bm == 128 && bn == 64) launch_cfg<T, 128, 64>(a, aligned, s);
-  else launch_cfg<T, 64, 64>(a, aligned, s);
+  ConvCfg c = choose_cfg<T>(a);
+  a.cin_tiles = c.cin_tiles; a.ktiles = c.ktiles; a.splits = c.splits; a.kt_per_split = c.kt_per_split;
+  if (c.rb == 128) {
+    if (c.bm == 128 && c.bn == 128) launch_cfg<T, 128, 128, 128>(a, c.aligned, s);
+    else if (c.bm == 128 && c.bn == 64) launch_cfg<T, 128, 64, 128>(a, c.aligned, s);
+    else launch_cfg<T, 64, 64, 128>(a, c.aligned, s);
+  } else {
+    if (c.bm == 128 && c.bn == 128) launch_cfg<T, 128, 128, 64>(a, c.aligned, s);
+    else if (c.bm == 128 && c.bn == 64) launch_cfg<T, 128, 64, 64>(a, c.aligned, s);
+    else launch_cfg<T, 64, 64, 64>(a, c.aligned, s);
+  }
 }
 
 }  // namespace
@@ -257,6 +350,9 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   a.Cout = op->i[12]; a.ldo = op->i[13]; a.out_coff = op->i[14]; a.act = op->i[15];
   a.ldr = op->i[16]; a.res_coff = op->i[17];
   a.scale = op->f[0];
+  a.ws = (float*)op->p[5];
+  a.ws_bytes = a.ws ? (long long)op->i[19] * 1024 : 0;   // i19 = workspace size in KiB
+  a.splits = 1; a.kt_per_split = 0;
   const int V = op->dtype == OMNI_F32 ? 4 : 8;
   OMNI_REQUIRE(op->dtype == OMNI_F32 || op->dtype == OMNI_F16, "conv: bad dtype %d", op->dtype);
   OMNI_REQUIRE(a.x && a.w && a.y, "conv: null pointer");

@@ -52,6 +52,8 @@ class PlanBuilder:
         self.V = vec_width(dtype)
         self.ops = []
         self.keep = []           # keep-alive for every tensor referenced by raw pointer
+        self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
+        self.ws_kib = 32 * 1024
         self.flops = 0           # 2*MAC of all conv ops (algorithmic work, for the roofline)
         self.bytes = 0           # algorithmic HBM bytes (each operand read once, output written once)
 
@@ -97,13 +99,16 @@ class PlanBuilder:
             b = bias if bias.device == self.device and bias.dtype == torch.float32 else self.upload(bias.detach().float())
             self.keep.append(b)
             assert b.numel() == cout
+        if self.ws is None and self.device.type == "cuda":
+            self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
         op = L.make_op(
             L.OP_CONV, self.dtype,
             p=[x.ptr, w_packed.data_ptr(), b.data_ptr() if b is not None else None,
-               res.ptr if res is not None else None, out.ptr],
+               res.ptr if res is not None else None, out.ptr, self.ws.data_ptr() if self.ws is not None else None],
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
-               16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0},
+               16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
+               19: self.ws_kib if self.ws is not None else 0},
             f={0: scale})
         self.ops.append(op)
         self.keep.append(w_packed)
