@@ -98,9 +98,45 @@ enum {
    *  p4 out boxes f32[max_det,4] p5 out scores f32[max_det] p6 out cls i32[max_det] p7 out count i32[1]
    *  i0 cap i1 max_det i2 img_w i3 img_h ; f0 iou */
   OMNI_OP_NMS = 7,
-  /* depthwise 3x3 conv + bias + residual (DaViT conv_pos_enc). */
+  /* x + depthwise3x3(x) + bias (DaViT conv1/conv2, hf:models/florence2/modeling_florence2.py:432-436).
+   *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p4 y; i0 B i1 H i2 W i3 C */
   OMNI_OP_DWCONV3 = 8,
+  /* nn.LayerNorm over C (<= 1024) of x (+ add[row % period]) (hf florence2 :154-574, bart :272-341).
+   *  p0 x [rows,C] p1 add [period,C] or NULL p2 gamma f32 p3 beta f32 p4 y; i0*i1 rows i3 C i5 period; f0 eps */
   OMNI_OP_LAYERNORM = 9,
+  /* softmax(q k^T * scale) v, one query row per thread; mode 0 plain MHA (bart :143-257), mode 1 DaViT
+   * 12x12 window attention incl. the unmasked zero-padded window tokens (florence2 :338-398).
+   *  p0 q p1 k p2 v (token matrices) p4 o p5 kbias f32 p6 vbias f32 (window padding rows)
+   *  i0 ldq i1 ldk i2 ldv i3 ldo i4 qoff i5 koff i6 voff i7 ooff i8 heads i9 nq i10 nk i11 groups
+   *  i12 mode i13 H i14 W i15 head_dim (32|64); f0 scale */
+  OMNI_OP_ATTN_ROWS = 10,
+  /* DaViT grouped channel attention (florence2 :223-259): p0 qkv [B*N,3C] p4 o [B*N,C] p5 ws f32[B*G*chunks*1024]
+   *  i0 B i1 N i3 C i4 G i5 chunk_tokens; f0 scale (0 => N^-0.5) */
+  OMNI_OP_CHAN_ATTN = 11,
+  /* projector input (florence2 :568-590): y[b] = [mean_n(x+pos+t) ; x+pos+t]; p0 x [B,N,C] p1 pos2d f32[N,C] p2 temporal f32[C] p4 y [B,N+1,C]
+   *  i0 B i1 N i3 C */
+  OMNI_OP_PROJ_PREP = 12,
+  /* encoder input = [image features ; prompt embeddings] (florence2 :933-960): p0 img [B,n_img,C] p1 txt [n_txt,C] p4 y
+   *  i0 B i1 n_img i2 n_txt i3 C */
+  OMNI_OP_ASSEMBLE = 13,
+  /* decoder token embedding + learned position (bart :80-98): y[b] = table[ids[b][step]]*scale + pos[step+off]
+   *  p0 table p1 pos p2 ids i32[B,T] p4 y [B,C] p6 step i32*; i0 B i3 C i4 T i5 pos offset; f0 scale */
+  OMNI_OP_EMBED_STEP = 14,
+  /* single-query attention, head_dim 64: self (append k/v at `step` to the cache, attend 0..step) or cross
+   * (nk_fixed keys).  p0 q p1 knew p2 vnew p3 kcache [B,cap,C] p5 vcache p4 o [B,ldo] p6 step
+   *  i0 ldq i1 qoff i2 ldn i3 koff i4 voff i5 ldo i6 heads i7 nk_fixed i8 cap i9 C i10 B i11 cache row stride (0 => C); f0 scale */
+  OMNI_OP_ATTN_DECODE = 15,
+  /* greedy decoding step (hf:generation/utils.py:2783-2937 + logits_process NoRepeatNGram/ForcedBOS/ForcedEOS):
+   *  p0 logits [B,ldl] p1 final_logits_bias f32 or NULL p2 ids i32[B,T] p3 finished i32[B] p6 step i32*
+   *  i0 B i1 vocab i2 ldl i3 T i4 max_new_tokens i5 no_repeat_ngram i6 bos i7 eos i8 pad i9 forced_bos(-1)
+   *  i10 forced_eos(-1) i11 increment step afterwards */
+  OMNI_OP_GREEDY_STEP = 16,
+  /* crop -> cv2.resize 64x64 INTER_LINEAR -> [Pillow BICUBIC to RxR] -> rescale, normalise
+   * (ref:util/utils.py:97-105,120-123 + hf CLIP image processor).
+   *  p0 img u8 [H,W,3] p1 boxes i32[n,4] (x0,y0,x1,y1 px) p2 c64 u8[n,64,64,3] p3 tmp u8[n,64,R,3]
+   *  p4 y [n,R,R,ldo] p5 bounds i32[R,2] p6 coef i32[R,ksize] p7 lut f32[256]
+   *  i0 n i1 H i2 W i3 R i4 ksize i13 ldo; f0..2 mean f3..5 std */
+  OMNI_OP_CROP_RESIZE = 17,
   OMNI_OP__COUNT
 };
 

@@ -1,0 +1,723 @@
+// Florence-2 (DaViT + BART) kernels that are not GEMMs, for gfx950.  Token tensors are [rows, C]
+// (NHWC with the spatial dims flattened); linear layers go through conv_igemm.hip.
+//
+//   dwconv3        x + depthwise3x3(x) + bias           hf:models/florence2/modeling_florence2.py:432-436,296-300
+//   layernorm      nn.LayerNorm (optionally of x + table[row % period])   :154,281,292,417,428,574; bart:272-341
+//   attn_rows      softmax(q k^T * scale) v, one thread per query row, K/V tiles broadcast from LDS
+//                  mode 0: plain MHA (BART encoder)     hf:models/bart/modeling_bart.py:143-257
+//                  mode 1: DaViT 12x12 window attention with UNMASKED zero-padded windows (:338-398)
+//   chan_attn      DaViT grouped channel attention (:223-259): 32x32 score matrix per (image, group)
+//   proj_prep      + learned 2-D position + sinusoid(t=0), [mean token ; tokens]   (:568-590, 56-113)
+//   assemble       encoder input = [image features ; prompt embeddings]            (:933-960)
+//   embed_step     decoder token embedding + learned position (offset 2)           bart:80-98,594-640
+//   attn_decode    single-query attention with KV-cache append (self) / fixed K,V (cross)
+//   greedy_step    final_logits_bias + NoRepeatNGram + ForcedBOS/EOS + argmax + EOS/pad bookkeeping
+//                  hf:generation/utils.py:2783-2937, hf:generation/logits_process.py:1115-1139,1556,1601
+//   crop_resize    crop -> cv2.resize(64x64, INTER_LINEAR) -> [PIL BICUBIC to RxR] -> /255, normalise
+//                  ref:util/utils.py:97-105,120-123 + hf CLIP image processor
+// All softmax / LayerNorm statistics are f32; f16 tensors are converted on load.
+#include "omni_internal.h"
+
+#pragma clang fp contract(off)
+
+namespace {
+
+template <typename T> __device__ __forceinline__ float ldf(const T* p) { return ElemTraits<T>::to_f32(*p); }
+template <typename T> __device__ __forceinline__ void stf(T* p, float v) { *p = ElemTraits<T>::from_f32(v); }
+
+__device__ __forceinline__ float wave_sum(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+__device__ __forceinline__ float wave_max(float v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) v = fmaxf(v, __shfl_xor(v, o));
+  return v;
+}
+
+// ------------------------------------------------------------------------------------ dwconv3
+struct DwArgs { const void* x; const void* w; const float* bias; void* y; int B, H, W, C; long long total; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
+  // w layout: [3][3][C] (tap-major) in T; y = x + bias + sum_taps w*x   (conv(x) + x)
+  const T* __restrict__ X = (const T*)a.x;
+  const T* __restrict__ Wt = (const T*)a.w;
+  T* __restrict__ Y = (T*)a.y;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
+       idx += (long long)gridDim.x * blockDim.x) {
+    int c = (int)(idx % a.C);
+    long long pix = idx / a.C;
+    int w = (int)(pix % a.W);
+    long long t = pix / a.W;
+    int h = (int)(t % a.H);
+    long long b = t / a.H;
+    float acc = 0.0f;
+#pragma unroll
+    for (int r = 0; r < 3; ++r) {
+      int hi = h + r - 1;
+      if (hi < 0 || hi >= a.H) continue;
+#pragma unroll
+      for (int s = 0; s < 3; ++s) {
+        int wi = w + s - 1;
+        if (wi < 0 || wi >= a.W) continue;
+        acc += ldf(Wt + (r * 3 + s) * a.C + c) * ldf(X + ((b * a.H + hi) * a.W + wi) * a.C + c);
+      }
+    }
+    acc += a.bias[c];
+    stf(Y + idx, acc + ldf(X + idx));
+  }
+}
+
+// ------------------------------------------------------------------------------------ layernorm
+struct LnArgs { const void* x; const void* add; const float* g; const float* b; void* y; long long rows; int C, period; float eps; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
+  // one wave per row; two-pass mean / variance in f32 (row cached in registers, C <= 64*16)
+  const int lane = threadIdx.x & 63;
+  const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (row >= a.rows) return;
+  const T* x = (const T*)a.x + row * a.C;
+  const T* ad = a.add ? (const T*)a.add + (row % a.period) * a.C : nullptr;
+  float v[16];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + i * 64;
+    float t = 0.0f;
+    if (c < a.C) { t = ldf(x + c); if (ad) t += ldf(ad + c); }
+    v[i] = t; s += t;
+  }
+  float mean = wave_sum(s) / (float)a.C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + i * 64;
+    if (c < a.C) { float d = v[i] - mean; q += d * d; }
+  }
+  float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.C + a.eps);
+  T* y = (T*)a.y + row * a.C;
+#pragma unroll
+  for (int i = 0; i < 16; ++i) {
+    int c = lane + i * 64;
+    if (c < a.C) stf(y + c, (v[i] - mean) * rstd * a.g[c] + a.b[c]);
+  }
+}
+
+// ------------------------------------------------------------------------------------ attn_rows
+struct AttnArgs {
+  const void* q; const void* k; const void* v; void* o; const float* kbias; const float* vbias;
+  int ldq, ldk, ldv, ldo, qoff, koff, voff, ooff;   // element strides / channel offsets
+  int heads, nq, nk, groups;                         // per group: nq queries, nk keys
+  int mode, H, W, wy, wx;                            // window mode: image H x W, wy x wx windows of 12x12
+  float scale;
+};
+
+// token row (into the [B*H*W] token matrix) of window-local index i (0..143), or -1 for padding
+__device__ __forceinline__ long long window_row(const AttnArgs& a, int g, int i) {
+  int wpi = a.wy * a.wx;
+  int b = g / wpi, wrem = g - b * wpi;
+  int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
+  int r = wyi * 12 + i / 12, c = wxi * 12 + i % 12;
+  if (r >= a.H || c >= a.W) return -1;
+  return ((long long)b * a.H + r) * a.W + c;
+}
+
+template <typename T, int D>
+__global__ __launch_bounds__(128) void attn_rows_kernel(AttnArgs a) {
+  constexpr int KT = 32;                       // keys per LDS tile
+  __shared__ __attribute__((aligned(16))) float sk[KT][D];
+  __shared__ __attribute__((aligned(16))) float sv[KT][D];
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int qi = blockIdx.x * 128 + threadIdx.x;
+  const T* Q = (const T*)a.q; const T* K = (const T*)a.k; const T* V = (const T*)a.v;
+  long long qrow = -1;
+  if (qi < a.nq) qrow = a.mode == 1 ? window_row(a, g, qi) : (long long)g * a.nq + qi;
+  float q[D], o[D];
+#pragma unroll
+  for (int d = 0; d < D; ++d) { q[d] = qrow >= 0 ? ldf(Q + qrow * a.ldq + a.qoff + h * D + d) : 0.0f; o[d] = 0.0f; }
+  float m = -INFINITY, l = 0.0f;
+  for (int k0 = 0; k0 < a.nk; k0 += KT) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < KT * D; e += 128) {
+      int kk = e / D, d = e - kk * D;
+      int ki = k0 + kk;
+      float kvv = 0.0f, vvv = 0.0f;
+      if (ki < a.nk) {
+        long long krow = a.mode == 1 ? window_row(a, g, ki) : (long long)g * a.nk + ki;
+        if (krow >= 0) {
+          kvv = ldf(K + krow * a.ldk + a.koff + h * D + d);
+          vvv = ldf(V + krow * a.ldv + a.voff + h * D + d);
+        } else {            // zero-padded window token: qkv(0) = bias, NOT masked (hf :345,372-379)
+          kvv = a.kbias ? a.kbias[h * D + d] : 0.0f;
+          vvv = a.vbias ? a.vbias[h * D + d] : 0.0f;
+        }
+      }
+      sk[kk][d] = kvv; sv[kk][d] = vvv;
+    }
+    __syncthreads();
+    int lim = a.nk - k0 < KT ? a.nk - k0 : KT;
+    for (int kk = 0; kk < lim; ++kk) {
+      float s = 0.0f;
+#pragma unroll
+      for (int d = 0; d < D; ++d) s = fmaf(q[d], sk[kk][d], s);
+      s *= a.scale;
+      float mn = fmaxf(m, s);
+      float corr = expf(m - mn);
+      float p = expf(s - mn);
+      l = l * corr + p;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] = fmaf(p, sv[kk][d], o[d] * corr);
+      m = mn;
+    }
+  }
+  if (qrow >= 0) {
+    T* O = (T*)a.o + qrow * a.ldo + a.ooff + h * D;
+    float inv = 1.0f / l;
+#pragma unroll
+    for (int d = 0; d < D; ++d) stf(O + d, o[d] * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------ channel attention
+struct ChanArgs {
+  const void* qkv; void* o; float* ws;    // qkv [B*N, 3C]; ws [B][G][chunks][32][32]
+  int B, N, C, G, chunks, chunk_tokens; float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_scores_kernel(ChanArgs a) {
+  // partial S[i][j] = sum_{n in chunk} q[n][i] * k[n][j]   (i, j in 0..31) for one (b, g, chunk)
+  __shared__ float sq[64][33];
+  __shared__ float sk[64][33];
+  const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const T* base = (const T*)a.qkv + (long long)b * a.N * 3 * a.C;
+  const int i = threadIdx.x >> 3;            // 0..31
+  const int j0 = (threadIdx.x & 7) * 4;      // 4 consecutive j
+  float acc[4] = {0.f, 0.f, 0.f, 0.f};
+  int n0 = chunk * a.chunk_tokens;
+  int n1 = n0 + a.chunk_tokens < a.N ? n0 + a.chunk_tokens : a.N;
+  for (int t0 = n0; t0 < n1; t0 += 64) {
+    __syncthreads();
+    for (int e = threadIdx.x; e < 64 * 32; e += 256) {
+      int tt = e >> 5, c = e & 31;
+      int n = t0 + tt;
+      float qv = 0.f, kv = 0.f;
+      if (n < n1) {
+        const T* row = base + (long long)n * 3 * a.C;
+        qv = ldf(row + g * 32 + c);
+        kv = ldf(row + a.C + g * 32 + c);
+      }
+      sq[tt][c] = qv; sk[tt][c] = kv;
+    }
+    __syncthreads();
+#pragma unroll 8
+    for (int tt = 0; tt < 64; ++tt) {
+      float qv = sq[tt][i];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) acc[e] = fmaf(qv, sk[tt][j0 + e], acc[e]);
+    }
+  }
+  float* out = a.ws + ((((long long)b * a.G + g) * a.chunks + chunk) * 32 + i) * 32 + j0;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) out[e] = acc[e];
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void chan_apply_kernel(ChanArgs a) {
+  // A = softmax_j(scale * sum_chunks S) ; out[n][g*32+i] = sum_j A[i][j] v[n][g*32+j]
+  __shared__ float sa[32][33];
+  const int g = blockIdx.y, b = blockIdx.z;
+  {
+    int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
+    const float* p = a.ws + (((long long)b * a.G + g) * a.chunks * 32 + i) * 32 + j0;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.chunks; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += p[(long long)c * 1024 + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sa[i][j0 + e] = s[e] * a.scale;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    int i = threadIdx.x;
+    float mx = -INFINITY;
+    for (int j = 0; j < 32; ++j) mx = fmaxf(mx, sa[i][j]);
+    float sum = 0.f;
+    for (int j = 0; j < 32; ++j) { float e = expf(sa[i][j] - mx); sa[i][j] = e; sum += e; }
+    float inv = 1.0f / sum;
+    for (int j = 0; j < 32; ++j) sa[i][j] *= inv;
+  }
+  __syncthreads();
+  int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.N) return;
+  const T* vrow = (const T*)a.qkv + ((long long)b * a.N + n) * 3 * a.C + 2 * a.C + g * 32;
+  float v[32];
+#pragma unroll
+  for (int j = 0; j < 32; ++j) v[j] = ldf(vrow + j);
+  T* orow = (T*)a.o + ((long long)b * a.N + n) * a.C + g * 32;
+#pragma unroll 4
+  for (int i = 0; i < 32; ++i) {
+    float s = 0.f;
+#pragma unroll
+    for (int j = 0; j < 32; ++j) s = fmaf(sa[i][j], v[j], s);
+    stf(orow + i, s);
+  }
+}
+
+// ------------------------------------------------------------------------------------ small glue kernels
+struct PrepArgs { const void* x; const float* pos; const float* temporal; void* y; int B, N, C; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void proj_prep_kernel(PrepArgs a) {
+  // y[b][0][c] = mean_n(x[b][n][c] + pos[n][c]);  y[b][1+n][c] = x[b][n][c] + pos[n][c]
+  int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= a.C) return;
+  const T* x = (const T*)a.x + (long long)b * a.N * a.C + c;
+  T* y = (T*)a.y + (long long)b * (a.N + 1) * a.C + c;
+  float s = 0.f;
+  for (int n = 0; n < a.N; ++n) {
+    float v = (ldf(x + (long long)n * a.C) + a.pos[(long long)n * a.C + c]) + a.temporal[c];
+    s += v;
+    stf(y + (long long)(n + 1) * a.C, v);
+  }
+  stf(y, s / (float)a.N);
+}
+
+struct AsmArgs { const void* img; const void* txt; void* y; int B, n_img, n_txt, C; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void assemble_kernel(AsmArgs a) {
+  long long total = (long long)a.B * (a.n_img + a.n_txt) * a.C;
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= total) return;
+  int c = (int)(idx % a.C);
+  long long r = idx / a.C;
+  int t = (int)(r % (a.n_img + a.n_txt));
+  long long b = r / (a.n_img + a.n_txt);
+  const T* src = t < a.n_img ? (const T*)a.img + (b * a.n_img + t) * a.C + c : (const T*)a.txt + (long long)(t - a.n_img) * a.C + c;
+  ((T*)a.y)[idx] = *src;
+}
+
+struct EmbArgs { const void* table; const void* pos; const int* ids; const int* step; void* y; int B, C, T, pos_offset; float scale; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void embed_step_kernel(EmbArgs a) {
+  // y[b] = table[ids[b][step]] * scale + pos[step + offset]
+  int c = blockIdx.x * 256 + threadIdx.x, b = blockIdx.y;
+  if (c >= a.C) return;
+  int st = *a.step;
+  int tok = a.ids[b * a.T + st];
+  float v = ldf((const T*)a.table + (long long)tok * a.C + c);
+  if (a.scale != 1.0f) v *= a.scale;
+  v += ldf((const T*)a.pos + (long long)(st + a.pos_offset) * a.C + c);
+  stf((T*)a.y + (long long)b * a.C + c, v);
+}
+
+// ------------------------------------------------------------------------------------ attn_decode
+struct DecArgs {
+  const void* q; const void* knew; const void* vnew; void* kc; void* vc; void* o; const int* step;
+  int ldq, qoff, ldn, koff, voff, ldo;    // q [B, ldq]; new k/v rows in [B, ldn]
+  int heads, nk_fixed, cap, C, ldc;       // cache [B, cap, ldc]; nk_fixed > 0 => cross attention over nk_fixed keys
+  float scale;
+};
+
+template <typename T>
+__global__ __launch_bounds__(64) void attn_decode_kernel(DecArgs a) {
+  // one wave per (b, head), head_dim 64: lanes split keys for the scores, then split d for P.V
+  extern __shared__ float sp[];               // nk probabilities
+  const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int C = a.ldc;
+  int nk;
+  T* Kc = (T*)a.kc + (long long)b * a.cap * C + h * 64;
+  T* Vc = (T*)a.vc + (long long)b * a.cap * C + h * 64;
+  if (a.nk_fixed > 0) {
+    nk = a.nk_fixed;
+  } else {
+    int st = *a.step;
+    nk = st + 1;
+    // append this step's k, v (lane = d)
+    Kc[(long long)st * C + lane] = ((const T*)a.knew)[(long long)b * a.ldn + a.koff + h * 64 + lane];
+    Vc[(long long)st * C + lane] = ((const T*)a.vnew)[(long long)b * a.ldn + a.voff + h * 64 + lane];
+    __syncthreads();
+  }
+  float qd = ldf((const T*)a.q + (long long)b * a.ldq + a.qoff + h * 64 + lane);
+  __shared__ float sq[64];
+  sq[lane] = qd;
+  __syncthreads();
+  float mx = -INFINITY;
+  for (int k = lane; k < nk; k += 64) {
+    const T* kr = Kc + (long long)k * C;
+    float s = 0.f;
+#pragma unroll 16
+    for (int d = 0; d < 64; ++d) s += sq[d] * ldf(kr + d);
+    s *= a.scale;
+    sp[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  mx = wave_max(mx);
+  float sum = 0.f;
+  for (int k = lane; k < nk; k += 64) { float e = expf(sp[k] - mx); sp[k] = e; sum += e; }
+  sum = wave_sum(sum);
+  __syncthreads();
+  float acc = 0.f;
+  for (int k = 0; k < nk; ++k) acc += sp[k] * ldf(Vc + (long long)k * C + lane);
+  stf((T*)a.o + (long long)b * a.ldo + h * 64 + lane, acc / sum);
+}
+
+// ------------------------------------------------------------------------------------ greedy_step
+struct GreedyArgs {
+  const void* logits; const float* bias; int* ids; int* finished; const int* step;
+  int B, V, ldl, T, max_new, ngram, bos, eos, pad, forced_bos, forced_eos;
+};
+
+template <typename T>
+__global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs a) {
+  __shared__ float sval[256];
+  __shared__ int sidx[256];
+  __shared__ int banned[32];
+  __shared__ int nban;
+  const int b = blockIdx.x;
+  const int st = *a.step;              // tokens so far = st + 1 (ids[b][0..st]); we write ids[b][st+1]
+  int* ids = a.ids + b * a.T;
+  const int cur_len = st + 1;
+  if (threadIdx.x == 0) {
+    int nb = 0;
+    // NoRepeatNGram: ban tokens completing an n-gram already generated (incl. decoder start token)
+    if (a.ngram > 0 && cur_len + 1 >= a.ngram) {
+      int n = a.ngram;
+      for (int i = 0; i + n - 1 < cur_len; ++i) {
+        bool match = true;
+        for (int j = 0; j < n - 1; ++j)
+          if (ids[i + j] != ids[cur_len - (n - 1) + j]) { match = false; break; }
+        if (match && nb < 32) banned[nb++] = ids[i + n - 1];
+      }
+    }
+    nban = nb;
+  }
+  __syncthreads();
+  int forced = -1;
+  if (a.forced_bos >= 0 && cur_len == 1) forced = a.forced_bos;
+  if (a.forced_eos >= 0 && cur_len == a.max_new) forced = a.forced_eos;   // max_length - 1 == max_new (start token + max_new)
+  int tok;
+  if (forced >= 0) {
+    tok = forced;
+  } else {
+    const T* lg = (const T*)a.logits + (long long)b * a.ldl;
+    float best = -INFINITY; int bi = 0x7fffffff;
+    for (int v = threadIdx.x; v < a.V; v += 256) {
+      float x = ldf(lg + v) + (a.bias ? a.bias[v] : 0.0f);
+      for (int q = 0; q < nban; ++q) if (banned[q] == v) x = -INFINITY;
+      if (x > best) { best = x; bi = v; }      // first max within this thread's ascending stride
+    }
+    sval[threadIdx.x] = best; sidx[threadIdx.x] = bi;
+    __syncthreads();
+    for (int s = 128; s > 0; s >>= 1) {
+      if (threadIdx.x < s) {
+        float ov = sval[threadIdx.x + s]; int oi = sidx[threadIdx.x + s];
+        if (ov > sval[threadIdx.x] || (ov == sval[threadIdx.x] && oi < sidx[threadIdx.x])) {
+          sval[threadIdx.x] = ov; sidx[threadIdx.x] = oi;
+        }
+      }
+      __syncthreads();
+    }
+    tok = sidx[0];
+  }
+  if (threadIdx.x == 0) {
+    int fin = a.finished[b];
+    if (fin) tok = a.pad;                       // finished rows keep emitting pad (hf utils.py:2925-2929)
+    ids[st + 1] = tok;
+    if (!fin && tok == a.eos) a.finished[b] = 1;
+  }
+}
+
+__global__ void step_inc_kernel(int* step) { if (threadIdx.x == 0 && blockIdx.x == 0) *step += 1; }
+
+// ------------------------------------------------------------------------------------ crop_resize
+struct CropArgs {
+  const unsigned char* img; const int* boxes; unsigned char* c64; unsigned char* tmp; const int* b; const int* k;
+  void* y; const float* lut; int n, H, W, R, ksize, ldo; float mean[3], stdv[3];
+};
+
+__device__ __forceinline__ int cv_round_short(float v) {   // saturate_cast<short>(float): round half to even
+  float r = rintf(v);
+  r = fminf(fmaxf(r, -32768.f), 32767.f);
+  return (int)r;
+}
+
+__global__ __launch_bounds__(256) void crop_bilinear64_kernel(CropArgs a) {
+  // OpenCV resize INTER_LINEAR, 8UC3, fixed point (INTER_RESIZE_COEF_BITS = 11): SURVEY App. A.2
+  int idx = blockIdx.x * 256 + threadIdx.x;
+  int crop = blockIdx.y;
+  if (idx >= 64 * 64) return;
+  int dy = idx >> 6, dx = idx & 63;
+  int x0 = a.boxes[crop * 4 + 0], y0 = a.boxes[crop * 4 + 1], x1 = a.boxes[crop * 4 + 2], y1 = a.boxes[crop * 4 + 3];
+  int sw = x1 - x0, sh = y1 - y0;
+  unsigned char* dst = a.c64 + ((long long)crop * 4096 + idx) * 3;
+  if (sw <= 0 || sh <= 0) { dst[0] = dst[1] = dst[2] = 0; return; }
+  double scale_x = (double)sw / 64.0, scale_y = (double)sh / 64.0;
+  float fx = (float)((dx + 0.5) * scale_x - 0.5);
+  int sx = (int)floorf(fx); fx -= sx;
+  if (sx < 0) { fx = 0.f; sx = 0; }
+  if (sx >= sw - 1) { fx = 0.f; sx = sw - 1; }
+  // vertical: beta from the un-clamped fraction, source rows clipped to [0, sh-1] (cv::resize invoker)
+  float fy = (float)((dy + 0.5) * scale_y - 0.5);
+  int sy = (int)floorf(fy); fy -= sy;
+  int a0 = cv_round_short((1.f - fx) * 2048.f), a1 = cv_round_short(fx * 2048.f);
+  int b0 = cv_round_short((1.f - fy) * 2048.f), b1 = cv_round_short(fy * 2048.f);
+  int sx1 = sx + 1 < sw ? sx + 1 : sx;
+  int sy0c = sy < 0 ? 0 : (sy < sh ? sy : sh - 1);
+  int sy1c = sy + 1 < 0 ? 0 : (sy + 1 < sh ? sy + 1 : sh - 1);
+  const unsigned char* r0 = a.img + ((long long)(y0 + sy0c) * a.W + x0) * 3;
+  const unsigned char* r1 = a.img + ((long long)(y0 + sy1c) * a.W + x0) * 3;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    int S0 = r0[sx * 3 + c] * a0 + r0[sx1 * 3 + c] * a1;
+    int S1 = r1[sx * 3 + c] * a0 + r1[sx1 * 3 + c] * a1;
+    int v = (((b0 * (S0 >> 4)) >> 16) + ((b1 * (S1 >> 4)) >> 16) + 2) >> 2;
+    dst[c] = (unsigned char)(v < 0 ? 0 : (v > 255 ? 255 : v));
+  }
+}
+
+__device__ __forceinline__ int clip8b(int v) { v >>= 22; return v < 0 ? 0 : (v > 255 ? 255 : v); }
+
+__global__ __launch_bounds__(256) void bicubic_h_kernel(CropArgs a) {
+  // 64 -> R horizontal pass (Pillow 8bpc), per crop: tmp [n][64][R][3]
+  int idx = blockIdx.x * 256 + threadIdx.x, crop = blockIdx.y;
+  if (idx >= 64 * a.R) return;
+  int y = idx / a.R, xx = idx - y * a.R;
+  int xmin = a.b[xx * 2], cnt = a.b[xx * 2 + 1];
+  const int* k = a.k + (long long)xx * a.ksize;
+  const unsigned char* src = a.c64 + ((long long)crop * 4096 + y * 64 + xmin) * 3;
+  int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+  for (int x = 0; x < cnt; ++x) { int kk = k[x]; s0 += src[x * 3] * kk; s1 += src[x * 3 + 1] * kk; s2 += src[x * 3 + 2] * kk; }
+  unsigned char* d = a.tmp + ((long long)crop * 64 * a.R + idx) * 3;
+  d[0] = (unsigned char)clip8b(s0); d[1] = (unsigned char)clip8b(s1); d[2] = (unsigned char)clip8b(s2);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void bicubic_v_norm_kernel(CropArgs a) {
+  // vertical pass (same square tables) + rescale 1/255 + (x - mean) / std  ->  y [n][R][R][ldo]
+  long long idx = (long long)blockIdx.x * 256 + threadIdx.x;
+  int crop = blockIdx.y;
+  if (idx >= (long long)a.R * a.R) return;
+  int yy = (int)(idx / a.R), xx = (int)(idx - (long long)yy * a.R);
+  int p[3];
+  if (a.R == 64) {
+    const unsigned char* s = a.c64 + ((long long)crop * 4096 + idx) * 3;
+    p[0] = s[0]; p[1] = s[1]; p[2] = s[2];
+  } else {
+    int ymin = a.b[yy * 2], cnt = a.b[yy * 2 + 1];
+    const int* k = a.k + (long long)yy * a.ksize;
+    int s0 = 1 << 21, s1 = 1 << 21, s2 = 1 << 21;
+    for (int y = 0; y < cnt; ++y) {
+      const unsigned char* s = a.tmp + (((long long)crop * 64 + ymin + y) * a.R + xx) * 3;
+      int kk = k[y]; s0 += s[0] * kk; s1 += s[1] * kk; s2 += s[2] * kk;
+    }
+    p[0] = clip8b(s0); p[1] = clip8b(s1); p[2] = clip8b(s2);
+  }
+  T* out = (T*)a.y + ((long long)crop * a.R * a.R + idx) * a.ldo;
+#pragma unroll
+  for (int c = 0; c < 3; ++c) {
+    float v = a.lut[p[c]];      // f32(f64(p) * (1/255)): hf image_transforms.rescale, host-built table
+    stf(out + c, (v - a.mean[c]) / a.stdv[c]);
+  }
+  for (int c = 3; c < a.ldo; ++c) stf(out + c, 0.0f);
+}
+
+template <typename F32, typename F16>
+int by_dtype(int dtype, const char* name, F32 f32, F16 f16) {
+  if (dtype == OMNI_F32) f32();
+  else if (dtype == OMNI_F16) f16();
+  else { omni_set_error("%s: bad dtype %d", name, dtype); return OMNI_E_ARG; }
+  return OMNI_OK;
+}
+
+}  // namespace
+
+int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
+  DwArgs a;
+  a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
+  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
+  OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
+  a.total = (long long)a.B * a.H * a.W * a.C;
+  long long blocks = (a.total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  int rc = by_dtype(op->dtype, "dwconv3",
+      [&] { hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(dwconv3_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+int omni_launch_layernorm(const omni_op_t* op, hipStream_t s) {
+  LnArgs a;
+  a.x = op->p[0]; a.add = op->p[1]; a.g = (const float*)op->p[2]; a.b = (const float*)op->p[3]; a.y = op->p[4];
+  a.rows = ((long long)op->i[0]) * (op->i[1] > 0 ? op->i[1] : 1); a.C = op->i[3]; a.period = op->i[5] > 0 ? op->i[5] : 1;
+  a.eps = op->f[0];
+  OMNI_REQUIRE(a.x && a.g && a.b && a.y && a.rows > 0 && a.C > 0 && a.C <= 1024, "layernorm: bad arguments (C <= 1024)");
+  unsigned blocks = (unsigned)((a.rows + 3) / 4);
+  int rc = by_dtype(op->dtype, "layernorm",
+      [&] { hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(blocks), dim3(256), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
+  AttnArgs a;
+  a.q = op->p[0]; a.k = op->p[1]; a.v = op->p[2]; a.o = op->p[4];
+  a.kbias = (const float*)op->p[5]; a.vbias = (const float*)op->p[6];
+  a.ldq = op->i[0]; a.ldk = op->i[1]; a.ldv = op->i[2]; a.ldo = op->i[3];
+  a.qoff = op->i[4]; a.koff = op->i[5]; a.voff = op->i[6]; a.ooff = op->i[7];
+  a.heads = op->i[8]; a.nq = op->i[9]; a.nk = op->i[10]; a.groups = op->i[11];
+  a.mode = op->i[12]; a.H = op->i[13]; a.W = op->i[14];
+  int D = op->i[15];
+  a.scale = op->f[0];
+  OMNI_REQUIRE(a.q && a.k && a.v && a.o && a.heads > 0 && a.nq > 0 && a.nk > 0 && a.groups > 0, "attn_rows: bad arguments");
+  OMNI_REQUIRE(D == 32 || D == 64, "attn_rows: head_dim %d unsupported", D);
+  if (a.mode == 1) {
+    OMNI_REQUIRE(a.nq == 144 && a.nk == 144 && a.H > 0 && a.W > 0, "attn_rows: window mode needs 12x12 windows");
+    a.wy = (a.H + 11) / 12; a.wx = (a.W + 11) / 12;
+    OMNI_REQUIRE(a.groups % (a.wy * a.wx) == 0, "attn_rows: groups must be B * windows");
+  } else { a.wy = a.wx = 0; }
+  dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
+  int rc;
+  if (D == 32) rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32>), grid, dim3(128), 0, s, a); },
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32>), grid, dim3(128), 0, s, a); });
+  else rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 64>), grid, dim3(128), 0, s, a); },
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 64>), grid, dim3(128), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
+  ChanArgs a;
+  a.qkv = op->p[0]; a.o = op->p[4]; a.ws = (float*)op->p[5];
+  a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3]; a.G = op->i[4]; a.chunk_tokens = op->i[5];
+  OMNI_REQUIRE(a.qkv && a.o && a.ws && a.B > 0 && a.N > 0 && a.C == a.G * 32 && a.chunk_tokens > 0, "chan_attn: bad arguments");
+  a.chunks = (a.N + a.chunk_tokens - 1) / a.chunk_tokens;
+  a.scale = 1.0f / sqrtf((float)a.N);
+  if (op->f[0] != 0.0f) a.scale = op->f[0];
+  dim3 g1(a.chunks, a.G, a.B), g2((a.N + 255) / 256, a.G, a.B);
+  int rc = by_dtype(op->dtype, "chan_attn",
+      [&] { hipLaunchKernelGGL(chan_scores_kernel<float>, g1, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(chan_apply_kernel<float>, g2, dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(chan_scores_kernel<half_t>, g1, dim3(256), 0, s, a);
+            hipLaunchKernelGGL(chan_apply_kernel<half_t>, g2, dim3(256), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
+  DecArgs a;
+  a.q = op->p[0]; a.knew = op->p[1]; a.vnew = op->p[2]; a.kc = op->p[3]; a.o = op->p[4]; a.vc = op->p[5];
+  a.step = (const int*)op->p[6];
+  a.ldq = op->i[0]; a.qoff = op->i[1]; a.ldn = op->i[2]; a.koff = op->i[3]; a.voff = op->i[4]; a.ldo = op->i[5];
+  a.heads = op->i[6]; a.nk_fixed = op->i[7]; a.cap = op->i[8]; a.C = op->i[9]; a.ldc = op->i[11] > 0 ? op->i[11] : a.C;
+  int B = op->i[10];
+  a.scale = op->f[0];
+  OMNI_REQUIRE(a.q && a.kc && a.vc && a.o && B > 0 && a.heads > 0 && a.C == a.heads * 64, "attn_decode: bad arguments (head_dim 64)");
+  OMNI_REQUIRE(a.nk_fixed > 0 || (a.knew && a.vnew && a.step), "attn_decode: self-attention needs new k/v and the step counter");
+  int nk_max = a.nk_fixed > 0 ? a.nk_fixed : a.cap;
+  dim3 grid(a.heads, B);
+  size_t sh = (size_t)nk_max * 4;
+  int rc = by_dtype(op->dtype, "attn_decode",
+      [&] { hipLaunchKernelGGL(attn_decode_kernel<float>, grid, dim3(64), sh, s, a); },
+      [&] { hipLaunchKernelGGL(attn_decode_kernel<half_t>, grid, dim3(64), sh, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_greedy(const omni_op_t* op, hipStream_t s) {
+  GreedyArgs a;
+  a.logits = op->p[0]; a.bias = (const float*)op->p[1]; a.ids = (int*)op->p[2]; a.finished = (int*)op->p[3];
+  a.step = (const int*)op->p[6];
+  a.B = op->i[0]; a.V = op->i[1]; a.ldl = op->i[2]; a.T = op->i[3]; a.max_new = op->i[4]; a.ngram = op->i[5];
+  a.bos = op->i[6]; a.eos = op->i[7]; a.pad = op->i[8]; a.forced_bos = op->i[9]; a.forced_eos = op->i[10];
+  OMNI_REQUIRE(a.logits && a.ids && a.finished && a.step && a.B > 0 && a.V > 0 && a.T >= a.max_new + 1, "greedy_step: bad arguments");
+  int rc = by_dtype(op->dtype, "greedy_step",
+      [&] { hipLaunchKernelGGL(greedy_step_kernel<float>, dim3(a.B), dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(greedy_step_kernel<half_t>, dim3(a.B), dim3(256), 0, s, a); });
+  if (rc) return rc;
+  if (op->i[11]) hipLaunchKernelGGL(step_inc_kernel, dim3(1), dim3(64), 0, s, (int*)op->p[6]);
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_crop_resize(const omni_op_t* op, hipStream_t s) {
+  CropArgs a;
+  a.img = (const unsigned char*)op->p[0]; a.boxes = (const int*)op->p[1]; a.c64 = (unsigned char*)op->p[2];
+  a.tmp = (unsigned char*)op->p[3]; a.y = op->p[4]; a.b = (const int*)op->p[5]; a.k = (const int*)op->p[6];
+  a.lut = (const float*)op->p[7];
+  a.n = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.R = op->i[3]; a.ksize = op->i[4]; a.ldo = op->i[13];
+  for (int c = 0; c < 3; ++c) { a.mean[c] = op->f[c]; a.stdv[c] = op->f[3 + c]; }
+  OMNI_REQUIRE(a.img && a.boxes && a.c64 && a.y && a.lut && a.n > 0 && a.H > 0 && a.W > 0 && a.R >= 64 && a.ldo >= 3, "crop_resize: bad arguments");
+  OMNI_REQUIRE(a.R == 64 || (a.tmp && a.b && a.k && a.ksize > 0), "crop_resize: bicubic tables missing");
+  hipLaunchKernelGGL(crop_bilinear64_kernel, dim3(16, a.n), dim3(256), 0, s, a);
+  if (a.R != 64) hipLaunchKernelGGL(bicubic_h_kernel, dim3((64 * a.R + 255) / 256, a.n), dim3(256), 0, s, a);
+  dim3 g((unsigned)(((long long)a.R * a.R + 255) / 256), a.n);
+  int rc = by_dtype(op->dtype, "crop_resize",
+      [&] { hipLaunchKernelGGL(bicubic_v_norm_kernel<float>, g, dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(bicubic_v_norm_kernel<half_t>, g, dim3(256), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+static int launch_glue(const omni_op_t* op, hipStream_t s) {
+  int rc = OMNI_OK;
+  if (op->kind == OMNI_OP_PROJ_PREP) {
+    PrepArgs a; a.x = op->p[0]; a.pos = (const float*)op->p[1]; a.temporal = (const float*)op->p[2]; a.y = op->p[4]; a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3];
+    OMNI_REQUIRE(a.x && a.pos && a.temporal && a.y && a.B > 0 && a.N > 0 && a.C > 0, "proj_prep: bad arguments");
+    dim3 g((a.C + 255) / 256, a.B);
+    rc = by_dtype(op->dtype, "proj_prep",
+        [&] { hipLaunchKernelGGL(proj_prep_kernel<float>, g, dim3(256), 0, s, a); },
+        [&] { hipLaunchKernelGGL(proj_prep_kernel<half_t>, g, dim3(256), 0, s, a); });
+  } else if (op->kind == OMNI_OP_ASSEMBLE) {
+    AsmArgs a; a.img = op->p[0]; a.txt = op->p[1]; a.y = op->p[4]; a.B = op->i[0]; a.n_img = op->i[1]; a.n_txt = op->i[2]; a.C = op->i[3];
+    OMNI_REQUIRE(a.img && a.txt && a.y && a.B > 0 && a.n_img > 0 && a.n_txt >= 0 && a.C > 0, "assemble: bad arguments");
+    long long total = (long long)a.B * (a.n_img + a.n_txt) * a.C;
+    dim3 g((unsigned)((total + 255) / 256));
+    rc = by_dtype(op->dtype, "assemble",
+        [&] { hipLaunchKernelGGL(assemble_kernel<float>, g, dim3(256), 0, s, a); },
+        [&] { hipLaunchKernelGGL(assemble_kernel<half_t>, g, dim3(256), 0, s, a); });
+  } else {
+    EmbArgs a; a.table = op->p[0]; a.pos = op->p[1]; a.ids = (const int*)op->p[2]; a.y = op->p[4]; a.step = (const int*)op->p[6];
+    a.B = op->i[0]; a.C = op->i[3]; a.T = op->i[4]; a.pos_offset = op->i[5]; a.scale = op->f[0] == 0.0f ? 1.0f : op->f[0];
+    OMNI_REQUIRE(a.table && a.pos && a.ids && a.y && a.step && a.B > 0 && a.C > 0, "embed_step: bad arguments");
+    dim3 g((a.C + 255) / 256, a.B);
+    rc = by_dtype(op->dtype, "embed_step",
+        [&] { hipLaunchKernelGGL(embed_step_kernel<float>, g, dim3(256), 0, s, a); },
+        [&] { hipLaunchKernelGGL(embed_step_kernel<half_t>, g, dim3(256), 0, s, a); });
+  }
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+int omni_launch_attention(const omni_op_t* op, hipStream_t s) {
+  switch (op->kind) {
+    case OMNI_OP_ATTN_ROWS: return launch_attn_rows(op, s);
+    case OMNI_OP_CHAN_ATTN: return launch_chan_attn(op, s);
+    case OMNI_OP_ATTN_DECODE: return launch_attn_decode(op, s);
+    default: omni_set_error("attention: bad kind %d", op->kind); return OMNI_E_ARG;
+  }
+}
+
+int omni_launch_misc(const omni_op_t* op, hipStream_t s) {
+  switch (op->kind) {
+    case OMNI_OP_GREEDY_STEP: return launch_greedy(op, s);
+    case OMNI_OP_CROP_RESIZE: return launch_crop_resize(op, s);
+    case OMNI_OP_PROJ_PREP: case OMNI_OP_ASSEMBLE: case OMNI_OP_EMBED_STEP: return launch_glue(op, s);
+    default: omni_set_error("misc: bad kind %d", op->kind); return OMNI_E_ARG;
+  }
+}

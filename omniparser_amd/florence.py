@@ -1,0 +1,513 @@
+"""MI355X-native Florence-2 icon captioner: DaViT vision tower + projector + BART encoder + on-device
+greedy decoder, as three static plans (vision+encoder, cross-KV, one decoder step) replayed from HIP
+graphs.  Replaces, for `icon_caption`, what the reference reaches through
+`processor(...)` + `model.generate(...)` (ref:util/utils.py:116-130) — i.e. transformers' Florence-2
+(hf:models/florence2/modeling_florence2.py), BART (hf:models/bart/modeling_bart.py) and the greedy
+loop of hf:generation/utils.py:2783-2937.  Host Python only wires pointers; there is no torch math
+on the path and no CPU fallback.
+"""
+import json
+import math
+import os
+from pathlib import Path
+from types import SimpleNamespace
+from typing import Dict, List, Optional
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .planner import PlanBuilder, View, torch_dtype
+
+PROMPT_IDS = [0, 2264, 473, 5, 2274, 6190, 116, 2]   # <s>What does the image describe?</s>  
+CLIP_MEAN = (0.485, 0.456, 0.406)
+CLIP_STD = (0.229, 0.224, 0.225)
+
+
+# ------------------------------------------------------------------------------------------ weights
+def _legacy_to_native(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
+    """Map the remote-code (`trust_remote_code`) Florence-2 key names to the native transformers ones
+    (from memory — audited only against the native layout, no legacy checkpoint here)."""
+    out = {}
+    for k, v in sd.items():
+        nk = k
+        if nk.startswith("vision_tower."):
+            nk = nk.replace(".proj.", ".conv.") if ".convs." in nk else nk
+            nk = nk.replace(".fn.dw.", ".")
+            nk = nk.replace(".window_attn.norm.", ".norm1.").replace(".channel_attn.norm.", ".norm1.")
+            nk = nk.replace(".window_attn.fn.", ".window_attn.").replace(".channel_attn.fn.", ".channel_attn.")
+            nk = nk.replace(".ffn.norm.", ".norm2.").replace(".ffn.fn.net.", ".ffn.")
+            nk = "model." + nk
+        elif nk == "image_projection":
+            nk, v = "model.multi_modal_projector.image_projection.weight", v.t().contiguous()
+        elif nk.startswith("image_proj_norm."):
+            nk = "model.multi_modal_projector." + nk
+        elif nk.startswith("image_pos_embed."):
+            nk = "model.multi_modal_projector.image_position_embed." + nk[len("image_pos_embed."):]
+        elif nk.startswith("visual_temporal_embed."):
+            nk = "model.multi_modal_projector." + nk
+        elif nk.startswith("language_model.model."):
+            nk = "model.language_model." + nk[len("language_model.model."):]
+        elif nk == "language_model.lm_head.weight":
+            nk = "lm_head.weight"
+        elif nk == "language_model.final_logits_bias":
+            nk = "final_logits_bias"
+        out[nk] = v
+    return out
+
+
+class FlorenceWeights:
+    def __init__(self, model_dir):
+        from safetensors.torch import load_file
+        d = Path(model_dir)
+        self.dir = d
+        self.cfg = json.loads((d / "config.json").read_text())
+        gpath = d / "generation_config.json"
+        self.gen = json.loads(gpath.read_text()) if gpath.exists() else {}
+        files = sorted(d.glob("*.safetensors"))
+        if not files:
+            raise FileNotFoundError(f"no .safetensors under {d}")
+        sd = {}
+        for f in files:
+            sd.update(load_file(str(f)))
+        if any(k.startswith("vision_tower.") for k in sd):
+            sd = _legacy_to_native(sd)
+        self.sd = {k: v.float() for k, v in sd.items()}
+        if "lm_head.weight" not in self.sd:
+            self.sd["lm_head.weight"] = self.sd["model.language_model.shared.weight"]
+        vc, tc = self.cfg["vision_config"], self.cfg["text_config"]
+        self.embed_dim = vc["embed_dim"]; self.depths = vc["depths"]; self.heads = vc["num_heads"]
+        self.groups = vc["num_groups"]; self.patch = list(zip(vc["patch_size"], vc["patch_stride"], vc["patch_padding"]))
+        self.prenorm = vc["patch_prenorm"]; self.window = vc["window_size"]
+        self.d_model = tc["d_model"]; self.n_heads = tc["encoder_attention_heads"]
+        self.enc_layers, self.dec_layers = tc["encoder_layers"], tc["decoder_layers"]
+        self.vocab = self.sd["lm_head.weight"].shape[0]
+        self.embed_scale = math.sqrt(self.d_model) if tc.get("scale_embedding", False) else 1.0
+        g = lambda k, dflt: self.gen.get(k, tc.get(k, dflt))
+        self.pad, self.bos, self.eos = g("pad_token_id", 1), g("bos_token_id", 0), g("eos_token_id", 2)
+        self.start = g("decoder_start_token_id", 2)
+        self.ngram = g("no_repeat_ngram_size", 0) or 0
+        fb, fe = g("forced_bos_token_id", None), g("forced_eos_token_id", None)
+        self.forced_bos = -1 if fb is None else fb
+        self.forced_eos = -1 if fe is None else fe
+        assert self.window == 12 and self.d_model // self.n_heads == 64
+
+
+# ------------------------------------------------------------------------------------------ plans
+class _CaptionPlans:
+    """Static plans for B crops at resolution R."""
+
+    def __init__(self, cap: "Florence2Captioner", B: int, R: int, max_new: int):
+        w, dev, dt = cap.w, cap.device, cap.dtype
+        sd = w.sd
+        self.B, self.R, self.T = B, R, max_new + 1
+        pb = PlanBuilder(dev, dt)
+        self.pb = pb
+        V = pb.V
+        wc = cap._wcache
+
+        def packed(key, make):
+            ck = (key, dt)
+            if ck not in wc:
+                wt, b = make()
+                wc[ck] = (pb.pack_weight(wt if wt.dim() == 4 else wt[:, :, None, None]),
+                          pb.upload(b.float()) if b is not None else None)
+            return wc[ck]
+
+        def f32(key):
+            ck = (key, "f32")
+            if ck not in wc:
+                wc[ck] = pb.upload(sd[key].float())
+            return wc[ck]
+
+        def tokens(v: View) -> View:
+            return View(v.t.view(v.B, v.H * v.W, 1, v.ld), v.coff, v.C)
+
+        def linear(key, x: View, out: View, act=L.ACT_NONE, res=None, bias=True, keys=None):
+            keys = keys or [key]
+            def make():
+                wt = torch.cat([sd[k + ".weight"] for k in keys], 0)
+                b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
+                return wt, b
+            wp, bp = packed("|".join(keys), make)
+            return pb.conv(tokens(x), wp, bp, tokens(out), 1, act=act, res=tokens(res) if res is not None else None)
+
+        def layernorm(key, x: View, out: View, add=None, period=0, eps=1e-5):
+            rows = x.B * x.H * x.W
+            pb.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[x.ptr, add.data_ptr() if add is not None else None,
+                                                      f32(key + ".weight").data_ptr(), f32(key + ".bias").data_ptr(), out.ptr],
+                                i={0: rows, 1: 1, 3: x.C, 5: period}, f={0: eps}))
+            return out
+
+        def dwconv(key, x: View, out: View):
+            ck = (key, dt)
+            if ck not in wc:
+                wt = sd[key + ".weight"]                      # [C,1,3,3] -> [3][3][C]
+                wc[ck] = (pb.upload(wt[:, 0].permute(1, 2, 0).contiguous().to(torch_dtype(dt))), pb.upload(sd[key + ".bias"].float()))
+            wp, bp = wc[ck]
+            pb.keep += [wp, bp]
+            pb.add_op(L.make_op(L.OP_DWCONV3, dt, p=[x.ptr, wp.data_ptr(), bp.data_ptr(), None, out.ptr],
+                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C}))
+            return out
+
+        # ---------------- input + vision tower
+        self.x_in = pb.alloc(B, R, R, V, zero=True)
+        x = self.x_in
+        vt = "model.vision_tower."
+        self.chan_ws = None
+        for s in range(4):
+            C = w.embed_dim[s]
+            k, st, pd = w.patch[s]
+            Ho = (x.H + 2 * pd - k) // st + 1
+            conv_key = f"{vt}convs.{s}.conv"
+            if w.prenorm[s]:
+                xn = pb.alloc(B, x.H, x.W, x.C)
+                layernorm(f"{vt}convs.{s}.norm", x, xn)
+                cur = pb.alloc(B, Ho, Ho, C)
+                wp, bp = packed(conv_key, lambda ck=conv_key: (sd[ck + ".weight"], sd[ck + ".bias"]))
+                pb.conv(xn, wp, bp, cur, k, st, pd)
+            else:
+                t0 = pb.alloc(B, Ho, Ho, C)
+                ck2 = (conv_key, dt, "pad")
+                if ck2 not in wc:
+                    wc[ck2] = (pb.pack_weight(sd[conv_key + ".weight"], cin_pad=V), pb.upload(sd[conv_key + ".bias"].float()))
+                wp, bp = wc[ck2]
+                pb.conv(x, wp, bp, t0, k, st, pd)
+                cur = pb.alloc(B, Ho, Ho, C)
+                layernorm(f"{vt}convs.{s}.norm", t0, cur)
+            H = Ho
+            N = H * H
+            A_, B_ = cur, pb.alloc(B, H, H, C)
+            hbuf = pb.alloc(B, H, H, C)
+            qkv = pb.alloc(B, H, H, 3 * C)
+            att = pb.alloc(B, H, H, C)
+            ffn = pb.alloc(B, H, H, 4 * C)
+            chunk_tokens = 1024
+            chunks = (N + chunk_tokens - 1) // chunk_tokens
+            cws = pb.raw((B * w.groups[s] * chunks * 1024,), torch.float32, zero=False)
+            for blk in range(w.depths[s]):
+                for kind in ("spatial_block", "channel_block"):
+                    pre = f"{vt}blocks.{s}.{blk}.{kind}."
+                    dwconv(pre + "conv1", A_, B_)
+                    layernorm(pre + "norm1", B_, hbuf)
+                    if kind == "spatial_block":
+                        linear(pre + "window_attn.qkv", hbuf, qkv)
+                        qb = f32(pre + "window_attn.qkv.bias")
+                        nw = ((H + 11) // 12) ** 2
+                        pb.add_op(L.make_op(
+                            L.OP_ATTN_ROWS, dt,
+                            p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr, qb.data_ptr() + 4 * C, qb.data_ptr() + 8 * C],
+                            i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
+                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s]},
+                            f={0: (C // w.heads[s]) ** -0.5}))
+                        linear(pre + "window_attn.proj", att, B_, res=B_)
+                    else:
+                        linear(pre + "channel_attn.qkv", hbuf, qkv)
+                        pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
+                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens}))
+                        linear(pre + "channel_attn.proj", att, B_, res=B_)
+                    dwconv(pre + "conv2", B_, A_)
+                    layernorm(pre + "norm2", A_, hbuf)
+                    linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU)
+                    linear(pre + "ffn.fc2", ffn, A_, res=A_)
+            x = A_
+        self.vision_out = x
+        # ---------------- projector
+        mp = "model.multi_modal_projector."
+        h = x.H
+        Cv = x.C
+        ck = ("pos2d", h)
+        if ck not in wc:
+            col = sd[mp + "image_position_embed.column_embeddings.weight"][:h]
+            row = sd[mp + "image_position_embed.row_embeddings.weight"][:h]
+            pos = torch.cat([col.unsqueeze(0).repeat(h, 1, 1), row.unsqueeze(1).repeat(1, h, 1)], -1).reshape(h * h, Cv)
+            wc[ck] = (pb.upload(pos.float()), pb.upload(sd[mp + "visual_temporal_embed.pos_idx_to_embed"][0].float()))
+        pos2d, temporal = wc[ck]
+        pb.keep += [pos2d, temporal]
+        n_img = h * h + 1
+        self.n_img = n_img
+        pp = pb.alloc(B, n_img, 1, Cv)
+        pb.add_op(L.make_op(L.OP_PROJ_PREP, dt, p=[x.ptr, pos2d.data_ptr(), temporal.data_ptr(), None, pp.ptr],
+                            i={0: B, 1: h * h, 3: Cv}))
+        D = w.d_model
+        pj = pb.alloc(B, n_img, 1, D)
+        linear(mp + "image_projection", pp, pj, bias=False)
+        img_feat = pb.alloc(B, n_img, 1, D)
+        layernorm(mp + "image_proj_norm", pj, img_feat)
+        self.img_feat = img_feat
+        # ---------------- encoder
+        lm = "model.language_model."
+        S = n_img + len(PROMPT_IDS)
+        self.S = S
+        ck = ("prompt", dt)
+        if ck not in wc:
+            emb = sd[lm + "shared.weight"][torch.tensor(PROMPT_IDS)] * w.embed_scale
+            wc[ck] = pb.upload(emb.to(torch_dtype(dt)))
+        txt = wc[ck]
+        pb.keep.append(txt)
+        enc = pb.alloc(B, S, 1, D)
+        pb.add_op(L.make_op(L.OP_ASSEMBLE, dt, p=[img_feat.ptr, txt.data_ptr(), None, None, enc.ptr],
+                            i={0: B, 1: n_img, 2: len(PROMPT_IDS), 3: D}))
+        ck = ("encpos", S, dt)
+        if ck not in wc:
+            wc[ck] = pb.upload(sd[lm + "encoder.embed_positions.weight"][2:2 + S].to(torch_dtype(dt)))
+        encpos = wc[ck]
+        pb.keep.append(encpos)
+        xa = pb.alloc(B, S, 1, D)
+        layernorm(lm + "encoder.layernorm_embedding", enc, xa, add=encpos, period=S)
+        qkv = pb.alloc(B, S, 1, 3 * D)
+        att = pb.alloc(B, S, 1, D)
+        tmp = pb.alloc(B, S, 1, D)
+        ffn = pb.alloc(B, S, 1, sd[lm + "encoder.layers.0.fc1.weight"].shape[0])
+        nh = w.n_heads
+        for l in range(w.enc_layers):
+            pre = f"{lm}encoder.layers.{l}."
+            linear(None, xa, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
+            pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
+                                i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
+                                   12: 0, 15: 64}, f={0: 64 ** -0.5}))
+            linear(pre + "self_attn.out_proj", att, tmp, res=xa)
+            layernorm(pre + "self_attn_layer_norm", tmp, xa)
+            linear(pre + "fc1", xa, ffn, act=L.ACT_GELU)
+            linear(pre + "fc2", ffn, tmp, res=xa)
+            layernorm(pre + "final_layer_norm", tmp, xa)
+        self.enc_out = xa
+        # ---------------- cross-attention K/V of every decoder layer (computed once per batch)
+        self.cross_kv = []
+        for l in range(w.dec_layers):
+            pre = f"{lm}decoder.layers.{l}.encoder_attn."
+            kv = pb.alloc(B, S, 1, 2 * D)
+            linear(None, xa, kv, keys=[pre + "k_proj", pre + "v_proj"])
+            self.cross_kv.append(kv)
+        self.n_encode_ops = len(pb.ops)
+        self.encode_flops = pb.flops
+        self.encode_plan = pb.build()
+        # ---------------- decoder step plan
+        pd_ = PlanBuilder(dev, dt)
+        pd_.ws = pb.ws
+        self.pd = pd_
+        T = self.T
+        self.ids = pd_.raw((B, T), torch.int32)
+        self.finished = pd_.raw((B,), torch.int32)
+        self.step = pd_.raw((1,), torch.int32)
+        esz = 4 if dt == L.F32 else 2
+
+        def dlinear(key, xin: View, out: View, act=L.ACT_NONE, res=None, keys=None, bias=True):
+            keys = keys or [key]
+            def make():
+                wt = torch.cat([sd[k + ".weight"] for k in keys], 0)
+                b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
+                return wt, b
+            wp, bp = packed("|".join(keys), make)
+            return pd_.conv(xin, wp, bp, out, 1, act=act, res=res)
+
+        def dln(key, xin: View, out: View):
+            pd_.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[xin.ptr, None, f32(key + ".weight").data_ptr(),
+                                                       f32(key + ".bias").data_ptr(), out.ptr],
+                                 i={0: B, 1: 1, 3: D, 5: 0}, f={0: 1e-5}))
+            return out
+
+        ck = ("dectab", dt)
+        if ck not in wc:
+            wc[ck] = (pb.upload(sd[lm + "shared.weight"].to(torch_dtype(dt))),
+                      pb.upload(sd[lm + "decoder.embed_positions.weight"].to(torch_dtype(dt))))
+        table, dpos = wc[ck]
+        pd_.keep += [table, dpos]
+        e = pd_.alloc(B, 1, 1, D)
+        pd_.add_op(L.make_op(L.OP_EMBED_STEP, dt, p=[table.data_ptr(), dpos.data_ptr(), self.ids.data_ptr(), None, e.ptr,
+                                                     None, self.step.data_ptr()],
+                             i={0: B, 3: D, 4: T, 5: 2}, f={0: w.embed_scale}))
+        xd = pd_.alloc(B, 1, 1, D)
+        dln(lm + "decoder.layernorm_embedding", e, xd)
+        dqkv = pd_.alloc(B, 1, 1, 3 * D)
+        dq = pd_.alloc(B, 1, 1, D)
+        da = pd_.alloc(B, 1, 1, D)
+        dt_ = pd_.alloc(B, 1, 1, D)
+        dffn = pd_.alloc(B, 1, 1, sd[lm + "decoder.layers.0.fc1.weight"].shape[0])
+        self.self_k = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
+        self.self_v = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
+        for l in range(w.dec_layers):
+            pre = f"{lm}decoder.layers.{l}."
+            dlinear(None, xd, dqkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
+            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
+                                 p=[dqkv.ptr, dqkv.ptr, dqkv.ptr, self.self_k[l].ptr, da.ptr, self.self_v[l].ptr, self.step.data_ptr()],
+                                 i={0: 3 * D, 1: 0, 2: 3 * D, 3: D, 4: 2 * D, 5: D, 6: nh, 7: 0, 8: T, 9: D, 10: B, 11: D},
+                                 f={0: 64 ** -0.5}))
+            dlinear(pre + "self_attn.out_proj", da, dt_, res=xd)
+            dln(pre + "self_attn_layer_norm", dt_, xd)
+            dlinear(pre + "encoder_attn.q_proj", xd, dq)
+            kv = self.cross_kv[l]
+            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
+                                 p=[dq.ptr, None, None, kv.ptr, da.ptr, kv.ptr + D * esz, None],
+                                 i={0: D, 1: 0, 2: 0, 3: 0, 4: 0, 5: D, 6: nh, 7: S, 8: S, 9: D, 10: B, 11: 2 * D},
+                                 f={0: 64 ** -0.5}))
+            dlinear(pre + "encoder_attn.out_proj", da, dt_, res=xd)
+            dln(pre + "encoder_attn_layer_norm", dt_, xd)
+            dlinear(pre + "fc1", xd, dffn, act=L.ACT_GELU)
+            dlinear(pre + "fc2", dffn, dt_, res=xd)
+            dln(pre + "final_layer_norm", dt_, xd)
+        logits = pd_.alloc(B, 1, 1, w.vocab)
+        self.logits = logits
+        wp, _ = packed("lm_head", lambda: (sd["lm_head.weight"], None))
+        pd_.conv(xd, wp, None, logits, 1)
+        flb = None
+        if "final_logits_bias" in sd:
+            flb = f32("final_logits_bias")
+            pd_.keep.append(flb)
+        pd_.add_op(L.make_op(L.OP_GREEDY_STEP, dt,
+                             p=[logits.ptr, flb.data_ptr() if flb is not None else None, self.ids.data_ptr(),
+                                self.finished.data_ptr(), None, None, self.step.data_ptr()],
+                             i={0: B, 1: w.vocab, 2: w.vocab, 3: T, 4: max_new, 5: w.ngram, 6: w.bos, 7: w.eos, 8: w.pad,
+                                9: w.forced_bos, 10: w.forced_eos, 11: 1}))
+        self.step_flops = pd_.flops
+        self.step_plan = pd_.build()
+        self.start_token = w.start
+        if cap.use_graph:
+            torch.cuda.synchronize(dev)
+            self.reset()
+            self.encode_plan.run(cap.stream); self.step_plan.run(cap.stream)
+            cap.stream.synchronize()
+            self.encode_plan.capture(cap.stream)
+            self.step_plan.capture(cap.stream)
+            cap.stream.synchronize()
+
+    def reset(self):
+        self.ids.zero_()
+        self.ids[:, 0] = self.start_token
+        self.finished.zero_()
+        self.step.zero_()
+
+
+# ------------------------------------------------------------------------------------------ public objects
+class _Config(SimpleNamespace):
+    pass
+
+
+class Florence2Captioner:
+    """Duck-types the `model` half of the reference's caption_model_processor dict
+    (ref:util/utils.py:108-125): `.config.name_or_path`, `.config.model_type`, `.device`, `.generate`."""
+
+    def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
+        device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+        if device.type != "cuda" or not torch.cuda.is_available():
+            raise RuntimeError("omniparser_amd Florence2Captioner is the MI355X path and has no CPU fallback")
+        if device.index is None:
+            device = torch.device("cuda", torch.cuda.current_device())
+        L.lib()
+        self.device = device
+        precision = precision or os.environ.get("OMNI_PRECISION", "f32")
+        self.dtype = L.F32 if precision == "f32" else L.F16
+        # 768 = the reference's CPU-path crop resolution (parity target); 64 = its cuda branch (do_resize=False)
+        self.resolution = int(resolution or os.environ.get("OMNI_CAPTION_RES", "768"))
+        self.w = FlorenceWeights(model_dir)
+        self.config = _Config(name_or_path=str(model_dir) if "florence" in str(model_dir).lower() else f"florence:{model_dir}",
+                              model_type="florence2")
+        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"
+        self.stream = torch.cuda.Stream(device=device)
+        self._wcache = {}
+        self._plans = {}
+        self.max_new_tokens = 20
+        self._lut = None
+
+    def to(self, *a, **k):
+        return self
+
+    def eval(self):
+        return self
+
+    @staticmethod
+    def bucket(n: int) -> int:
+        for b in (8, 16, 32, 64, 128):
+            if n <= b:
+                return b
+        return 128
+
+    def plans(self, B, R, max_new) -> _CaptionPlans:
+        key = (B, R, max_new)
+        if key not in self._plans:
+            with torch.cuda.device(self.device):
+                self._plans[key] = _CaptionPlans(self, B, R, max_new)
+        return self._plans[key]
+
+    # ---- decode loop shared by both entry points
+    def _run(self, cp: _CaptionPlans, n: int, max_new: int) -> torch.Tensor:
+        run = (lambda p: p.replay(self.stream)) if self.use_graph else (lambda p: p.run(self.stream))
+        run(cp.encode_plan)
+        for _ in range(max_new):
+            run(cp.step_plan)
+        ids = cp.ids[:n].cpu().long()     # synchronises the stream
+        # hf stops as soon as every row has emitted EOS (generation/utils.py:2936): trim the all-pad tail
+        T = ids.shape[1]
+        done_at = T
+        seen = torch.zeros(n, dtype=torch.bool)
+        for t in range(1, T):
+            seen |= ids[:, t] == self.w.eos
+            if bool(seen.all()):
+                done_at = t + 1
+                break
+        return ids[:, :done_at]
+
+    @torch.inference_mode()
+    def generate(self, input_ids=None, pixel_values=None, max_new_tokens=20, num_beams=1, do_sample=False, **kw):
+        """hf-compatible entry point (ref:util/utils.py:125).  pixel_values: [B,3,R,R] float (NCHW)."""
+        if num_beams != 1 or do_sample:
+            raise NotImplementedError("greedy decoding only (the reference calls num_beams=1, do_sample=False)")
+        Bn, _, R, R2 = pixel_values.shape
+        assert R == R2
+        out = []
+        for s in range(0, Bn, 128):
+            chunk = pixel_values[s:s + 128]
+            n = chunk.shape[0]
+            cp = self.plans(self.bucket(n), R, max_new_tokens)
+            with torch.cuda.stream(self.stream):
+                cp.reset()
+                cp.x_in.t[:n, :, :, :3] = chunk.to(self.device).permute(0, 2, 3, 1).to(cp.x_in.t.dtype)
+                out.append(self._run(cp, n, max_new_tokens))
+        T = max(o.shape[1] for o in out)
+        res = torch.full((Bn, T), self.w.pad, dtype=torch.long)
+        o0 = 0
+        for o in out:
+            res[o0:o0 + o.shape[0], :o.shape[1]] = o
+            o0 += o.shape[0]
+        return res
+
+    @torch.inference_mode()
+    def caption_crops(self, image_u8: torch.Tensor, boxes_px: List[List[int]], max_new_tokens=20, batch_size=128):
+        """Fused fast path: crops are cut, resized (cv2-bilinear 64x64, then Pillow-bicubic to R on the
+        768 path) and normalised on device from the HBM-resident screenshot (ref:util/utils.py:97-123)."""
+        n_all = len(boxes_px)
+        R = self.resolution
+        outs = []
+        H, W = image_u8.shape[:2]
+        if self._lut is None:
+            self._lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)).to(self.device)
+            if R != 64:
+                b, k = L.resample_coeffs(64, R, 1)
+                self._bic = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device), k.shape[1])
+        for s in range(0, n_all, batch_size):
+            boxes = boxes_px[s:s + batch_size]
+            n = len(boxes)
+            cp = self.plans(self.bucket(n), R, max_new_tokens)
+            with torch.cuda.stream(self.stream):
+                cp.reset()
+                bx = torch.tensor(boxes, dtype=torch.int32).to(self.device, non_blocking=True)
+                c64 = torch.empty((n, 64, 64, 3), dtype=torch.uint8, device=self.device)
+                tmp = torch.empty((n, 64, R, 3), dtype=torch.uint8, device=self.device) if R != 64 else None
+                bb, kk, ks = self._bic if R != 64 else (None, None, 0)
+                op = L.make_op(L.OP_CROP_RESIZE, self.dtype,
+                               p=[image_u8.data_ptr(), bx.data_ptr(), c64.data_ptr(), tmp.data_ptr() if tmp is not None else None,
+                                  cp.x_in.ptr, bb.data_ptr() if bb is not None else None, kk.data_ptr() if kk is not None else None,
+                                  self._lut.data_ptr()],
+                               i={0: n, 1: H, 2: W, 3: R, 4: ks, 13: cp.x_in.ld},
+                               f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
+                L.launch(op, self.stream)
+                outs.append(self._run(cp, n, max_new_tokens))
+        if not outs:
+            return torch.zeros((0, 1), dtype=torch.long)
+        T = max(o.shape[1] for o in outs)
+        res = torch.full((n_all, T), self.w.pad, dtype=torch.long)
+        o0 = 0
+        for o in outs:
+            res[o0:o0 + o.shape[0], :o.shape[1]] = o
+            o0 += o.shape[0]
+        return res

@@ -424,3 +424,161 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
     out["ops"] = dp.n_ops
     out["net_gflop"] = dp.net_flops / 1e9
     return out, det
+
+
+# ------------------------------------------------------------------------------------------ captioner kernels
+def _op_pair(tensors, build):
+    """Run one op through the CPU interpreter and through the HIP kernel on copies of the same tensors.
+    tensors: name -> cpu tensor; build(ptr) -> omni_op_t where ptr(name, byte_offset=0) gives an address."""
+    from plan_interp import Mem, run_op
+    cpu = {k: v.clone() for k, v in tensors.items()}
+    gpu = {k: v.clone().to(DEV) for k, v in tensors.items()}
+    op_c = build(lambda n, off=0: cpu[n].data_ptr() + off)
+    op_g = build(lambda n, off=0: gpu[n].data_ptr() + off)
+    run_op(op_c, Mem(list(cpu.values())))
+    L.launch(op_g); _sync()
+    return cpu, {k: v.cpu() for k, v in gpu.items()}
+
+
+def _cmp(a, b, tol, what):
+    a, b = a.float(), b.float()
+    e = (a - b).abs().max().item() / max(b.abs().max().item(), 1e-12)
+    assert e <= tol, f"{what}: rel err {e:.3e} > {tol}"
+    return e
+
+
+def check_caption_ops(dtype=L.F32, seed=0):
+    g = torch.Generator().manual_seed(seed)
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    tol = 2e-5 if dtype == L.F32 else 5e-3
+    R = lambda *s: torch.randn(*s, generator=g)
+    res = {}
+    # dwconv3
+    B, H, W, C = 2, 9, 11, 96
+    t = {"x": R(B, H, W, C).to(tdt), "w": (R(3, 3, C) * 0.3).to(tdt), "b": R(C), "y": torch.zeros(B, H, W, C, dtype=tdt)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_DWCONV3, dtype, p=[P("x"), P("w"), P("b"), None, P("y")], i={0: B, 1: H, 2: W, 3: C}))
+    res["dwconv3"] = _cmp(gq["y"], c["y"], tol, "dwconv3")
+    # layernorm (+ add table), several widths
+    for Cc in (128, 768, 1024):
+        rows, period = 24, 6
+        t = {"x": R(rows, Cc).to(tdt) * 3 + 1, "add": R(period, Cc).to(tdt), "g": R(Cc), "b": R(Cc), "y": torch.zeros(rows, Cc, dtype=tdt)}
+        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_LAYERNORM, dtype, p=[P("x"), P("add"), P("g"), P("b"), P("y")],
+                                                i={0: rows, 1: 1, 3: Cc, 5: period}, f={0: 1e-5}))
+        res[f"layernorm{Cc}"] = _cmp(gq["y"], c["y"], tol * 5, f"layernorm C={Cc}")
+    # plain attention (encoder shape, odd S) and window attention with padding (H=W=16 -> 2x2 windows)
+    Bq, S, heads, D = 2, 77, 12, 64
+    Cm = heads * D
+    t = {"qkv": R(Bq * S, 3 * Cm).to(tdt), "o": torch.zeros(Bq * S, Cm, dtype=tdt)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_ROWS, dtype, p=[P("qkv"), P("qkv"), P("qkv"), None, P("o")],
+                                            i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
+                                               11: Bq, 12: 0, 15: D}, f={0: D ** -0.5}))
+    res["attn_plain"] = _cmp(gq["o"], c["o"], tol * 5, "attn_rows plain")
+    for (Hh, heads, D) in ((16, 4, 32), (24, 4, 32), (2, 8, 32)):
+        Cm = heads * D
+        Bq = 2
+        nw = ((Hh + 11) // 12) ** 2
+        t = {"qkv": R(Bq * Hh * Hh, 3 * Cm).to(tdt), "bias": R(3 * Cm), "o": torch.zeros(Bq * Hh * Hh, Cm, dtype=tdt)}
+        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_ROWS, dtype,
+                                                p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
+                                                i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
+                                                   11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D}, f={0: D ** -0.5}))
+        res[f"attn_window_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh}")
+    # channel attention
+    Bq, N, G = 2, 2500, 4
+    Cm = G * 32
+    chunks = (N + 1023) // 1024
+    t = {"qkv": R(Bq * N, 3 * Cm).to(tdt), "o": torch.zeros(Bq * N, Cm, dtype=tdt), "ws": torch.zeros(Bq * G * chunks * 1024)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
+                                            i={0: Bq, 1: N, 3: Cm, 4: G, 5: 1024}))
+    res["chan_attn"] = _cmp(gq["o"], c["o"], tol * 10, "channel attention")
+    # proj_prep / assemble
+    Bq, N, Cm = 2, 36, 256
+    t = {"x": R(Bq, N, Cm).to(tdt), "pos": R(N, Cm), "tmp": R(Cm), "y": torch.zeros(Bq, N + 1, Cm, dtype=tdt)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_PROJ_PREP, dtype, p=[P("x"), P("pos"), P("tmp"), None, P("y")], i={0: Bq, 1: N, 3: Cm}))
+    res["proj_prep"] = _cmp(gq["y"], c["y"], tol * 5, "proj_prep")
+    t = {"img": R(Bq, 5, Cm).to(tdt), "txt": R(8, Cm).to(tdt), "y": torch.zeros(Bq, 13, Cm, dtype=tdt)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ASSEMBLE, dtype, p=[P("img"), P("txt"), None, None, P("y")], i={0: Bq, 1: 5, 2: 8, 3: Cm}))
+    assert torch.equal(gq["y"], c["y"]), "assemble"
+    # decode attention: self (cache append at step 3) + cross
+    Bq, heads, T, S = 3, 12, 21, 45
+    Cm = heads * 64
+    t = {"qkv": R(Bq, 3 * Cm).to(tdt), "kc": R(Bq, T, Cm).to(tdt), "vc": R(Bq, T, Cm).to(tdt), "o": torch.zeros(Bq, Cm, dtype=tdt),
+         "step": torch.tensor([3], dtype=torch.int32)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_DECODE, dtype, p=[P("qkv"), P("qkv"), P("qkv"), P("kc"), P("o"), P("vc"), P("step")],
+                                            i={0: 3 * Cm, 1: 0, 2: 3 * Cm, 3: Cm, 4: 2 * Cm, 5: Cm, 6: heads, 7: 0, 8: T, 9: Cm, 10: Bq, 11: Cm},
+                                            f={0: 0.125}))
+    res["attn_decode_self"] = _cmp(gq["o"], c["o"], tol * 5, "attn_decode self")
+    assert torch.equal(gq["kc"], c["kc"]) and torch.equal(gq["vc"], c["vc"]), "KV cache append"
+    esz = 4 if dtype == L.F32 else 2
+    t = {"q": R(Bq, Cm).to(tdt), "kv": R(Bq, S, 2 * Cm).to(tdt), "o": torch.zeros(Bq, Cm, dtype=tdt)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_DECODE, dtype, p=[P("q"), None, None, P("kv"), P("o"), P("kv", Cm * esz), None],
+                                            i={0: Cm, 1: 0, 5: Cm, 6: heads, 7: S, 8: S, 9: Cm, 10: Bq, 11: 2 * Cm}, f={0: 0.125}))
+    res["attn_decode_cross"] = _cmp(gq["o"], c["o"], tol * 5, "attn_decode cross")
+    # embed_step + greedy_step (ngram ban, forced tokens, finished rows)
+    Bq, Vv, T, Cm = 4, 1000, 21, 64
+    ids = torch.zeros(Bq, T, dtype=torch.int32); ids[:, 0] = 2
+    ids[:, 1:6] = torch.tensor([[0, 7, 8, 7, 8], [0, 5, 5, 5, 5], [0, 9, 3, 9, 3], [0, 1, 2, 3, 4]], dtype=torch.int32)
+    logits = R(Bq, Vv).to(tdt)
+    logits[0, 7] = 50.0      # banned: (8,7)->8 already seen? prefix (7,8) -> bans 7
+    logits[1, 5] = 50.0      # banned by (5,5)->5
+    t = {"table": R(Vv, Cm).to(tdt), "pos": R(T + 2, Cm).to(tdt), "ids": ids, "y": torch.zeros(Bq, Cm, dtype=tdt),
+         "step": torch.tensor([5], dtype=torch.int32)}
+    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_EMBED_STEP, dtype, p=[P("table"), P("pos"), P("ids"), None, P("y"), None, P("step")],
+                                            i={0: Bq, 3: Cm, 4: T, 5: 2}, f={0: 1.0}))
+    res["embed_step"] = _cmp(gq["y"], c["y"], tol, "embed_step")
+    for st, name in ((5, "mid"), (0, "forced_bos"), (19, "forced_eos")):
+        t = {"logits": logits, "bias": R(Vv) * 0.01, "ids": ids.clone(), "fin": torch.tensor([0, 0, 1, 0], dtype=torch.int32),
+             "step": torch.tensor([st], dtype=torch.int32)}
+        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_GREEDY_STEP, dtype, p=[P("logits"), P("bias"), P("ids"), P("fin"), None, None, P("step")],
+                                                i={0: Bq, 1: Vv, 2: Vv, 3: T, 4: 20, 5: 3, 6: 0, 7: 2, 8: 1, 9: 0, 10: 2, 11: 1}))
+        assert torch.equal(gq["ids"], c["ids"]), f"greedy_step {name}: {gq['ids'][:, :8]} vs {c['ids'][:, :8]}"
+        assert torch.equal(gq["fin"], c["fin"]) and int(gq["step"][0]) == st + 1, f"greedy_step {name} bookkeeping"
+    res["greedy_step"] = 0.0
+    # crop_resize at both resolutions (exact vs the oracle restatement + real Pillow)
+    from omniparser_amd.synth import synthetic_screenshot
+    img = torch.from_numpy(synthetic_screenshot(3, 640, 360))
+    boxes = torch.tensor([[10, 20, 74, 84], [100, 50, 228, 178], [300, 10, 333, 47], [0, 0, 640, 360], [5, 5, 13, 9]], dtype=torch.int32)
+    lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32))
+    for Rr in (64, 96):
+        n = boxes.shape[0]
+        V = 4 if dtype == L.F32 else 8
+        t = {"img": img, "boxes": boxes, "c64": torch.zeros(n, 64, 64, 3, dtype=torch.uint8), "tmp": torch.zeros(n, 64, Rr, 3, dtype=torch.uint8),
+             "y": torch.zeros(n, Rr, Rr, V, dtype=tdt), "lut": lut}
+        ks = 0
+        if Rr != 64:
+            b_, k_ = L.resample_coeffs(64, Rr, 1)
+            t["b"], t["k"], ks = torch.from_numpy(b_), torch.from_numpy(k_), k_.shape[1]
+        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_CROP_RESIZE, dtype,
+                                                p=[P("img"), P("boxes"), P("c64"), P("tmp"), P("y"), P("b") if Rr != 64 else None,
+                                                   P("k") if Rr != 64 else None, P("lut")],
+                                                i={0: n, 1: 360, 2: 640, 3: Rr, 4: ks, 13: V},
+                                                f={0: 0.485, 1: 0.456, 2: 0.406, 3: 0.229, 4: 0.224, 5: 0.225}))
+        if dtype == L.F32:
+            nbad = int((gq["y"] != c["y"]).sum())
+            assert nbad == 0, f"crop_resize R={Rr}: {nbad} differing values"
+        else:
+            _cmp(gq["y"], c["y"], 2e-3, "crop_resize f16")
+        res[f"crop_resize_{Rr}"] = 0.0
+    return res
+
+
+def check_captioner(R=64, n=5, seed=0, precision="f32", max_new=20):
+    """Florence2Captioner.generate (HIP path) vs transformers-native Florence-2 on CPU: token-exact ids."""
+    import caption_checks as CC
+    from omniparser_amd.florence import Florence2Captioner
+    from tools.make_weights import ensure_caption_checkpoint, build_random_captioner
+    d = ensure_caption_checkpoint(seed)
+    model = build_random_captioner(seed)
+    g = torch.Generator().manual_seed(11 + R)
+    pix = torch.randn(n, 3, R, R, generator=g)
+    feats, enc, ids = CC.hf_reference(model, pix, max_new)
+    cap = Florence2Captioner(d, "cuda", precision=precision, resolution=R)
+    got = cap.generate(pixel_values=pix, max_new_tokens=max_new)
+    cp = cap.plans(cap.bucket(n), R, max_new)
+    f2 = cp.img_feat.t[:n, :, 0, :].float().cpu()
+    e2 = cp.enc_out.t[:n, :, 0, :].float().cpu()
+    out = {"R": R, "n": n, "feat_rel_err": rel_err(f2, feats), "enc_rel_err": rel_err(e2, enc),
+           "ids_equal": bool(got.shape == ids.shape and torch.equal(got, ids)),
+           "tokens_match": float((got[:, : ids.shape[1]] == ids[:, : got.shape[1]]).float().mean()) if got.numel() else 0.0,
+           "T": int(ids.shape[1]), "encode_gflop": cp.encode_flops / 1e9, "step_gflop": cp.step_flops / 1e9}
+    return out, cap

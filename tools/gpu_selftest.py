@@ -15,7 +15,7 @@ def main():
     import gpu_checks as G
     from omniparser_amd import _lib as L
     out = {"device": torch.cuda.get_device_name(0), "nproc": os.cpu_count()}
-    checks = [
+    checks = [] if "--only-extra" in sys.argv else [
         ("mfma_layout", lambda: G.check_mfma_layout()),
         ("conv_f32", lambda: G.check_conv(L.F32)),
         ("conv_f16", lambda: G.check_conv(L.F16)),
@@ -27,6 +27,12 @@ def main():
         ("post_dense", lambda: G.check_post(seed=2, nc=1, frac=0.6)),
         ("nms_known", lambda: G.check_nms_known_answers()),
     ]
+    if "--caption" in sys.argv:
+        checks.append(("caption_ops_f32", lambda: G.check_caption_ops(L.F32)))
+        checks.append(("caption_ops_f16", lambda: G.check_caption_ops(L.F16)))
+        checks.append(("captioner_r64", lambda: G.check_captioner(R=64, n=5)[0]))
+        if "--r768" in sys.argv:
+            checks.append(("captioner_r768", lambda: G.check_captioner(R=768, n=2)[0]))
     if "--detector" in sys.argv:
         w = float(os.environ.get("SELFTEST_WIDTH", "0.5"))
         checks.append(("detector_f32", lambda: G.check_detector(width=w, image_seeds=(0, 1))[0]))

@@ -49,3 +49,65 @@ if __name__ == "__main__":
     out = a.out or default_path(a.seed, a.nc, a.width)
     make_blob(out, a.seed, a.nc, a.width)
     print(out)
+
+
+# ------------------------------------------------------------------------------------------------
+# Florence-2-base-shaped caption checkpoint (random weights): config.json + model.safetensors +
+# generation_config.json in the layout `get_caption_model_processor` loads (ref:util/utils.py:63-68).
+def florence_base_config():
+    from transformers import Florence2Config
+    cfg = Florence2Config(
+        vision_config=dict(projection_dim=768),
+        text_config=dict(model_type="bart", vocab_size=51290, d_model=768, encoder_layers=6, decoder_layers=6,
+                         encoder_attention_heads=12, decoder_attention_heads=12, encoder_ffn_dim=3072,
+                         decoder_ffn_dim=3072, max_position_embeddings=1024, activation_function="gelu",
+                         scale_embedding=False, dropout=0.1, num_beams=3, no_repeat_ngram_size=3,
+                         forced_bos_token_id=0, forced_eos_token_id=2),
+    )
+    cfg._attn_implementation = "eager"
+    return cfg
+
+
+def caption_dir(seed=0):
+    return ROOT / "weights" / f"icon_caption_florence_s{seed}"
+
+
+def build_random_captioner(seed=0, init_std=0.06):
+    """transformers-native Florence2ForConditionalGeneration, fp32, eager attention, seeded weights.
+    init_std is larger than the library default (0.02) so that logits depend visibly on the image."""
+    from transformers import Florence2ForConditionalGeneration
+    cfg = florence_base_config()
+    torch.manual_seed(seed)
+    model = Florence2ForConditionalGeneration(cfg)
+    g = torch.Generator().manual_seed(seed)
+    with torch.no_grad():
+        for name, p in model.named_parameters():
+            if p.dim() >= 2:
+                p.copy_(torch.randn(p.shape, generator=g) * init_std)
+            elif name.endswith("bias"):
+                p.copy_(torch.randn(p.shape, generator=g) * 0.02)
+            else:   # LayerNorm weights
+                p.copy_(1.0 + 0.05 * torch.randn(p.shape, generator=g))
+        model.tie_weights()
+    model.generation_config.no_repeat_ngram_size = 3
+    model.generation_config.forced_bos_token_id = 0
+    model.generation_config.forced_eos_token_id = 2
+    return model.eval()
+
+
+def ensure_caption_checkpoint(seed=0):
+    import json
+    from safetensors.torch import save_file
+    d = caption_dir(seed)
+    if not (d / "model.safetensors").exists():
+        d.mkdir(parents=True, exist_ok=True)
+        model = build_random_captioner(seed)
+        skip = ("lm_head.weight", "model.language_model.encoder.embed_tokens.weight",
+                "model.language_model.decoder.embed_tokens.weight")            # tied to shared.weight
+        sd = {k: v.contiguous().clone() for k, v in model.state_dict().items() if k not in skip}
+        save_file(sd, str(d / "model.safetensors"))
+        (d / "config.json").write_text(model.config.to_json_string())
+        (d / "generation_config.json").write_text(json.dumps(
+            {"no_repeat_ngram_size": 3, "forced_bos_token_id": 0, "forced_eos_token_id": 2, "num_beams": 3,
+             "bos_token_id": 0, "eos_token_id": 2, "pad_token_id": 1, "decoder_start_token_id": 2}))
+    return d
