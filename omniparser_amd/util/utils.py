@@ -1,0 +1,290 @@
+"""Drop-in for the hot half of ref:util/utils.py on MI355X.
+
+Same names, arguments and return values as the reference for the functions on the detect -> caption
+path: `get_yolo_model`, `get_caption_model_processor`, `predict_yolo`,
+`int_box_area`, `remove_overlap_new`, `get_parsed_content_icon`, `get_som_labeled_img`,
+`check_ocr_box` (pass-through: OCR models are out of scope, SURVEY 2.1 #2b).  The two model stages run
+as HIP plans (util/yolov9.py, florence.py); the glue between them reproduces the reference's list
+semantics (App. E of SURVEY.md) and is pinned by golden fixtures generated from the reference's own
+source under dependency shims (tests/golden/).
+"""
+import base64
+import io
+import os
+import time
+from pathlib import Path
+from typing import List, Optional, Union
+
+import numpy as np
+import torch
+from PIL import Image, ImageDraw
+
+from ..florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS, Florence2Captioner
+from .yolov9 import YOLOv9Detector
+
+
+# ------------------------------------------------------------------------------------------ loaders
+def get_yolo_model(model_path=None, device=None):
+    """ref:util/utils.py:72-85 — local weights/icon_detect_v3/model.pt if present, YOLOv9-E adapter."""
+    if model_path is None:
+        local = Path(__file__).resolve().parents[2] / "weights/icon_detect_v3/model.pt"
+        if local.is_file():
+            model_path = local
+    if model_path is None or "icon_detect_v3" in Path(model_path).parts:
+        return YOLOv9Detector(model_path=model_path, device=device)
+    raise NotImplementedError("only the YOLOv9-E icon_detect_v3 detector is implemented on MI355X "
+                              "(the Ultralytics fallback of ref:util/utils.py:83-85 is out of scope)")
+
+
+class _Batch(dict):
+    """Minimal BatchFeature: mapping with `.to(device=, dtype=)` (ref:util/utils.py:121-123)."""
+
+    def to(self, device=None, dtype=None, **kw):
+        out = _Batch()
+        for k, v in self.items():
+            if isinstance(v, torch.Tensor):
+                if dtype is not None and v.is_floating_point():
+                    v = v.to(dtype)
+                if device is not None:
+                    v = v.to(device)
+            out[k] = v
+        return out
+
+    __getattr__ = dict.get
+
+
+class FlorenceProcessor:
+    """Stand-in for AutoProcessor("microsoft/Florence-2-base") on the `<CAPTION>` path
+    (hf:models/florence2/processing_florence2.py:84-152 + CLIP image processor).  Tokenizer files are
+    not shipped with the reference; if `tokenizer.json` sits next to the checkpoint it is used for
+    `batch_decode`, otherwise token ids are rendered as text."""
+
+    def __init__(self, model_dir=None, image_token_id=51289):
+        self.image_token_id = image_token_id
+        self.tok = None
+        if model_dir is not None and (Path(model_dir) / "tokenizer.json").exists():
+            from tokenizers import Tokenizer
+            self.tok = Tokenizer.from_file(str(Path(model_dir) / "tokenizer.json"))
+
+    def __call__(self, images=None, text=None, return_tensors="pt", do_resize=True, **kw):
+        imgs = images if isinstance(images, (list, tuple)) else [images]
+        arrs = []
+        for im in imgs:
+            if do_resize:
+                im = im.convert("RGB").resize((768, 768), Image.Resampling.BICUBIC)
+            a = (np.asarray(im.convert("RGB")).astype(np.float64) * (1 / 255)).astype(np.float32)
+            a = (a - np.asarray(CLIP_MEAN, dtype=np.float32)) / np.asarray(CLIP_STD, dtype=np.float32)
+            arrs.append(torch.from_numpy(a.transpose(2, 0, 1).copy()))
+        pix = torch.stack(arrs)
+        n_img = (pix.shape[-1] // 32) ** 2 + 1
+        ids = torch.tensor([[self.image_token_id] * n_img + PROMPT_IDS] * len(imgs))
+        return _Batch(input_ids=ids, pixel_values=pix, attention_mask=torch.ones_like(ids))
+
+    def batch_decode(self, ids, skip_special_tokens=True):
+        special = {0, 1, 2, 3, self.image_token_id}
+        out = []
+        for row in ids.tolist():
+            toks = [t for t in row if not (skip_special_tokens and t in special)]
+            if self.tok is not None:
+                out.append(self.tok.decode(toks, skip_special_tokens=skip_special_tokens))
+            else:
+                out.append(" ".join(f"tok{t}" for t in toks))
+        return out
+
+
+def get_caption_model_processor(model_name, model_name_or_path="Salesforce/blip2-opt-2.7b", device=None):
+    """ref:util/utils.py:48-69 for model_name == 'florence2' (BLIP-2 / phi3v are legacy, out of scope)."""
+    if not device:
+        device = "cuda" if torch.cuda.is_available() else "cpu"
+    if model_name != "florence2":
+        raise NotImplementedError(f"caption model '{model_name}': only 'florence2' is implemented on MI355X")
+    model = Florence2Captioner(model_name_or_path, device)
+    processor = FlorenceProcessor(model_name_or_path, image_token_id=model.w.cfg.get("image_token_id", 51289))
+    return {"model": model, "processor": processor}
+
+
+def check_ocr_box(image_source, display_img=True, output_bb_format="xywh", goal_filtering=None, easyocr_args=None,
+                  use_paddleocr=False, ocr_result=None):
+    """OCR front-end (ref:util/utils.py:514-549) is a separate model family and out of scope: callers
+    pass `ocr_result=(texts, xyxy boxes)` (e.g. omniparser_amd.synth.synthetic_ocr) or get no text boxes."""
+    texts, boxes = ocr_result if ocr_result is not None else ([], [])
+    if output_bb_format == "xywh":
+        boxes = [[b[0], b[1], b[2] - b[0], b[3] - b[1]] for b in boxes]
+    return (list(texts), [list(b) for b in boxes]), goal_filtering
+
+
+# ------------------------------------------------------------------------------------------ glue (App. E)
+def predict_yolo(model, image, box_threshold, imgsz, scale_img, iou_threshold=0.7):
+    """ref:util/utils.py:388-409."""
+    if scale_img:
+        result = model.predict(source=image, conf=box_threshold, imgsz=imgsz, iou=iou_threshold)
+    else:
+        result = model.predict(source=image, conf=box_threshold, iou=iou_threshold)
+    boxes = result[0].boxes.xyxy
+    conf = result[0].boxes.conf
+    phrases = [str(i) for i in range(len(boxes))]
+    return boxes, conf, phrases
+
+
+def int_box_area(box, w, h):
+    """ref:util/utils.py:411-415."""
+    x1, y1, x2, y2 = box
+    ib = [int(x1 * w), int(y1 * h), int(x2 * w), int(y2 * h)]
+    return (ib[2] - ib[0]) * (ib[3] - ib[1])
+
+
+def _area(b):
+    return (b[2] - b[0]) * (b[3] - b[1])
+
+
+def _inter(a, b):
+    return max(0, min(a[2], b[2]) - max(a[0], b[0])) * max(0, min(a[3], b[3]) - max(a[1], b[1]))
+
+
+def _overlap(a, b):
+    """the reference's IoU(): max(IoU with +1e-6 in the union, inter/areaA, inter/areaB)."""
+    it = _inter(a, b)
+    aa, ab = _area(a), _area(b)
+    r1, r2 = (it / aa, it / ab) if (aa > 0 and ab > 0) else (0, 0)
+    return max(it / (aa + ab - it + 1e-6), r1, r2)
+
+
+def _inside(a, b):
+    return _inter(a, b) / _area(a) > 0.80
+
+
+def remove_overlap_new(boxes, iou_threshold, ocr_bbox=None):
+    """ref:util/utils.py:241-319 — same outputs, same list-mutation quirks, different bookkeeping.
+
+    An icon is dropped when some other icon overlaps it above the threshold and is smaller; OCR boxes
+    lying inside a kept icon donate their text to it and are removed from the output (first dict-equal
+    entry; a failed removal still donates the text); an icon lying inside an OCR box is dropped."""
+    assert ocr_bbox is None or isinstance(ocr_bbox, list)
+    out = list(ocr_bbox) if ocr_bbox else []
+    bb = [e["bbox"] for e in boxes]
+    for i, elem in enumerate(boxes):
+        b1 = bb[i]
+        a1 = _area(b1)
+        if any(i != j and _overlap(b1, b2) > iou_threshold and a1 > _area(b2) for j, b2 in enumerate(bb)):
+            continue
+        if not ocr_bbox:
+            out.append(b1)          # reference appends the bare box when there is no OCR list
+            continue
+        labels = ""
+        swallowed = False
+        for t in ocr_bbox:
+            if _inside(t["bbox"], b1):
+                labels += t["content"] + " "
+                try:
+                    out.remove(t)
+                except ValueError:
+                    pass
+            elif _inside(b1, t["bbox"]):
+                swallowed = True
+                break
+        if not swallowed:
+            out.append({"type": "icon", "bbox": elem["bbox"], "interactivity": True,
+                        "content": labels if labels else None,
+                        "source": "box_yolo_content_ocr" if labels else "box_yolo_content_yolo"})
+    return out
+
+
+@torch.inference_mode()
+def get_parsed_content_icon(filtered_boxes, starting_idx, image_source, caption_model_processor, prompt=None, batch_size=128):
+    """ref:util/utils.py:88-132.  Crops are cut/resized/normalised on device and captioned by the HIP
+    captioner; `image_source` may be the uint8 HWC numpy image (as in the reference) or a device tensor."""
+    model, processor = caption_model_processor["model"], caption_model_processor["processor"]
+    non_ocr = filtered_boxes[starting_idx:] if starting_idx else filtered_boxes
+    H, W = image_source.shape[0], image_source.shape[1]
+    boxes_px = []
+    for coord in (non_ocr.tolist() if isinstance(non_ocr, torch.Tensor) else non_ocr):
+        x0, x1 = int(coord[0] * W), int(coord[2] * W)
+        y0, y1 = int(coord[1] * H), int(coord[3] * H)
+        if x1 - x0 <= 0 or y1 - y0 <= 0 or x0 < 0 or y0 < 0:
+            continue           # cv2.resize raises on empty crops; the reference's bare `except` skips them
+        boxes_px.append([x0, y0, min(x1, W), min(y1, H)])
+    if not boxes_px:
+        return []
+    img_dev = image_source if isinstance(image_source, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image_source))
+    img_dev = img_dev.to(model.device)
+    ids = model.caption_crops(img_dev, boxes_px, max_new_tokens=20, batch_size=batch_size)
+    texts = processor.batch_decode(ids, skip_special_tokens=True)
+    return [t.strip() for t in texts]
+
+
+def _box_convert_xyxy_to_cxcywh(b: torch.Tensor) -> torch.Tensor:
+    x1, y1, x2, y2 = b.unbind(-1)
+    return torch.stack(((x1 + x2) / 2, (y1 + y2) / 2, x2 - x1, y2 - y1), -1)
+
+
+def annotate(image_source: np.ndarray, boxes: torch.Tensor, logits, phrases, text_scale=0.4, text_padding=5,
+             text_thickness=2, thickness=3):
+    """ref:util/utils.py:336-364: returns (annotated RGB frame, {str(i): xywh}).  Drawing uses PIL
+    (cv2/supervision are absent); the image is a visual aid, not parity-gated."""
+    h, w, _ = image_source.shape
+    b = boxes * torch.tensor([w, h, w, h], dtype=boxes.dtype)
+    cx, cy, bw, bh = b.unbind(-1)
+    xyxy = torch.stack((cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2), -1).numpy()
+    xywh = torch.stack((cx - bw / 2, cy - bh / 2, bw, bh), -1).numpy()
+    label_coordinates = {f"{phrase}": v for phrase, v in zip(phrases, xywh)}
+    im = Image.fromarray(image_source.copy())
+    draw = ImageDraw.Draw(im)
+    for i, (x1, y1, x2, y2) in enumerate(xyxy.tolist()):
+        col = ((37 * i) % 200 + 30, (91 * i) % 200 + 30, (151 * i) % 200 + 30)
+        draw.rectangle([x1, y1, x2, y2], outline=col, width=max(int(thickness), 1))
+        draw.text((x1 + 2, max(y1 - 10, 0)), str(phrases[i]), fill=col)
+    return np.asarray(im), label_coordinates
+
+
+def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_TRESHOLD=0.01, output_coord_in_ratio=False,
+                        ocr_bbox=None, text_scale=0.4, text_padding=5, draw_bbox_config=None, caption_model_processor=None,
+                        ocr_text=[], use_local_semantics=True, iou_threshold=0.9, prompt=None, scale_img=False, imgsz=None,
+                        batch_size=128):
+    """ref:util/utils.py:417-496 — returns (base64 PNG, label_coordinates, filtered_boxes_elem)."""
+    if isinstance(image_source, str):
+        image_source = Image.open(image_source)
+    image_source = image_source.convert("RGB")
+    w, h = image_source.size
+    if not imgsz:
+        imgsz = (h, w)
+    xyxy, logits, phrases = predict_yolo(model=model, image=image_source, box_threshold=BOX_TRESHOLD, imgsz=imgsz,
+                                         scale_img=scale_img, iou_threshold=0.1)
+    xyxy = xyxy.cpu() / torch.Tensor([w, h, w, h])       # f32 divide, as the reference (on its device)
+    image_np = np.asarray(image_source)
+    if ocr_bbox:
+        ocr_bbox = (torch.tensor(ocr_bbox) / torch.Tensor([w, h, w, h])).tolist()
+    else:
+        ocr_bbox, ocr_text = [], []        # the reference raises TypeError here (zip(None, ...)); we tolerate it
+    ocr_elems = [{"type": "text", "bbox": box, "interactivity": False, "content": txt, "source": "box_ocr_content_ocr"}
+                 for box, txt in zip(ocr_bbox, ocr_text) if int_box_area(box, w, h) > 0]
+    icon_elems = [{"type": "icon", "bbox": box, "interactivity": True, "content": None}
+                  for box in xyxy.tolist() if int_box_area(box, w, h) > 0]
+    filtered = remove_overlap_new(boxes=icon_elems, iou_threshold=iou_threshold, ocr_bbox=ocr_elems)
+    if not ocr_elems:   # reference returns bare boxes in that (crashing) configuration; normalise to elements
+        filtered = [e if isinstance(e, dict) else {"type": "icon", "bbox": e, "interactivity": True, "content": None,
+                                                    "source": "box_yolo_content_yolo"} for e in filtered]
+    elems = sorted(filtered, key=lambda x: x["content"] is None)
+    starting_idx = next((i for i, box in enumerate(elems) if box["content"] is None), -1)
+    filtered_boxes = torch.tensor([box["bbox"] for box in elems]).reshape(-1, 4)
+    if use_local_semantics:
+        parsed = get_parsed_content_icon(filtered_boxes, starting_idx, image_np, caption_model_processor, prompt=prompt,
+                                         batch_size=batch_size)
+        for box in elems:
+            if box["content"] is None and parsed:
+                box["content"] = parsed.pop(0)
+    boxes_cxcywh = _box_convert_xyxy_to_cxcywh(filtered_boxes)
+    phrases = [i for i in range(len(boxes_cxcywh))]
+    if os.environ.get("OMNI_SKIP_ANNOTATE", "0") == "1":
+        encoded = ""
+        label_coordinates = {f"{i}": v for i, v in enumerate(
+            torch.stack((filtered_boxes[:, 0] * w, filtered_boxes[:, 1] * h, (filtered_boxes[:, 2] - filtered_boxes[:, 0]) * w,
+                         (filtered_boxes[:, 3] - filtered_boxes[:, 1]) * h), -1).numpy())} if len(filtered_boxes) else {}
+    else:
+        cfg = draw_bbox_config or {"text_scale": text_scale, "text_padding": text_padding}
+        frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)
+        buf = io.BytesIO()
+        Image.fromarray(frame).save(buf, format="PNG")
+        encoded = base64.b64encode(buf.getvalue()).decode("ascii")
+    if output_coord_in_ratio:
+        label_coordinates = {k: [v[0] / w, v[1] / h, v[2] / w, v[3] / h] for k, v in label_coordinates.items()}
+    return encoded, label_coordinates, elems
