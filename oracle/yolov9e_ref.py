@@ -277,8 +277,10 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05):
             if isinstance(m, nn.BatchNorm2d):
                 m.momentum = 1.0
         model.train()
-        for seq in model.head.cv2:   # softer DFL distributions
+        for seq in model.head.cv2:   # icon-sized boxes: DFL mass centred near 1.5 strides per side
             seq[-1].weight.mul_(0.3)
+            bins = torch.arange(16, dtype=torch.float32)
+            seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
         x = _calibration_input()
         model(x)
         model.eval()
