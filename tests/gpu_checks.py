@@ -582,3 +582,84 @@ def check_captioner(R=64, n=5, seed=0, precision="f32", max_new=20):
            "tokens_match": float((got[:, : ids.shape[1]] == ids[:, : got.shape[1]]).float().mean()) if got.numel() else 0.0,
            "T": int(ids.shape[1]), "encode_gflop": cp.encode_flops / 1e9, "step_gflop": cp.step_flops / 1e9}
     return out, cap
+
+
+# ------------------------------------------------------------------------------------------ end to end
+class _OracleCaptioner:
+    """CPU reference of the caption stage: oracle crop pre-processing + transformers Florence-2."""
+
+    def __init__(self, model, R):
+        self.model, self.R = model, R
+        self.device = torch.device("cpu")
+        self.config = type("C", (), {"name_or_path": "florence-oracle", "model_type": "florence2"})()
+        self.boxes_seen = []
+
+    def caption_crops(self, image, boxes, max_new_tokens=20, batch_size=128):
+        from oracle import preprocess_ref as PR
+        from omniparser_amd.florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS
+        img = image.numpy() if isinstance(image, torch.Tensor) else image
+        self.boxes_seen = [list(b) for b in boxes]
+        outs = []
+        for s in range(0, len(boxes), batch_size):
+            pv = np.stack([PR.caption_pixel_values(img, b, self.R, CLIP_MEAN, CLIP_STD) for b in boxes[s:s + batch_size]])
+            pix = torch.from_numpy(pv).permute(0, 3, 1, 2).contiguous()
+            n_img = (self.R // 32) ** 2 + 1
+            ids = torch.tensor([[self.model.config.image_token_id] * n_img + PROMPT_IDS] * pix.shape[0])
+            with torch.inference_mode():
+                outs.append(self.model.generate(input_ids=ids, pixel_values=pix, max_new_tokens=max_new_tokens, num_beams=1, do_sample=False))
+        T = max(o.shape[1] for o in outs)
+        res = torch.full((len(boxes), T), 1, dtype=torch.long)
+        o0 = 0
+        for o in outs:
+            res[o0:o0 + o.shape[0], :o.shape[1]] = o; o0 += o.shape[0]
+        return res
+
+
+def check_end_to_end(width=0.5, R=64, image_seed=1, max_crops_checked=None, iw=1920, ih=1080):
+    """get_som_labeled_img on the HIP path vs the reference-equivalent CPU pipeline
+    (oracle detector -> reference-pinned glue -> oracle crops -> transformers Florence-2)."""
+    import types
+    from PIL import Image
+    from oracle import detector_ref as D
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.util import utils as U
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import build_random_captioner, ensure_blob, ensure_caption_checkpoint
+    blob = ensure_blob(seed=0, nc=1, width=width)
+    cdir = ensure_caption_checkpoint(0)
+    det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
+    cap = Florence2Captioner(cdir, "cuda", precision="f32", resolution=R)
+    proc = U.FlorenceProcessor(cdir)
+    img = Image.fromarray(synthetic_screenshot(image_seed, iw, ih))
+    texts, obox = synthetic_ocr(image_seed, iw, ih, 40)
+    kw = dict(BOX_TRESHOLD=0.05, output_coord_in_ratio=True, ocr_bbox=obox, ocr_text=texts, use_local_semantics=True,
+              iou_threshold=0.7, scale_img=False, batch_size=128)
+    enc_g, lab_g, el_g = U.get_som_labeled_img(img, det, caption_model_processor={"model": cap, "processor": proc}, **kw)
+    # CPU reference
+    cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
+    rb, rs, rc = D.predict(cpu_model, img, conf=0.05, imgsz=640, iou=0.1)
+    class _Det:
+        def predict(self, source, conf, iou, imgsz=None):
+            return [types.SimpleNamespace(boxes=types.SimpleNamespace(xyxy=rb, conf=rs))]
+    ocap = _OracleCaptioner(build_random_captioner(0), R)
+    enc_r, lab_r, el_r = U.get_som_labeled_img(img, _Det(), caption_model_processor={"model": ocap, "processor": proc}, **kw)
+    out = {"n_gpu": len(el_g), "n_ref": len(el_r), "icons": sum(e["type"] == "icon" for e in el_r), "R": R}
+    assert len(el_g) == len(el_r), f"element count {len(el_g)} vs {len(el_r)}"
+    min_iou, same_caps, caps = 1.0, 0, 0
+    for a, b in zip(el_g, el_r):
+        assert a["type"] == b["type"] and a["source"] == b["source"] and a["interactivity"] == b["interactivity"]
+        iou = box_iou_pairs(torch.tensor([a["bbox"]]), torch.tensor([b["bbox"]])).item()
+        min_iou = min(min_iou, iou)
+        if a["type"] == "icon" and a["source"] == "box_yolo_content_yolo":
+            caps += 1
+            pa = [int(a["bbox"][0] * iw), int(a["bbox"][1] * ih), int(a["bbox"][2] * iw), int(a["bbox"][3] * ih)]
+            pb = [int(b["bbox"][0] * iw), int(b["bbox"][1] * ih), int(b["bbox"][2] * iw), int(b["bbox"][3] * ih)]
+            if pa == pb:
+                assert a["content"] == b["content"], f"caption differs on identical crop {pa}: {a['content']} vs {b['content']}"
+                same_caps += 1
+        else:
+            assert a["content"] == b["content"]
+    assert min_iou >= 0.999, f"min IoU {min_iou}"
+    out.update(min_iou=min_iou, captioned=caps, identical_crops_token_exact=same_caps)
+    return out

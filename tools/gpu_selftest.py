@@ -33,6 +33,8 @@ def main():
         checks.append(("captioner_r64", lambda: G.check_captioner(R=64, n=5)[0]))
         if "--r768" in sys.argv:
             checks.append(("captioner_r768", lambda: G.check_captioner(R=768, n=2)[0]))
+    if "--e2e" in sys.argv:
+        checks.append(("e2e_r64", lambda: G.check_end_to_end(width=0.5, R=64, image_seed=1)))
     if "--detector" in sys.argv:
         w = float(os.environ.get("SELFTEST_WIDTH", "0.5"))
         checks.append(("detector_f32", lambda: G.check_detector(width=w, image_seeds=(0, 1))[0]))
