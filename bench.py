@@ -2,19 +2,24 @@
 """bench.py — screenshots/sec of the MI355X screen-parsing hot path (BASELINE.json metric).
 
 Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
-per GPU).  A *step* is one synthetic 1920x1080 screenshot, already resident in HBM as RGB bytes,
-through the hot path: Pillow-exact Lanczos letterbox -> YOLOv9-E -> DFL/decode/threshold -> NMS
-(BASELINE config 2: detector only, batch 1; the captioner stage is reported once it exists).
-W untimed warm-up steps, exactly K timed steps between barrier+synchronize pairs, MAX over ranks,
-rank 0 prints ONE JSON line.  Screenshots shard across ranks with no data-path collective; the only
-exchange is one all_gather of the packed element records at the end of the job (inside the timed
-region).
+per GPU).  A *step* is one pass of the hot path over one batch of synthetic 1920x1080 screenshots that
+are already resident in HBM as RGB bytes:
 
-Extra objects on the same line:
-  roofline     — dominant kernel (conv_igemm_kernel family): algorithmic conv FLOPs per screenshot /
-                 HIP-event time of the conv launches, vs the dense MFMA peak of the dtype.
-  cpu_baseline — the reference-equivalent CPU path (oracle/detector_ref.py: torch.jit blob on host
-                 cores + PIL letterbox + torch NMS) timed on rank 0 at N=1 on a bounded sample.
+  --mode e2e (default; BASELINE configs[2]): batch of 8 screenshots -> Pillow-exact Lanczos letterbox ->
+      YOLOv9-E -> decode + NMS -> reference glue (overlap removal vs a synthetic OCR fixture) -> crop,
+      cv2-bilinear 64x64, Pillow-bicubic to 768x768 (the reference's CPU-path crop size = the parity
+      target; --caption-res 64 is its cuda branch) -> Florence-2 (DaViT + BART encoder) -> 20-step greedy
+      decode.  Output: parsed element lists (boxes + caption ids).  Annotated-PNG rendering is a caller-side
+      visual and is not part of the timed path.
+  --mode detect (BASELINE configs[1]): detector stage only, batch 1.
+
+W untimed warm-up steps, exactly K timed steps between barrier+synchronize pairs, MAX over ranks, rank 0
+prints ONE JSON line; `value` = screenshots of all ranks / that time.  Screenshots shard across ranks with
+no data-path collective; the only exchange is one all_gather of packed element records per job.
+
+Extra objects: `roofline` (dominant kernel family conv_igemm_kernel: algorithmic conv/linear FLOPs per
+step / HIP-event time of exactly those launches, vs the dense MFMA peak of the dtype) and `cpu_baseline`
+(the reference-equivalent CPU path from oracle/, timed on rank 0 at N=1 on a bounded sample).
 Weights are seeded-random (tools/make_weights.py); data is synthetic (omniparser_amd/synth.py).
 """
 import argparse
@@ -31,14 +36,27 @@ sys.path.insert(0, str(ROOT))
 def parse_args():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
-    ap.add_argument("--steps", type=int, default=200)
-    ap.add_argument("--warmup", type=int, default=20)
+    ap.add_argument("--steps", type=int, default=None)
+    ap.add_argument("--warmup", type=int, default=None)
+    ap.add_argument("--mode", default="e2e", choices=["e2e", "detect"])
+    ap.add_argument("--batch", type=int, default=None, help="screenshots per step (e2e default 8, detect default 1)")
     ap.add_argument("--precision", default=os.environ.get("OMNI_PRECISION", "f32"), choices=["f32", "f16"])
+    ap.add_argument("--caption-res", type=int, default=768, choices=[64, 768])
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
-    ap.add_argument("--cpu-samples", type=int, default=3)
-    ap.add_argument("--width", type=float, default=1.0, help="debug only: channel multiplier (1.0 = YOLOv9-E)")
-    return ap.parse_args()
+    ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
+    a = ap.parse_args()
+    if a.batch is None:
+        a.batch = 8 if a.mode == "e2e" else 1
+    if a.steps is None:
+        a.steps = 3 if (a.mode == "e2e" and a.caption_res == 768) else (10 if a.mode == "e2e" else 200)
+    if a.warmup is None:
+        a.warmup = 1 if a.mode == "e2e" else 20
+    return a
+
+
+IW, IH = 1920, 1080
+CONF, NMS_IOU, OVERLAP_IOU, MAX_DET = 0.05, 0.1, 0.7, 300   # ref:util/omniparser.py:30, ref:util/utils.py:431
 
 
 def main():
@@ -47,36 +65,70 @@ def main():
     import torch.distributed as dist
     from omniparser_amd import _lib as L
     from omniparser_amd import dist as OD
-    from omniparser_amd.synth import synthetic_screenshot
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import ensure_blob
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
 
     rank, world, local_rank = OD.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
-    IW, IH = 1920, 1080
     imgsz = 640 if args.imgsz == "640" else (IH, IW)
-    conf, iou, max_det = 0.05, 0.1, 300     # ref:util/omniparser.py:30 / ref:util/utils.py:431
-
     if rank == 0:
-        blob = ensure_blob(seed=0, nc=1, width=args.width)
+        ensure_blob(seed=0, nc=1, width=args.width)
+        if args.mode == "e2e":
+            ensure_caption_checkpoint(0)
     if world > 1:
         dist.barrier()
     blob = ensure_blob(seed=0, nc=1, width=args.width)
     det = YOLOv9Detector(model_path=blob, device=dev, precision=args.precision)
-    dp = det.get_plan(IW, IH, imgsz, conf, iou, max_det, batch=1)
-
-    # this rank's shard of the job's screenshots (8 distinct synthetic frames, cycled), resident in HBM
-    n_total = (args.steps + args.warmup) * world
+    B = args.batch
     frames = [torch.from_numpy(synthetic_screenshot(s, IW, IH)).to(dev) for s in range(8)]
-    my_items = OD.shard_indices(args.steps * world, rank, world)
+    ocr = [synthetic_ocr(s, IW, IH, 40) for s in range(8)]
+    n_items = args.steps * B * world
+    my_items = OD.shard_indices(args.steps * world, rank, world)      # step-granular round robin
     assert len(my_items) == args.steps
 
-    def step(item):
-        with torch.cuda.stream(det.stream):
-            dp.img[0].copy_(frames[item % 8], non_blocking=True)   # device->device, 6 MB
-            dp.launch(det)
+    parser = None
+    if args.mode == "e2e":
+        from omniparser_amd.florence import Florence2Captioner
+        from omniparser_amd.pipeline import ScreenParser
+        cap = Florence2Captioner(ensure_caption_checkpoint(0), dev, precision=args.precision, resolution=args.caption_res)
+        parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
+    else:
+        dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=B)
+
+    recs = torch.zeros(args.steps * B, OD.REC_W, dtype=torch.int32, device=dev)
+    crop_counts = []
+
+    def step(step_id, li=None):
+        idx = [(step_id * B + j) % 8 for j in range(B)]
+        if args.mode == "detect":
+            with torch.cuda.stream(det.stream):
+                for j, f in enumerate(idx):
+                    dp.img[j].copy_(frames[f], non_blocking=True)
+                dp.launch(det)
+                if li is not None:
+                    for j in range(B):
+                        r = recs[li * B + j]
+                        r[0] = step_id * B + j
+                        r[1:2] = dp.out_count[j:j + 1]
+                        r[2:2 + 4 * MAX_DET] = dp.out_boxes[j].view(torch.int32).flatten()
+                        r[2 + 4 * OD.MAX_DET:2 + 5 * OD.MAX_DET] = dp.out_scores[j].view(torch.int32)
+                        r[2 + 5 * OD.MAX_DET:2 + 6 * OD.MAX_DET] = dp.out_cls[j]
+            return
+        elems, ids = parser.parse_batch([frames[f] for f in idx], [ocr[f] for f in idx], return_ids=True)
+        crop_counts.append(sum(parser.stats["crops"]))
+        if li is not None:
+            for j in range(B):
+                boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
+                k = boxes.shape[0]
+                capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
+                ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
+                for row, i in zip(ids[j], ic):
+                    if i < k:
+                        capt[i, : row.shape[0]] = row
+                recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
 
     def sync_all():
         det.stream.synchronize()
@@ -87,103 +139,142 @@ def main():
     for w in range(args.warmup):
         step(w)
     sync_all()
-
-    recs = torch.zeros(len(my_items), OD.REC_W, dtype=torch.int32, device=dev)
+    crop_counts.clear()
     t0 = time.perf_counter()
+    for li, item in enumerate(my_items):
+        step(item, li)
     with torch.cuda.stream(det.stream):
-        for li, item in enumerate(my_items):
-            step(item)
-            # results stay on device; pack without a host sync (count is clamped inside pack via K slot)
-            recs[li, 0] = item
-            recs[li, 1:2] = dp.out_count[0:1]
-            o = 2
-            recs[li, o:o + 4 * max_det] = dp.out_boxes[0].view(torch.int32).flatten()
-            o += 4 * OD.MAX_DET
-            recs[li, o:o + max_det] = dp.out_scores[0].view(torch.int32)
-            o += OD.MAX_DET
-            recs[li, o:o + max_det] = dp.out_cls[0]
-        allr = OD.gather_records(recs, args.steps * world, rank, world)
-    det.stream.synchronize()
-    torch.cuda.synchronize(dev)
-    if world > 1:
-        dist.barrier()
+        allr = OD.gather_records(recs, n_items, rank, world)
+    sync_all()
     elapsed = time.perf_counter() - t0
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
         elapsed = float(t.item())
-    total_items = args.steps * world
-    value = total_items / elapsed
+    value = n_items / elapsed
     kept = allr[:, 1].float().mean().item()
 
+    workload = ("BASELINE configs[2]: full detect -> crop -> Florence-2 caption, batch=%d screenshots, greedy decode, caption crops %dx%d"
+                % (B, args.caption_res, args.caption_res)) if args.mode == "e2e" else \
+        "BASELINE configs[1]: YOLOv9-E icon_detect only, batch=%d, 1920x1080 (letterbox+network+decode+NMS)" % B
     out = {
         "metric": "screenshots/sec end-to-end (detect+caption) @1920x1080",
-        "value": round(value, 3),
-        "unit": "screenshots/s",
-        "n_gpus": world,
-        "steps": args.steps,
-        "warmup": args.warmup,
-        "ms_per_step": round(1000.0 * elapsed / args.steps, 4),
-        "higher_is_better": True,
-        "scaling": "weak",
-        "vs_baseline": None,
+        "value": round(value, 4), "unit": "screenshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
+        "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision,
-        "data": "synthetic 1920x1080 GUI-like screenshots (8 seeds) + seeded random-weight YOLOv9-E blob",
+        "data": "synthetic 1920x1080 GUI-like screenshots (8 seeds) + synthetic OCR boxes; seeded random-weight YOLOv9-E blob "
+                "and Florence-2-base-shaped checkpoint",
         "config": {
-            "workload": "BASELINE configs[1]: YOLOv9-E icon_detect only, batch=1, 1920x1080 "
-                        "(letterbox+network+decode+NMS; captioner not yet in the timed path)",
+            "workload": workload, "screenshots_per_step": B,
             "network_input": "640x640" if args.imgsz == "640" else "1088x1920",
-            "conf": conf, "iou": iou, "max_det": max_det,
-            "parallelism": f"replicas x{world}, round-robin shards, 1 all_gather/job",
-            "hipgraph": det.use_graph, "ops_per_screenshot": dp.n_ops,
-            "mean_kept_boxes": round(kept, 2),
+            "conf": CONF, "nms_iou": NMS_IOU, "overlap_iou": OVERLAP_IOU, "max_det": MAX_DET,
+            "parallelism": f"replicas x{world}, round-robin shards of steps, 1 all_gather/job",
+            "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
         },
     }
+    if args.mode == "e2e":
+        out["config"]["mean_crops_per_screenshot"] = round(sum(crop_counts) / max(len(crop_counts), 1) / B, 2)
+        out["config"]["caption_micro_batch"] = 128
 
     if rank == 0:
-        # ---- roofline of the dominant kernel family, measured live with HIP events on det.stream
-        conv_ops = [op for op in dp.plan.ops if op.kind == L.OP_CONV]
-        conv_plan = L.Plan(conv_ops)
-        conv_plan.run(det.stream); det.stream.synchronize()
-        iters = 20
-        conv_ms = conv_plan.time(iters, det.stream)
-        full_ms = dp.plan.time(iters, det.stream)
-        flops = dp.net_flops
-        peak = 157.3 if args.precision == "f32" else 2500.0
-        achieved = flops / (conv_ms * 1e-3) / 1e12
-        out["roofline"] = {
-            "bound": "mfma", "kernel": "conv_igemm_kernel<T,BM,BN,ALIGNED> (all instantiations)",
-            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4),
-            "traffic": None,
-            "flops_per_screenshot": flops, "conv_launches": len(conv_ops),
-            "conv_ms_per_screenshot": round(conv_ms, 4), "avg_launch_us": round(1000 * conv_ms / len(conv_ops), 3),
-            "plan_ms_per_screenshot_hip_events": round(full_ms, 4),
-            "algorithmic_bytes_per_screenshot": dp.net_bytes,
-        }
+        out["roofline"] = roofline(args, det, parser, locals().get("dp"), crop_counts, B)
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(blob, imgsz, conf, iou, max_det, args.cpu_samples)
+            out["cpu_baseline"] = cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0))
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
 
 
-def cpu_baseline(blob, imgsz, conf, iou, max_det, samples):
-    """Reference-equivalent CPU path on the host cores (oracle restatement of ref:util/yolov9.py)."""
+def roofline(args, det, parser, dp, crop_counts, B):
+    """conv_igemm_kernel family: algorithmic FLOPs of every conv/linear launch in one step divided by the
+    HIP-event time of exactly those launches (timed per plan on the stream they run on)."""
+    from omniparser_amd import _lib as L
+    peak = 157.3 if args.precision == "f32" else 2500.0
+
+    def conv_time(plan, stream, iters):
+        ops = [op for op in plan.ops if op.kind == L.OP_CONV]
+        sub = L.Plan(ops)
+        sub.run(stream); stream.synchronize()
+        return sub.time(iters, stream), len(ops)
+
+    flops = ms = 0.0
+    launches = 0
+    parts = {}
+    if args.mode == "detect":
+        t, n = conv_time(dp.plan, det.stream, 20)
+        flops, ms, launches = dp.net_flops, t, n
+        parts["detector"] = {"ms": round(t, 4), "gflop": round(dp.net_flops / 1e9, 2)}
+    else:
+        cap = parser.cap
+        ddp = next(iter(det._plans.values()))
+        t, n = conv_time(ddp.plan, det.stream, 5)
+        flops, ms, launches = ddp.net_flops, t, n
+        parts["detector_batch%d" % B] = {"ms": round(t, 4), "gflop": round(ddp.net_flops / 1e9, 2)}
+        crops = int(round(sum(crop_counts) / max(len(crop_counts), 1)))
+        mbs = [128] * (crops // 128) + ([cap.bucket(crops % 128)] if crops % 128 else [])
+        for bucket in sorted(set(mbs)):
+            key = (bucket, cap.resolution, 20)
+            if key not in cap._plans:
+                continue
+            cp = cap._plans[key]
+            te, ne = conv_time(cp.encode_plan, cap.stream, 2)
+            ts, ns = conv_time(cp.step_plan, cap.stream, 5)
+            cnt = mbs.count(bucket)
+            flops += cnt * (cp.encode_flops + 20 * cp.step_flops)
+            ms += cnt * (te + 20 * ts)
+            launches += cnt * (ne + 20 * ns)
+            parts["caption_mb%d_x%d" % (bucket, cnt)] = {"encode_ms": round(te, 3), "step_ms": round(ts, 4),
+                                                         "encode_gflop": round(cp.encode_flops / 1e9, 1),
+                                                         "step_gflop": round(cp.step_flops / 1e9, 3)}
+    achieved = flops / (ms * 1e-3) / 1e12
+    return {"bound": "mfma", "kernel": "conv_igemm_kernel<T,BM,BN,RB,ALIGNED> (+ splitk_reduce_kernel)",
+            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+            "flops_per_step": flops, "launches_per_step": launches, "kernel_ms_per_step": round(ms, 3),
+            "avg_launch_us": round(1000 * ms / max(launches, 1), 3), "parts": parts}
+
+
+def cpu_baseline(args, blob, imgsz, mean_crops):
+    """Reference-equivalent CPU path on the host cores (oracle/: torch.jit blob + PIL letterbox + restated
+    batched_nms; transformers Florence-2 fp32 on 768x768 crops), bounded sample."""
+    import numpy as np
     import torch
     from PIL import Image
     from oracle import detector_ref as D
     from omniparser_amd.synth import synthetic_screenshot
     model = torch.jit.load(str(blob), map_location="cpu").eval()
-    imgs = [Image.fromarray(synthetic_screenshot(s)) for s in range(samples)]
-    D.predict(model, imgs[0], conf=conf, imgsz=imgsz, iou=iou, max_det=max_det)   # warm-up
+    imgs = [Image.fromarray(synthetic_screenshot(s)) for s in range(2)]
+    D.predict(model, imgs[0], conf=CONF, imgsz=imgsz, iou=NMS_IOU, max_det=MAX_DET)
     t0 = time.perf_counter()
     for im in imgs:
-        D.predict(model, im, conf=conf, imgsz=imgsz, iou=iou, max_det=max_det)
-    dt = time.perf_counter() - t0
-    return {"value": round(samples / dt, 4), "unit": "screenshots/s", "cores": torch.get_num_threads(),
-            "kind": "port", "sample": f"{samples} synthetic 1920x1080 screenshots, detector stage "
-            f"(PIL Lanczos letterbox + TorchScript YOLOv9-E fp32 on CPU + decode + batched_nms), 1 warm-up"}
+        D.predict(model, im, conf=CONF, imgsz=imgsz, iou=NMS_IOU, max_det=MAX_DET)
+    t_det = (time.perf_counter() - t0) / len(imgs)
+    res = {"unit": "screenshots/s", "cores": torch.get_num_threads(), "kind": "port"}
+    if args.mode == "detect":
+        res.update(value=round(1.0 / t_det, 4), sample="2 screenshots, detector stage (PIL letterbox + TorchScript YOLOv9-E fp32 + decode + "
+                   "batched_nms), 1 warm-up")
+        return res
+    from oracle import preprocess_ref as PR
+    from omniparser_amd.florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS
+    from tools.make_weights import build_random_captioner
+    cap = build_random_captioner(0)
+    R = args.caption_res
+    n = 8
+    rng = np.random.default_rng(0)
+    img = synthetic_screenshot(0)
+    boxes = [(int(x), int(y), int(x) + 60, int(y) + 48) for x, y in zip(rng.integers(0, 1800, n), rng.integers(0, 1000, n))]
+    t0 = time.perf_counter()
+    pv = np.stack([PR.caption_pixel_values(img, b, R, CLIP_MEAN, CLIP_STD) for b in boxes])
+    pix = torch.from_numpy(pv).permute(0, 3, 1, 2).contiguous()
+    ids = torch.tensor([[cap.config.image_token_id] * ((R // 32) ** 2 + 1) + PROMPT_IDS] * n)
+    with torch.inference_mode():
+        cap.generate(input_ids=ids, pixel_values=pix, max_new_tokens=20, num_beams=1, do_sample=False)
+    t_crop = (time.perf_counter() - t0) / n
+    per_shot = t_det + mean_crops * t_crop
+    res.update(value=round(1.0 / per_shot, 5),
+               sample=f"detector on 2 screenshots ({t_det:.2f} s each) + crop/resize/Florence-2 generate on one batch of {n} crops at "
+                      f"{R}x{R} ({t_crop:.2f} s/crop), composed as t_det + {mean_crops} crops x t_crop (glue excluded)")
+    return res
 
 
 if __name__ == "__main__":

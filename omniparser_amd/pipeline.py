@@ -1,0 +1,135 @@
+"""Batched screen parser: B screenshots -> parsed elements, everything model-side on device.
+
+The reference parses one screenshot at a time (ref:util/omniparser.py:16-32).  Screenshots are
+independent units, so here a batch is parsed as: ONE detector graph over all B frames -> host glue per
+frame (the reference's list semantics, util/utils.py) -> the crops of ALL frames packed into 128-crop
+caption micro-batches (ref batch_size=128) -> on-device greedy decode.  Results equal a per-frame
+`get_som_labeled_img(...)[2]` call (same functions underneath); only the packing differs.
+"""
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import _lib as L
+from .florence import CLIP_MEAN, CLIP_STD, Florence2Captioner
+from .util import utils as U
+from .util.yolov9 import YOLOv9Detector
+
+
+class ScreenParser:
+    def __init__(self, detector: YOLOv9Detector, captioner: Florence2Captioner, processor=None,
+                 box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640, batch_size=128):
+        self.det, self.cap = detector, captioner
+        self.proc = processor or U.FlorenceProcessor(captioner.w.dir)
+        self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
+        self.max_det, self.imgsz, self.batch_size = max_det, imgsz, batch_size
+        self.stats = {}
+
+    # ---- stage 1: detector over the whole batch (one graph launch)
+    def detect(self, frames: Sequence[torch.Tensor]):
+        ih, iw = frames[0].shape[:2]
+        dp = self.det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=len(frames))
+        with torch.cuda.stream(self.det.stream):
+            for bi, f in enumerate(frames):
+                dp.img[bi].copy_(f, non_blocking=True)
+            dp.launch(self.det)
+            counts = dp.out_count.cpu()                     # sync
+            boxes = dp.out_boxes.cpu()
+        return [boxes[bi, : int(counts[bi])] for bi in range(len(frames))]
+
+    # ---- stage 2: host glue (reference semantics) -> elements + crop boxes
+    def glue(self, xyxy_px: torch.Tensor, w: int, h: int, ocr_bbox, ocr_text):
+        xyxy = xyxy_px / torch.Tensor([w, h, w, h])
+        if ocr_bbox:
+            ocr_r = (torch.tensor(ocr_bbox) / torch.Tensor([w, h, w, h])).tolist()
+        else:
+            ocr_r, ocr_text = [], []
+        ocr_el = [{"type": "text", "bbox": b, "interactivity": False, "content": t, "source": "box_ocr_content_ocr"}
+                  for b, t in zip(ocr_r, ocr_text) if U.int_box_area(b, w, h) > 0]
+        icon_el = [{"type": "icon", "bbox": b, "interactivity": True, "content": None}
+                   for b in xyxy.tolist() if U.int_box_area(b, w, h) > 0]
+        filtered = U.remove_overlap_new(boxes=icon_el, iou_threshold=self.iou_threshold, ocr_bbox=ocr_el)
+        if not ocr_el:
+            filtered = [e if isinstance(e, dict) else {"type": "icon", "bbox": e, "interactivity": True, "content": None,
+                                                        "source": "box_yolo_content_yolo"} for e in filtered]
+        elems = sorted(filtered, key=lambda x: x["content"] is None)
+        start = next((i for i, b in enumerate(elems) if b["content"] is None), -1)
+        boxes = [e["bbox"] for e in elems]
+        non_ocr = boxes[start:] if start else boxes        # ref:util/utils.py:92-95 quirk kept
+        crops = []
+        for c in non_ocr:
+            x0, x1, y0, y1 = int(c[0] * w), int(c[2] * w), int(c[1] * h), int(c[3] * h)
+            if x1 - x0 <= 0 or y1 - y0 <= 0 or x0 < 0 or y0 < 0:
+                continue
+            crops.append([x0, y0, min(x1, w), min(y1, h)])
+        return elems, crops
+
+    # ---- stage 3: caption all crops of all frames in packed micro-batches
+    def caption(self, frames: Sequence[torch.Tensor], crops_per_frame: List[List[List[int]]], max_new_tokens=20):
+        cap = self.cap
+        R = cap.resolution
+        flat = [(fi, b) for fi, cl in enumerate(crops_per_frame) for b in cl]
+        ids_all = []
+        if cap._lut is None:
+            cap._lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)).to(cap.device)
+            if R != 64:
+                b, k = L.resample_coeffs(64, R, 1)
+                cap._bic = (torch.from_numpy(b).to(cap.device), torch.from_numpy(k).to(cap.device), k.shape[1])
+        esz = 4 if cap.dtype == L.F32 else 2
+        for s in range(0, len(flat), self.batch_size):
+            chunk = flat[s:s + self.batch_size]
+            n = len(chunk)
+            cp = cap.plans(cap.bucket(n), R, max_new_tokens)
+            with torch.cuda.stream(cap.stream):
+                cp.reset()
+                c64 = torch.empty((n, 64, 64, 3), dtype=torch.uint8, device=cap.device)
+                tmp = torch.empty((n, 64, R, 3), dtype=torch.uint8, device=cap.device) if R != 64 else None
+                bb, kk, ks = cap._bic if R != 64 else (None, None, 0)
+                bx = torch.tensor([b for _, b in chunk], dtype=torch.int32).to(cap.device, non_blocking=True)
+                o = 0
+                while o < n:                                   # one crop launch per source frame run
+                    fi = chunk[o][0]
+                    e = o
+                    while e < n and chunk[e][0] == fi:
+                        e += 1
+                    H, W = frames[fi].shape[:2]
+                    op = L.make_op(
+                        L.OP_CROP_RESIZE, cap.dtype,
+                        p=[frames[fi].data_ptr(), bx[o:].data_ptr(), c64[o:].data_ptr(), tmp[o:].data_ptr() if tmp is not None else None,
+                           cp.x_in.ptr + o * R * R * cp.x_in.ld * esz, bb.data_ptr() if bb is not None else None,
+                           kk.data_ptr() if kk is not None else None, cap._lut.data_ptr()],
+                        i={0: e - o, 1: H, 2: W, 3: R, 4: ks, 13: cp.x_in.ld},
+                        f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
+                    L.launch(op, cap.stream)
+                    o = e
+                ids_all.append(cap._run(cp, n, max_new_tokens))
+        out = [[] for _ in frames]
+        k = 0
+        for ids in ids_all:
+            texts = [t.strip() for t in self.proc.batch_decode(ids, skip_special_tokens=True)]
+            for t, row in zip(texts, ids):
+                out[flat[k][0]].append((t, row))
+                k += 1
+        return out
+
+    @torch.inference_mode()
+    def parse_batch(self, frames: Sequence[torch.Tensor], ocr: Optional[Sequence] = None, return_ids=False):
+        """frames: uint8 [H,W,3] device tensors (same size); ocr: per frame (texts, xyxy px boxes) or None."""
+        ih, iw = frames[0].shape[:2]
+        det_boxes = self.detect(frames)
+        elems_all, crops_all = [], []
+        for fi, xy in enumerate(det_boxes):
+            texts, boxes = ocr[fi] if ocr is not None else ([], [])
+            el, cr = self.glue(xy, iw, ih, boxes, texts)
+            elems_all.append(el); crops_all.append(cr)
+        caps = self.caption(frames, crops_all)
+        ids_out = []
+        for el, cl in zip(elems_all, caps):
+            q = list(cl)
+            for e in el:
+                if e["content"] is None and q:
+                    e["content"] = q.pop(0)[0]
+            ids_out.append([r for _, r in cl])
+        self.stats = {"crops": [len(c) for c in crops_all], "boxes": [len(b) for b in det_boxes]}
+        return (elems_all, ids_out) if return_ids else elems_all
