@@ -41,19 +41,28 @@ struct DwArgs { const void* x; const void* w; const float* bias; void* y; int B,
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
-  // w layout: [3][3][C] (tap-major) in T; y = x + bias + sum_taps w*x   (conv(x) + x)
+  // w layout: [3][3][C] (tap-major) in T; y = x + bias + sum_taps w*x   (conv(x) + x).
+  // One 16-byte channel vector per lane: consecutive lanes walk consecutive channels of a pixel, the
+  // 3x3 neighbourhood is re-read through L1/L2, HBM sees x once and y once.
+  constexpr int V = ElemTraits<T>::kVec;
+  struct Vec { T v[V]; };
   const T* __restrict__ X = (const T*)a.x;
   const T* __restrict__ Wt = (const T*)a.w;
   T* __restrict__ Y = (T*)a.y;
-  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < a.total;
+  const int cv = a.C / V;
+  const long long total = a.total / V;
+  for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
        idx += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(idx % a.C);
-    long long pix = idx / a.C;
+    int c = (int)(idx % cv) * V;
+    long long pix = idx / cv;
     int w = (int)(pix % a.W);
     long long t = pix / a.W;
     int h = (int)(t % a.H);
     long long b = t / a.H;
-    float acc = 0.0f;
+    float acc[V];
+#pragma unroll
+    for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+    Vec ctr;
 #pragma unroll
     for (int r = 0; r < 3; ++r) {
       int hi = h + r - 1;
@@ -62,11 +71,17 @@ __global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
       for (int s = 0; s < 3; ++s) {
         int wi = w + s - 1;
         if (wi < 0 || wi >= a.W) continue;
-        acc += ldf(Wt + (r * 3 + s) * a.C + c) * ldf(X + ((b * a.H + hi) * a.W + wi) * a.C + c);
+        Vec xv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(X + ((b * a.H + hi) * a.W + wi) * a.C + c));
+        Vec wv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(Wt + (r * 3 + s) * a.C + c));
+        if (r == 1 && s == 1) ctr = xv;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[e] += ElemTraits<T>::to_f32(wv.v[e]) * ElemTraits<T>::to_f32(xv.v[e]);
       }
     }
-    acc += a.bias[c];
-    stf(Y + idx, acc + ldf(X + idx));
+    Vec out;
+#pragma unroll
+    for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((acc[e] + a.bias[c + e]) + ElemTraits<T>::to_f32(ctr.v[e]));
+    *reinterpret_cast<u32x4*>(Y + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
   }
 }
 
@@ -125,13 +140,13 @@ __device__ __forceinline__ long long window_row(const AttnArgs& a, int g, int i)
   return ((long long)b * a.H + r) * a.W + c;
 }
 
-template <typename T, int D>
-__global__ __launch_bounds__(128) void attn_rows_kernel(AttnArgs a) {
-  constexpr int KT = 32;                       // keys per LDS tile
+template <typename T, int D, int NT>
+__global__ __launch_bounds__(NT) void attn_rows_kernel(AttnArgs a) {
+  constexpr int KT = 48;                       // keys per LDS tile (144 = 3 tiles)
   __shared__ __attribute__((aligned(16))) float sk[KT][D];
   __shared__ __attribute__((aligned(16))) float sv[KT][D];
   const int g = blockIdx.z, h = blockIdx.y;
-  const int qi = blockIdx.x * 128 + threadIdx.x;
+  const int qi = blockIdx.x * NT + threadIdx.x;
   const T* Q = (const T*)a.q; const T* K = (const T*)a.k; const T* V = (const T*)a.v;
   long long qrow = -1;
   if (qi < a.nq) qrow = a.mode == 1 ? window_row(a, g, qi) : (long long)g * a.nq + qi;
@@ -141,21 +156,27 @@ __global__ __launch_bounds__(128) void attn_rows_kernel(AttnArgs a) {
   float m = -INFINITY, l = 0.0f;
   for (int k0 = 0; k0 < a.nk; k0 += KT) {
     __syncthreads();
-    for (int e = threadIdx.x; e < KT * D; e += 128) {
-      int kk = e / D, d = e - kk * D;
+    for (int e = threadIdx.x; e < KT * (D / 4); e += NT) {     // one 4-float group per lane
+      int kk = e / (D / 4), d = (e - kk * (D / 4)) * 4;
       int ki = k0 + kk;
-      float kvv = 0.0f, vvv = 0.0f;
+      float kq[4] = {0.f, 0.f, 0.f, 0.f}, vq[4] = {0.f, 0.f, 0.f, 0.f};
       if (ki < a.nk) {
         long long krow = a.mode == 1 ? window_row(a, g, ki) : (long long)g * a.nk + ki;
         if (krow >= 0) {
-          kvv = ldf(K + krow * a.ldk + a.koff + h * D + d);
-          vvv = ldf(V + krow * a.ldv + a.voff + h * D + d);
+          const T* kp = K + krow * a.ldk + a.koff + h * D + d;
+          const T* vp = V + krow * a.ldv + a.voff + h * D + d;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) { kq[u] = ldf(kp + u); vq[u] = ldf(vp + u); }
         } else {            // zero-padded window token: qkv(0) = bias, NOT masked (hf :345,372-379)
-          kvv = a.kbias ? a.kbias[h * D + d] : 0.0f;
-          vvv = a.vbias ? a.vbias[h * D + d] : 0.0f;
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            kq[u] = a.kbias ? a.kbias[h * D + d + u] : 0.0f;
+            vq[u] = a.vbias ? a.vbias[h * D + d + u] : 0.0f;
+          }
         }
       }
-      sk[kk][d] = kvv; sv[kk][d] = vvv;
+#pragma unroll
+      for (int u = 0; u < 4; ++u) { sk[kk][d + u] = kq[u]; sv[kk][d + u] = vq[u]; }
     }
     __syncthreads();
     int lim = a.nk - k0 < KT ? a.nk - k0 : KT;
@@ -542,8 +563,9 @@ int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
   OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
+  OMNI_REQUIRE(a.C % (op->dtype == OMNI_F32 ? 4 : 8) == 0, "dwconv3: C must be a multiple of the 16-byte vector width");
   a.total = (long long)a.B * a.H * a.W * a.C;
-  long long blocks = (a.total + 255) / 256; if (blocks > 65536) blocks = 65536;
+  long long blocks = (a.total / (op->dtype == OMNI_F32 ? 4 : 8) + 255) / 256; if (blocks > 65536) blocks = 65536;
   int rc = by_dtype(op->dtype, "dwconv3",
       [&] { hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); },
       [&] { hipLaunchKernelGGL(dwconv3_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
@@ -584,14 +606,21 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
     a.wy = (a.H + 11) / 12; a.wx = (a.W + 11) / 12;
     OMNI_REQUIRE(a.groups % (a.wy * a.wx) == 0, "attn_rows: groups must be B * windows");
   } else { a.wy = a.wx = 0; }
-  dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
   int rc;
-  if (D == 32) rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32>), grid, dim3(128), 0, s, a); },
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32>), grid, dim3(128), 0, s, a); });
-  else rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 64>), grid, dim3(128), 0, s, a); },
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 64>), grid, dim3(128), 0, s, a); });
+  if (a.mode == 1 && D == 32) {          // 12x12 window: 144 queries in one 192-thread workgroup
+    dim3 grid(1, a.heads, a.groups);
+    rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32, 192>), grid, dim3(192), 0, s, a); },
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32, 192>), grid, dim3(192), 0, s, a); });
+  } else {
+    dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
+    if (D == 32) rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32, 128>), grid, dim3(128), 0, s, a); },
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32, 128>), grid, dim3(128), 0, s, a); });
+    else rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 64, 128>), grid, dim3(128), 0, s, a); },
+      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 64, 128>), grid, dim3(128), 0, s, a); });
+  }
   if (rc) return rc;
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;

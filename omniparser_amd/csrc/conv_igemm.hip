@@ -25,6 +25,7 @@
 //     bias/act/residual) fills the 256 CUs when M*Cout is small (P4/P5 layers at batch 1).
 //   * concat / chunk are zero-copy: in_coff/ldi and out_coff/ldo address channel slices.
 #include "omni_internal.h"
+#include <stdlib.h>
 
 namespace {
 
@@ -33,7 +34,7 @@ struct ConvArgs {
   int B, H, W, Cin, ldi, in_coff, KH, KW, stride, pad, Ho, Wo;
   int Cout, ldo, out_coff, act, ldr, res_coff;
   int M, K, ktiles, cin_tiles;
-  int splits, kt_per_split;
+  int splits, kt_per_split, mtiles, ntiles;
   float* ws; long long ws_bytes;
   float scale;
 };
@@ -68,8 +69,16 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   const int lane = tid & 63;
   const int wave = tid >> 6;
   const int wm = wave >> 1, wn = wave & 1;
-  const int m0 = blockIdx.x * BM;
-  const int n0 = blockIdx.y * BN;
+  // XCD-aware tile order: workgroup b runs on XCD b % 8 (observed dispatch order; speed only).  Each XCD
+  // walks all N tiles of ONE M tile back to back, so the activation tile stays in that XCD's 4 MiB L2
+  // and is fetched from HBM once instead of once per N tile; the (small) weight matrix is shared via
+  // L2/Infinity Cache by everybody.
+  const int bid = blockIdx.x;
+  const int mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
+  const int nt = (bid >> 3) % a.ntiles;
+  if (mt >= a.mtiles) return;
+  const int m0 = mt * BM;
+  const int n0 = nt * BN;
   const int vec = tid % VPR;
   const int r0 = tid / VPR;
 
@@ -278,8 +287,10 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
 }
 
 template <typename T, int BM, int BN, int RB>
-void launch_cfg(const ConvArgs& a, bool aligned, hipStream_t s) {
-  dim3 grid((a.M + BM - 1) / BM, (a.Cout + BN - 1) / BN, a.splits);
+void launch_cfg(ConvArgs& a, bool aligned, hipStream_t s) {
+  a.mtiles = (a.M + BM - 1) / BM;
+  a.ntiles = (a.Cout + BN - 1) / BN;
+  dim3 grid(((a.mtiles + 7) / 8) * 8 * a.ntiles, 1, a.splits);
   if (aligned)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true>), grid, dim3(256), 0, s, a);
   else
@@ -300,6 +311,7 @@ ConvCfg choose_cfg(const ConvArgs& a) {
   constexpr int V = ElemTraits<T>::kVec;
   ConvCfg c;
   c.rb = (a.Cin % (8 * V) == 0) ? 128 : 64;
+  if (const char* e = getenv("OMNI_CONV_RB")) { if (atoi(e) == 64) c.rb = 64; }
   int bke = (c.rb / 16) * V;
   c.aligned = (a.Cin % bke) == 0;
   c.cin_tiles = c.aligned ? a.Cin / bke : 1;

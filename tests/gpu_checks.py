@@ -230,7 +230,11 @@ def _run_post(heads_cpu, nc, th, tw, conf, iou, max_det, iw, ih, scale, pad_left
                     i={0: A, 1: max_det, 2: iw, 3: ih}, f={0: iou})
     L.launch(op1); L.launch(op2); _sync()
     k = int(on.item()); n = int(count.item())
-    return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long(), n
+    rec = cand.cpu().view(torch.float32).view(-1, 8)[:n]
+    reci = cand.cpu().view(torch.int32).view(-1, 8)[:n]
+    order = torch.argsort(reci[:, 6])                     # compaction order is arbitrary: sort by anchor
+    cands = (rec[order, 0:4].clone(), rec[order, 4].clone(), reci[order, 5].long().clone(), reci[order, 6].long().clone())
+    return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long(), n, cands
 
 
 def _oracle_post(heads_cpu, conf, iou, max_det, iw, ih, scale, pad_left, pad_top):
@@ -248,11 +252,18 @@ def _oracle_post(heads_cpu, conf, iou, max_det, iw, ih, scale, pad_left, pad_top
     scores, class_ids, boxes = scores[valid], class_ids[valid], boxes[0][valid]
     boxes[:, [0, 2]] = (boxes[:, [0, 2]] - pad_left) / scale
     boxes[:, [1, 3]] = (boxes[:, [1, 3]] - pad_top) / scale
+    cand = (boxes.clone(), scores.clone(), class_ids.clone(), torch.nonzero(valid).flatten())
+    b, s_, c = _oracle_nms_clamp(boxes, scores, class_ids, iou, max_det, iw, ih)
+    return b, s_, c, int(valid.sum()), cand
+
+
+def _oracle_nms_clamp(boxes, scores, class_ids, iou, max_det, iw, ih):
+    from oracle import detector_ref as D
     keep = D.batched_nms(boxes, scores, class_ids, iou)[:max_det]
-    boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
+    boxes, scores, class_ids = boxes[keep].clone(), scores[keep], class_ids[keep]
     boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, iw)
     boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, ih)
-    return boxes, scores, class_ids, int(valid.sum())
+    return boxes, scores, class_ids
 
 
 def box_iou_pairs(a, b):
@@ -281,17 +292,32 @@ def check_post(seed=0, nc=1, th=160, tw=192, frac=0.08, conf=0.05, iou=0.1, max_
     scale = min(tw / iw, th / ih)
     rw, rh = int(iw * scale), int(ih * scale)
     pad_left, pad_top = (tw - rw) // 2, (th - rh) // 2
-    gb, gs, gc, n_gpu = _run_post(heads, nc, th, tw, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
-    rb, rs, rc, n_ref = _oracle_post(heads, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
+    gb, gs, gc, n_gpu, gcand = _run_post(heads, nc, th, tw, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
+    rb, rs, rc, n_ref, rcand = _oracle_post(heads, conf, iou, max_det, iw, ih, scale, pad_left, pad_top)
+    # (1) decode: same anchors pass the threshold, same classes, coordinates / scores to rounding (expf vs torch.exp)
     assert n_gpu == n_ref, f"candidate count {n_gpu} != {n_ref}"
-    assert len(gb) == len(rb), f"kept {len(gb)} != {len(rb)}"
-    assert (gc == rc).all(), "class ids differ"
-    assert torch.allclose(gs, rs, rtol=0, atol=2e-7), f"scores differ {(gs - rs).abs().max()}"
-    miou = box_iou_pairs(gb, rb).min().item() if len(gb) else 1.0
-    assert miou >= 0.999, f"min IoU {miou}"
-    return {"candidates": n_gpu, "kept": len(gb), "min_iou": miou,
-            "max_box_abs_diff": (gb - rb).abs().max().item() if len(gb) else 0.0,
-            "bitwise_boxes": bool((gb == rb).all())}
+    assert torch.equal(gcand[3], rcand[3]) and torch.equal(gcand[2], rcand[2]), "candidate anchors / classes differ"
+    assert torch.allclose(gcand[1], rcand[1], rtol=0, atol=2e-7), "candidate scores differ"
+    cand_err = (gcand[0] - rcand[0]).abs().max().item() if n_gpu else 0.0
+    assert cand_err < 2e-3, f"candidate boxes differ by {cand_err} px"
+    # (2) NMS: exact against the restated torchvision batched_nms run on the GPU's own candidates
+    xb, xs, xc = _oracle_nms_clamp(gcand[0], gcand[1], gcand[2], iou, max_det, iw, ih)
+    assert len(gb) == len(xb) and torch.equal(gb, xb) and torch.equal(gs, xs) and torch.equal(gc, xc), \
+        f"NMS keep-list differs from the oracle on identical candidates ({len(gb)} vs {len(xb)})"
+    out = {"candidates": n_gpu, "kept": len(gb), "cand_box_max_abs_diff": cand_err, "nms_exact_on_gpu_candidates": True}
+    # (3) whole post-processing vs the oracle path; a pair whose IoU sits within rounding of the threshold may flip
+    #     when thousands of candidates interact, so the strict comparison is applied to moderate N only
+    if n_gpu <= 600:
+        assert len(gb) == len(rb), f"kept {len(gb)} != {len(rb)}"
+        assert (gc == rc).all(), "class ids differ"
+        assert torch.allclose(gs, rs, rtol=0, atol=2e-7), f"scores differ {(gs - rs).abs().max()}"
+        miou = box_iou_pairs(gb, rb).min().item() if len(gb) else 1.0
+        assert miou >= 0.999, f"min IoU {miou}"
+        out.update(min_iou=miou, max_box_abs_diff=(gb - rb).abs().max().item() if len(gb) else 0.0,
+                   bitwise_boxes=bool((gb == rb).all()))
+    else:
+        out["min_iou"] = 1.0 if len(gb) == len(rb) and box_iou_pairs(gb, rb).min().item() >= 0.999 else None
+    return out
 
 
 def check_nms_known_answers():

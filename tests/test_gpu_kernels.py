@@ -34,14 +34,14 @@ def test_letterbox_matches_pillow(dtype):
 def test_decode_nms_vs_oracle(seed, nc, frac):
     import gpu_checks as G
     r = G.check_post(seed=seed, nc=nc, frac=frac)
-    assert r["min_iou"] >= 0.999
+    assert r["nms_exact_on_gpu_candidates"] and (r["min_iou"] is None or r["min_iou"] >= 0.999)
 
 
 def test_decode_nms_native_size():
     """A = 42 840 anchors (1088x1920 network input), thousands of candidates."""
     import gpu_checks as G
     r = G.check_post(seed=5, nc=1, th=1088, tw=1920, frac=0.05)
-    assert r["candidates"] > 1500
+    assert r["candidates"] > 1500 and r["nms_exact_on_gpu_candidates"]
 
 
 def test_nms_known_answers():

@@ -1,0 +1,42 @@
+"""Micro-benchmark of conv_igemm on the captioner's dominant GEMM shapes (HIP events, per variant)."""
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+SHAPES = [  # name, M, N, K, act, res
+    ("s2.fc1", 294912, 2048, 512, 2, False), ("s2.fc2", 294912, 512, 2048, 0, True), ("s2.qkv", 294912, 1536, 512, 0, False),
+    ("s2.proj", 294912, 512, 512, 0, True), ("s0.fc1", 4718592, 512, 128, 2, False), ("s0.fc2", 4718592, 128, 512, 0, True),
+    ("enc.fc1", 74880, 3072, 768, 2, False), ("s3.fc1", 73728, 4096, 1024, 2, False), ("det.p3", 51200, 128, 1152, 1, False),
+]
+
+
+def main():
+    import torch
+    from omniparser_amd import _lib as L
+    from omniparser_amd.planner import PlanBuilder, View
+    dtype = L.F32 if os.environ.get("OMNI_PRECISION", "f32") == "f32" else L.F16
+    tdt = torch.float32 if dtype == L.F32 else torch.float16
+    stream = torch.cuda.Stream()
+    for variant in os.environ.get("VARIANTS", "128,64").split(","):
+        os.environ["OMNI_CONV_RB"] = variant
+        print(f"--- OMNI_CONV_RB={variant}")
+        for name, M, N, K, act, res in SHAPES:
+            pb = PlanBuilder("cuda", dtype)
+            x = View(torch.randn(1, M, 1, K, device="cuda").to(tdt), 0, K)
+            w = pb.upload((torch.randn(N, K) * 0.05).to(tdt))
+            y = pb.alloc(1, M, 1, N)
+            r = View(torch.randn(1, M, 1, N, device="cuda").to(tdt), 0, N) if res else None
+            pb.conv(x, w, torch.randn(N), y, 1, act=act, res=r)
+            plan = pb.build()
+            plan.run(stream); stream.synchronize()
+            ms = plan.time(5, stream)
+            print(f"{name:8s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {2*M*N*K/ms/1e9:7.1f} TF/s")
+            del pb, plan, x, y, r
+            torch.cuda.empty_cache()
+
+
+if __name__ == "__main__":
+    main()
