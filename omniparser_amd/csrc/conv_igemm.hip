@@ -50,7 +50,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
   return v;
 }
 
-template <typename T, int BM, int BN, int RB, bool ALIGNED>
+template <typename T, int BM, int BN, int RB, bool ALIGNED, bool PW>
 __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   constexpr int V = ElemTraits<T>::kVec;   // elements per 16-byte vector
   constexpr int VPR = RB / 16;             // 16-byte vectors per K-slice row
@@ -117,21 +117,49 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   u32x4 ra[A_IT], rb[B_IT];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
 
+  // K-slice walker state: (tap r, tap s, first channel) advance incrementally — no divisions in the loop
+  int w_r = 0, w_s = 0, w_c = 0;
+  if (ALIGNED && !PW) {
+    int tap = kt0 / a.cin_tiles;
+    w_c = (kt0 - tap * a.cin_tiles) * BKE;
+    w_r = tap / a.KW;
+    w_s = tap - w_r * a.KW;
+  }
+  const T* a_row[A_IT];
+  if (PW) {
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      int m = m0 + r0 + it * RPP;
+      a_row[it] = X + (long long)(a_ok[it] ? m : 0) * a.ldi + a.in_coff + vec * V;
+    }
+  }
+
   auto load_tile = [&](int kt) {
-    int tap, c;
+    if (PW) {
+      // pointwise (1x1, stride 1, no padding): A is a plain row-major [M, ldi] matrix
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it)
+        rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + kt * BKE + vec * V) : zero4;
+      return;
+    }
+    int r, s, c;
     bool kok = true;
     if (ALIGNED) {
-      tap = kt / a.cin_tiles;
-      c = (kt - tap * a.cin_tiles) * BKE + vec * V;
+      r = w_r; s = w_s; c = w_c + vec * V;
+      w_c += BKE;
+      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
     } else {
       int k = kt * BKE + vec * V;
       kok = k < a.K;
       int kk = kok ? k : 0;
-      tap = kk / a.Cin;
+      int tap = kk / a.Cin;
       c = kk - tap * a.Cin;
+      r = tap / a.KW;
+      s = tap - r * a.KW;
     }
-    int r = tap / a.KW;
-    int s = tap - r * a.KW;
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       int hi = a_hi0[it] + r;
@@ -291,10 +319,13 @@ void launch_cfg(ConvArgs& a, bool aligned, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
   dim3 grid(((a.mtiles + 7) / 8) * 8 * a.ntiles, 1, a.splits);
-  if (aligned)
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true>), grid, dim3(256), 0, s, a);
+  const bool pw = aligned && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
+  if (pw)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true, true>), grid, dim3(256), 0, s, a);
+  else if (aligned)
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true, false>), grid, dim3(256), 0, s, a);
   else
-    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, false>), grid, dim3(256), 0, s, a);
+    hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, false, false>), grid, dim3(256), 0, s, a);
   if (a.splits > 1) {
     long long total = (long long)a.M * a.Cout;
     hipLaunchKernelGGL((splitk_reduce_kernel<T>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
@@ -311,7 +342,6 @@ ConvCfg choose_cfg(const ConvArgs& a) {
   constexpr int V = ElemTraits<T>::kVec;
   ConvCfg c;
   c.rb = (a.Cin % (8 * V) == 0) ? 128 : 64;
-  if (const char* e = getenv("OMNI_CONV_RB")) { if (atoi(e) == 64) c.rb = 64; }
   int bke = (c.rb / 16) * V;
   c.aligned = (a.Cin % bke) == 0;
   c.cin_tiles = c.aligned ? a.Cin / bke : 1;
@@ -321,6 +351,19 @@ ConvCfg choose_cfg(const ConvArgs& a) {
   auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
   if (blocks(c.bm, c.bn) < 1024 && c.bn == 128) c.bn = 64;
   if (blocks(c.bm, c.bn) < 1024) c.bm = 64;
+  // 128-row tiles: 64-byte K slices keep LDS at 40 KB -> 3 workgroups per CU (measured +8..25 % over 128-byte
+  // slices at 2 per CU); 64x64 tiles keep 128-byte slices (fewer barriers, LDS is not the limiter there)
+  int rb_env = 0;
+  if (const char* e = getenv("OMNI_CONV_RB")) rb_env = atoi(e);
+  if ((c.bm == 128 && rb_env != 128) || rb_env == 64) {
+    if (c.rb == 128) {
+      c.rb = 64;
+      bke = (c.rb / 16) * V;
+      c.aligned = (a.Cin % bke) == 0;
+      c.cin_tiles = c.aligned ? a.Cin / bke : 1;
+      c.ktiles = (a.K + bke - 1) / bke;
+    }
+  }
   long long nb = blocks(c.bm, c.bn);
   c.splits = 1;
   if (nb < 768 && a.ws) {
