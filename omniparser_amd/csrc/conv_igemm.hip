@@ -34,7 +34,7 @@ struct ConvArgs {
   int B, H, W, Cin, ldi, in_coff, KH, KW, stride, pad, Ho, Wo;
   int Cout, ldo, out_coff, act, ldr, res_coff;
   int M, K, ktiles, cin_tiles;
-  int splits, kt_per_split, mtiles, ntiles;
+  int splits, kt_per_split, mtiles, ntiles, xcd_order;
   float* ws; long long ws_bytes;
   float scale;
 };
@@ -74,9 +74,15 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // and is fetched from HBM once instead of once per N tile; the (small) weight matrix is shared via
   // L2/Infinity Cache by everybody.
   const int bid = blockIdx.x;
-  const int mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
-  const int nt = (bid >> 3) % a.ntiles;
-  if (mt >= a.mtiles) return;
+  int mt, nt;
+  if (a.xcd_order) {
+    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
+    nt = (bid >> 3) % a.ntiles;
+    if (mt >= a.mtiles) return;
+  } else {               // few M tiles: plain order keeps all 8 XCDs busy
+    mt = bid % a.mtiles;
+    nt = bid / a.mtiles;
+  }
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   const int vec = tid % VPR;
@@ -318,7 +324,8 @@ template <typename T, int BM, int BN, int RB>
 void launch_cfg(ConvArgs& a, bool aligned, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
-  dim3 grid(((a.mtiles + 7) / 8) * 8 * a.ntiles, 1, a.splits);
+  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
+  dim3 grid(a.xcd_order ? ((a.mtiles + 7) / 8) * 8 * a.ntiles : a.mtiles * a.ntiles, 1, a.splits);
   const bool pw = aligned && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
   if (pw)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true, true>), grid, dim3(256), 0, s, a);
