@@ -153,12 +153,9 @@ def _inside(a, b):
     return _inter(a, b) / _area(a) > 0.80
 
 
-def remove_overlap_new(boxes, iou_threshold, ocr_bbox=None):
-    """ref:util/utils.py:241-319 — same outputs, same list-mutation quirks, different bookkeeping.
-
-    An icon is dropped when some other icon overlaps it above the threshold and is smaller; OCR boxes
-    lying inside a kept icon donate their text to it and are removed from the output (first dict-equal
-    entry; a failed removal still donates the text); an icon lying inside an OCR box is dropped."""
+def _remove_overlap_new_simple(boxes, iou_threshold, ocr_bbox=None):
+    """Straightforward restatement of ref:util/utils.py:241-319 (kept as the cross-check of the vectorised
+    version below; O(K^2 + K*M) Python)."""
     assert ocr_bbox is None or isinstance(ocr_bbox, list)
     out = list(ocr_bbox) if ocr_bbox else []
     bb = [e["bbox"] for e in boxes]
@@ -187,6 +184,73 @@ def remove_overlap_new(boxes, iou_threshold, ocr_bbox=None):
                         "content": labels if labels else None,
                         "source": "box_yolo_content_ocr" if labels else "box_yolo_content_yolo"})
     return out
+
+
+def _pair_inter(a, b):
+    """f64 intersection areas [len(a), len(b)] with the reference's operation order."""
+    iw = np.minimum(a[:, None, 2], b[None, :, 2]) - np.maximum(a[:, None, 0], b[None, :, 0])
+    ih = np.minimum(a[:, None, 3], b[None, :, 3]) - np.maximum(a[:, None, 1], b[None, :, 1])
+    return np.maximum(0, iw) * np.maximum(0, ih)
+
+
+def remove_overlap_new(boxes, iou_threshold, ocr_bbox=None):
+    """ref:util/utils.py:241-319 — same outputs and list-mutation quirks, vectorised (numpy f64 = the
+    reference's Python-float arithmetic, same operation order) so the detect -> caption hand-off costs
+    ~1 ms instead of ~100 ms of interpreter time at 300 boxes.
+
+    An icon is dropped when some other icon overlaps it above the threshold and is smaller; OCR boxes
+    lying inside a kept icon donate their text to it and are removed from the output (first dict-equal
+    entry; a failed removal still donates the text); an icon lying inside an OCR box is dropped."""
+    assert ocr_bbox is None or isinstance(ocr_bbox, list)
+    out = list(ocr_bbox) if ocr_bbox else []
+    n = len(boxes)
+    if n == 0:
+        return out
+    bb = np.asarray([e["bbox"] for e in boxes], dtype=np.float64).reshape(n, 4)
+    area = (bb[:, 2] - bb[:, 0]) * (bb[:, 3] - bb[:, 1])
+    inter = _pair_inter(bb, bb)
+    with np.errstate(divide="ignore", invalid="ignore"):
+        iou = inter / (area[:, None] + area[None, :] - inter + 1e-6)
+        pos = (area[:, None] > 0) & (area[None, :] > 0)
+        r1 = np.where(pos, inter / area[:, None], 0.0)
+        r2 = np.where(pos, inter / area[None, :], 0.0)
+    ov = np.maximum(np.maximum(iou, r1), r2)
+    bad = (ov > iou_threshold) & (area[:, None] > area[None, :])
+    np.fill_diagonal(bad, False)
+    valid = ~bad.any(1)
+    if not ocr_bbox:
+        out.extend(boxes[i]["bbox"] for i in range(n) if valid[i])   # reference appends bare boxes without an OCR list
+        return out
+    m = len(ocr_bbox)
+    ob = np.asarray([t["bbox"] for t in ocr_bbox], dtype=np.float64).reshape(m, 4)
+    oarea = (ob[:, 2] - ob[:, 0]) * (ob[:, 3] - ob[:, 1])
+    io = _pair_inter(bb, ob)                                     # [icons, ocr]
+    ocr_in_icon = io / oarea[None, :] > 0.80                     # ZeroDivisionError in the reference <-> inf/nan here: never hit (int area > 0)
+    icon_in_ocr = io / area[:, None] > 0.80
+    # removal bookkeeping: `list.remove(x)` deletes the first remaining dict-equal entry
+    key = [(tuple(t["bbox"]), t["content"], t["type"], t["interactivity"], t.get("source")) for t in ocr_bbox]
+    alive = [True] * m
+    members = {}
+    for t_i, k in enumerate(key):
+        members.setdefault(k, []).append(t_i)
+    appended = []
+    for i in np.nonzero(valid)[0]:
+        stop = np.nonzero(~ocr_in_icon[i] & icon_in_ocr[i])[0]
+        upto = stop[0] if len(stop) else m
+        donors = np.nonzero(ocr_in_icon[i, :upto])[0]
+        labels = ""
+        for t_i in donors:
+            labels += ocr_bbox[t_i]["content"] + " "
+            for cand in members[key[t_i]]:
+                if alive[cand]:
+                    alive[cand] = False
+                    break
+        if len(stop):
+            continue
+        appended.append({"type": "icon", "bbox": boxes[i]["bbox"], "interactivity": True,
+                         "content": labels if labels else None,
+                         "source": "box_yolo_content_ocr" if labels else "box_yolo_content_yolo"})
+    return [t for t_i, t in enumerate(ocr_bbox) if alive[t_i]] + appended
 
 
 @torch.inference_mode()

@@ -94,3 +94,31 @@ def test_empty_ocr_is_tolerated():
     enc, lab, elems = get_som_labeled_img(img, _FakeDet(xyxy), ocr_bbox=None, ocr_text=[],
                                           caption_model_processor={"model": _FakeCap(), "processor": _FakeProc()})
     assert [e["content"] for e in elems] == ["cap0", "cap1"] and all(e["type"] == "icon" for e in elems)
+
+
+def test_vectorised_overlap_removal_equals_simple_restatement():
+    """randomised cross-check incl. duplicated OCR entries, nested boxes and the no-OCR branch."""
+    from omniparser_amd.util.utils import _remove_overlap_new_simple, remove_overlap_new
+    rng = np.random.default_rng(7)
+    for trial in range(60):
+        w, h = 1920, 1080
+        n, m = int(rng.integers(0, 80)), int(rng.integers(0, 30))
+        xy = rng.uniform(0, 1, (n, 2)) * [w - 150, h - 150]
+        wh = rng.uniform(5, 150, (n, 2))
+        ic = np.concatenate([xy, xy + wh], 1)
+        for j in range(0, max(n - 1, 0), 3):
+            ic[j + 1] = ic[j] + rng.uniform(-6, 6, 4)
+        oc = np.concatenate([rng.uniform(0, 1, (m, 2)) * [w - 200, h - 60], np.zeros((m, 2))], 1)
+        oc[:, 2:] = oc[:, :2] + rng.uniform(8, 200, (m, 2))
+        for j in range(0, min(n, m), 2):
+            oc[j] = ic[j] + ([3, 3, -3, -3] if j % 4 == 0 else [-20, -20, 20, 20])
+        if m > 3:
+            oc[2] = oc[1]
+        icons = [{"type": "icon", "bbox": b, "interactivity": True, "content": None}
+                 for b in (torch.tensor(ic, dtype=torch.float32).reshape(-1, 4) / torch.Tensor([w, h, w, h])).tolist()]
+        ocr = [{"type": "text", "bbox": b, "interactivity": False, "content": f"t{j % 5}", "source": "box_ocr_content_ocr"}
+               for j, b in enumerate((torch.tensor(oc, dtype=torch.float32).reshape(-1, 4) / torch.Tensor([w, h, w, h])).tolist())]
+        thr = [0.1, 0.7, 0.9][trial % 3]
+        a = remove_overlap_new(copy.deepcopy(icons), thr, copy.deepcopy(ocr) if (ocr and trial % 5) else None)
+        b = _remove_overlap_new_simple(copy.deepcopy(icons), thr, copy.deepcopy(ocr) if (ocr and trial % 5) else None)
+        assert a == b, trial
