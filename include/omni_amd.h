@@ -65,7 +65,9 @@ enum {
    *  p3 residual [M,ldr] or NULL   p4 y [B,Ho,Wo,ldo]
    *  i0 B i1 H i2 W i3 Cin i4 ldi i5 in_coff i6 KH i7 KW i8 stride i9 pad i10 Ho i11 Wo
    *  i12 Cout i13 ldo i14 out_coff i15 act i16 ldr i17 res_coff
-   *  p5 optional split-K workspace (f32), i19 its size in KiB   f0 output scale (0 => 1) */
+   *  p5 optional split-K workspace (f32), i19 its size in KiB   f0 output scale (0 => 1)
+   *  i20 = 1: split-f16 mode (f32 activations; w = [Cout][K/16][16 hi | 16 lo] f16 halves with w = hi + lo*2^-11;
+   *           three f16 MFMAs per block give f32-class accuracy at the f16 matrix rate; needs Cin % 32 == 0) */
   OMNI_OP_CONV = 1,
   /* avg_pool2d(k=2,s=1,p=0) (ADown, ref blob T1).  p0 x, p4 y.
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */

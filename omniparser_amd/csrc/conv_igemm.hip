@@ -26,6 +26,7 @@
 //   * concat / chunk are zero-copy: in_coff/ldi and out_coff/ldo address channel slices.
 #include "omni_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 namespace {
 
@@ -320,6 +321,268 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
   reinterpret_cast<T*>(a.y)[m * a.ldo + a.out_coff + n] = ElemTraits<T>::from_f32(v);
 }
 
+
+// ---------------------------------------------------------------------------------------------------------
+// Split-f16 path: f32-class accuracy at the f16 MFMA rate.
+//   a = ah + al * 2^-11,  w = wh + wl * 2^-11   (ah, wh = RTNE f16; al, wl = f16 of the scaled remainder)
+//   a.w  ~=  ah.wh  +  2^-11 (ah.wl + al.wh)      (dropped al.wl term: 2^-22 relative)
+// Three v_mfma_f32_32x32x16_f16 (32 cycles each) replace eight v_mfma_f32_32x32x2_f32 (64 cycles each) per
+// 32x32x16 block: 5.3x fewer matrix-pipe cycles.  Products of f16 pairs are exact in f32; both partial sums
+// accumulate in f32 (two accumulator sets) and are combined in the epilogue, so the result carries ~22 mantissa
+// bits per operand — measured error vs f64 is at or below a plain f32 GEMM's accumulation error.
+// Activations stay f32 in HBM and are split on the fly while staging to LDS; weights are split once on the host
+// and stored as [Cout][K/16][16 hi | 16 lo] halves, i.e. the same 128 bytes per 32-wide K slice as f32 weights.
+__device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& lo) {
+  f32x4 v = __builtin_bit_cast(f32x4, raw);
+  half_t h[4], l[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    float a = fminf(fmaxf(v[e], -65504.0f), 65504.0f);
+    h[e] = (half_t)a;
+    l[e] = (half_t)((a - (float)h[e]) * 2048.0f);
+  }
+  f16x4 hv = {h[0], h[1], h[2], h[3]}, lv = {l[0], l[1], l[2], l[3]};
+  hi = __builtin_bit_cast(uint2, hv);
+  lo = __builtin_bit_cast(uint2, lv);
+}
+
+template <int BM, int BN, bool PW>
+__global__ __launch_bounds__(256) void conv_split_kernel(ConvArgs a) {
+  constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = 32;
+  constexpr int BKE = 32;                  // f32 elements of K per slice
+  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int STAGE = (BM + BN) * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 1, wn = wave & 1;
+  const int bid = blockIdx.x;
+  int mt, nt;
+  if (a.xcd_order) {
+    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
+    nt = (bid >> 3) % a.ntiles;
+    if (mt >= a.mtiles) return;
+  } else {
+    mt = bid % a.mtiles;
+    nt = bid / a.mtiles;
+  }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int vec = tid % VPR, r0 = tid / VPR;
+  const int kt0 = blockIdx.z * a.kt_per_split;
+  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
+
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(a.w);   // 4 bytes per (n, k)
+
+  long long a_base[A_IT];
+  int a_hi0[A_IT], a_wi0[A_IT];
+  bool a_ok[A_IT];
+  const float* a_row[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    int m = m0 + r0 + it * RPP;
+    a_ok[it] = m < a.M;
+    int mm = a_ok[it] ? m : 0;
+    int wo = mm % a.Wo;
+    int t = mm / a.Wo;
+    int ho = t % a.Ho;
+    int b = t / a.Ho;
+    a_hi0[it] = ho * a.stride - a.pad;
+    a_wi0[it] = wo * a.stride - a.pad;
+    a_base[it] = (long long)b * a.H * a.W * a.ldi + a.in_coff;
+    a_row[it] = X + (long long)mm * a.ldi + a.in_coff + vec * 4;
+  }
+  const unsigned char* b_ptr[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    int n = n0 + r0 + it * RPP;
+    b_ok[it] = n < a.Cout;
+    b_ptr[it] = Wb + (long long)(b_ok[it] ? n : 0) * a.K * 4 + vec * 16;
+  }
+  int w_r = 0, w_s = 0, w_c = 0;
+  if (!PW) {
+    int tap = kt0 / a.cin_tiles;
+    w_c = (kt0 - tap * a.cin_tiles) * BKE;
+    w_r = tap / a.KW;
+    w_s = tap - w_r * a.KW;
+  }
+
+  u32x4 ra[A_IT], rb[B_IT];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](int kt) {
+    if (PW) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
+    } else {
+      int r = w_r, s = w_s, c = w_c + vec * 4;
+      w_c += BKE;
+      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
+        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
+      }
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + (long long)kt * RB) : zero4;
+  };
+  // LDS row = two 16-wide K blocks, each [16 hi halves | 16 lo halves]
+  const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
+  auto store_tile = [&](int stage) {
+    unsigned char* sA = lds + stage * STAGE;
+    unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      uint2 hi, lo;
+      split_f16x4(ra[it], hi, lo);
+      unsigned char* p = sA + (r0 + it * RPP) * ROWB + a_wr;
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + 32) = lo;
+    }
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
+  };
+
+  f32x16 accM[TM][TN], accC[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
+
+  const int a_rd = (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_rd = BM * ROWB + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+
+  if (kt0 < kt1) { load_tile(kt0); store_tile(0); }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    const unsigned char* st = lds + cur * STAGE;
+#pragma unroll
+    for (int j16 = 0; j16 < 2; ++j16) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64);
+        al[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64 + 32);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64);
+        bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64 + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
+        }
+    }
+    if (more) store_tile(cur ^ 1);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const float inv = 1.0f / 2048.0f;
+  if (a.splits > 1) {
+    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      if (n >= a.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][j][e] + accC[i][j][e] * inv;
+        }
+      }
+    }
+    return;
+  }
+  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
+  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
+  const float scale = a.scale;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    bool nok = n < a.Cout;
+    float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = mb + (e & 3) + 8 * (e >> 2);
+        if (nok && m < a.M) {
+          float v = (accM[i][j][e] + accC[i][j][e] * inv) + bias;
+          if (scale != 0.0f) v *= scale;
+          v = act_apply(v, a.act);
+          if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
+          Y[(long long)m * a.ldo + a.out_coff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN>
+void launch_split_cfg(ConvArgs& a, hipStream_t s) {
+  a.mtiles = (a.M + BM - 1) / BM;
+  a.ntiles = (a.Cout + BN - 1) / BN;
+  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
+  dim3 grid(a.xcd_order ? ((a.mtiles + 7) / 8) * 8 * a.ntiles : a.mtiles * a.ntiles, 1, a.splits);
+  const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
+  if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((conv_split_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
+  if (a.splits > 1) {
+    long long total = (long long)a.M * a.Cout;
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
+}
+
+void launch_split(ConvArgs& a, hipStream_t s) {
+  a.cin_tiles = a.Cin / 32;
+  a.ktiles = a.K / 32;
+  int bn = a.Cout > 64 ? 128 : 64, bm = 128;
+  auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
+  if (blocks(bm, bn) < 1024 && bn == 128) bn = 64;
+  if (blocks(bm, bn) < 1024) bm = 64;
+  long long nb = blocks(bm, bn);
+  a.splits = 1;
+  if (nb < 768 && a.ws) {
+    int want = (int)((1024 + nb - 1) / nb);
+    int maxs = a.ktiles / 4;
+    if (maxs > 32) maxs = 32;
+    long long cap = a.ws_bytes / ((long long)a.M * a.Cout * 4);
+    if (maxs > cap) maxs = (int)cap;
+    a.splits = want < maxs ? want : maxs;
+    if (a.splits < 2) a.splits = 1;
+  }
+  a.kt_per_split = (a.ktiles + a.splits - 1) / a.splits;
+  a.splits = (a.ktiles + a.kt_per_split - 1) / a.kt_per_split;
+  if (const char* e = getenv("OMNI_SPLIT_TILE")) {        // tuning knob
+    if (bm == 128 && !strcmp(e, "128x64")) bn = 64;
+    if (bm == 128 && !strcmp(e, "128x128") && a.Cout > 64) bn = 128;
+  }
+  if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
+  else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);
+  else launch_split_cfg<64, 64>(a, s);
+}
+
 template <typename T, int BM, int BN, int RB>
 void launch_cfg(ConvArgs& a, bool aligned, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
@@ -427,7 +690,10 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(M < (1ll << 31), "conv: M too large");
   a.M = (int)M;
   a.K = a.KH * a.KW * a.Cin;
-  if (op->dtype == OMNI_F32) launch_typed<float>(a, s);
+  if (op->i[20]) {        // split-f16 weights ([Cout][K/16][16 hi | 16 lo]) + f32 activations
+    OMNI_REQUIRE(op->dtype == OMNI_F32 && a.Cin % 32 == 0, "conv: split-f16 mode needs f32 activations and Cin %% 32 == 0");
+    launch_split(a, s);
+  } else if (op->dtype == OMNI_F32) launch_typed<float>(a, s);
   else launch_typed<half_t>(a, s);
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;

@@ -3,6 +3,7 @@
 Tensors are NHWC.  A `View` is a channel slice [coff, coff+C) of a buffer with `ld` channels per
 pixel, so chunk/concat/split never copy: producers write into slices, consumers read slices.
 """
+import os
 from dataclasses import dataclass
 from typing import Optional
 
@@ -52,6 +53,9 @@ class PlanBuilder:
         self.V = vec_width(dtype)
         self.ops = []
         self.keep = []           # keep-alive for every tensor referenced by raw pointer
+        # OMNI_CONV_SPLIT=1: f32 plans run their GEMMs on the split-f16 MFMA path (f32-class accuracy, f16 matrix rate)
+        self.split = os.environ.get("OMNI_CONV_SPLIT", "0") == "1"
+        self.split_weights = set()
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
         self.flops = 0           # 2*MAC of all conv ops (algorithmic work, for the roofline)
@@ -74,6 +78,17 @@ class PlanBuilder:
         self.keep.append(t)
         return t
 
+    @staticmethod
+    def split_f16(w2d: torch.Tensor) -> torch.Tensor:
+        """[Cout, K] f32 (K % 16 == 0) -> f16 [Cout, K/16, 32]: per 16-wide K block 16 hi halves then 16 lo halves,
+        w = hi + lo * 2^-11 (conv_igemm.hip split-f16 path)."""
+        cout, K = w2d.shape
+        assert K % 16 == 0
+        w2d = w2d.float().clamp(-65504.0, 65504.0)
+        hi = w2d.to(torch.float16)
+        lo = ((w2d - hi.float()) * 2048.0).to(torch.float16)
+        return torch.cat([hi.view(cout, K // 16, 16), lo.view(cout, K // 16, 16)], -1).contiguous()
+
     def pack_weight(self, w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
         """[Cout, Cin, kh, kw] f32 -> device [Cout, kh*kw*Cin'] in plan dtype (k = (r*kw+s)*Cin'+c)."""
         w = w.detach().float()
@@ -81,6 +96,11 @@ class PlanBuilder:
         if cin_pad and cin_pad > cin:
             w = torch.cat([w, w.new_zeros(cout, cin_pad - cin, kh, kw)], 1)
         w = w.permute(0, 2, 3, 1).reshape(cout, -1)
+        cin_eff = max(cin, cin_pad or 0)
+        if self.split and self.dtype == L.F32 and cin_eff % 32 == 0:
+            t = self.upload(self.split_f16(w))
+            self.split_weights.add(t.data_ptr())
+            return t
         return self.upload(w.to(torch_dtype(self.dtype)))
 
     # ---- ops
@@ -91,7 +111,11 @@ class PlanBuilder:
         Wo = (x.W + 2 * p - k) // s + 1
         assert (out.B, out.H, out.W) == (x.B, Ho, Wo), ((out.B, out.H, out.W), (x.B, Ho, Wo))
         cout = out.C
-        assert tuple(w_packed.shape) == (cout, k * k * x.C), (tuple(w_packed.shape), cout, k, x.C)
+        is_split = w_packed.dtype == torch.float16 and self.dtype == L.F32
+        if is_split:
+            assert w_packed.numel() == 2 * cout * k * k * x.C and x.C % 32 == 0, (tuple(w_packed.shape), cout, k, x.C)
+        else:
+            assert tuple(w_packed.shape) == (cout, k * k * x.C), (tuple(w_packed.shape), cout, k, x.C)
         if res is not None:
             assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
         b = None
@@ -108,7 +132,7 @@ class PlanBuilder:
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
-               19: self.ws_kib if self.ws is not None else 0},
+               19: self.ws_kib if self.ws is not None else 0, 20: 1 if is_split else 0},
             f={0: scale})
         self.ops.append(op)
         self.keep.append(w_packed)

@@ -56,7 +56,11 @@ def run_op(op, m):
     if k == L.OP_CONV:
         B, H, W, Cin, ldi, icoff, KH, KW, s, pad, Ho, Wo, Cout, ldo, ocoff, act, ldr, rcoff = [i[j] for j in range(18)]
         x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi)[..., icoff:icoff + Cin].permute(0, 3, 1, 2).float()
-        w = m.at(p[1], dt)[: Cout * KH * KW * Cin].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2).float()
+        if i[20]:
+            hl = m.at(p[1], torch.float16)[: 2 * Cout * KH * KW * Cin].view(Cout, KH * KW * Cin // 16, 2, 16).float()
+            w = (hl[:, :, 0] + hl[:, :, 1] / 2048.0).reshape(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
+        else:
+            w = m.at(p[1], dt)[: Cout * KH * KW * Cin].view(Cout, KH, KW, Cin).permute(0, 3, 1, 2).float()
         b = m.at(p[2], torch.float32)[:Cout] if p[2] else None
         y = F.conv2d(x, w, b, stride=s, padding=pad)
         if f[0] != 0.0:

@@ -20,20 +20,32 @@ def main():
     dtype = L.F32 if os.environ.get("OMNI_PRECISION", "f32") == "f32" else L.F16
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     stream = torch.cuda.Stream()
-    for variant in os.environ.get("VARIANTS", "128,64").split(","):
-        os.environ["OMNI_CONV_RB"] = variant
-        print(f"--- OMNI_CONV_RB={variant}")
+    for variant in os.environ.get("VARIANTS", "f32,split:128x64,split:128x128").split(","):
+        os.environ["OMNI_CONV_SPLIT"] = "1" if variant.startswith("split") else "0"
+        if ":" in variant:
+            os.environ["OMNI_SPLIT_TILE"] = variant.split(":")[1]
+        print(f"--- variant {variant}")
         for name, M, N, K, act, res in SHAPES:
             pb = PlanBuilder("cuda", dtype)
             x = View(torch.randn(1, M, 1, K, device="cuda").to(tdt), 0, K)
-            w = pb.upload((torch.randn(N, K) * 0.05).to(tdt))
+            wcpu = torch.randn(N, K) * 0.05
+            w = pb.pack_weight(wcpu[:, :, None, None])
             y = pb.alloc(1, M, 1, N)
             r = View(torch.randn(1, M, 1, N, device="cuda").to(tdt), 0, N) if res else None
-            pb.conv(x, w, torch.randn(N), y, 1, act=act, res=r)
+            bias = torch.randn(N)
+            pb.conv(x, w, bias, y, 1, act=act, res=r)
             plan = pb.build()
             plan.run(stream); stream.synchronize()
             ms = plan.time(5, stream)
-            print(f"{name:8s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {2*M*N*K/ms/1e9:7.1f} TF/s")
+            # accuracy on the first 256 rows vs f64
+            xs = x.t[0, :256, 0, :].double().cpu()
+            ref = xs @ wcpu.double().t()
+            got = y.t[0, :256, 0, :].double().cpu()
+            if act == 0 and not res:
+                err = ((got - (ref + bias.double())).abs().max() / ref.abs().max()).item()
+            else:
+                err = float("nan")
+            print(f"{name:8s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {2*M*N*K/ms/1e9:7.1f} TF/s  relerr {err:.2e}")
             del pb, plan, x, y, r
             torch.cuda.empty_cache()
 
