@@ -97,7 +97,7 @@ class PlanBuilder:
             w = torch.cat([w, w.new_zeros(cout, cin_pad - cin, kh, kw)], 1)
         w = w.permute(0, 2, 3, 1).reshape(cout, -1)
         cin_eff = max(cin, cin_pad or 0)
-        if self.split and self.dtype == L.F32 and cin_eff % 32 == 0:
+        if self.split and self.dtype == L.F32 and cin_eff % 32 == 0 and cin_eff * kh * kw >= 128:
             t = self.upload(self.split_f16(w))
             self.split_weights.add(t.data_ptr())
             return t
