@@ -53,8 +53,9 @@ class PlanBuilder:
         self.V = vec_width(dtype)
         self.ops = []
         self.keep = []           # keep-alive for every tensor referenced by raw pointer
-        # OMNI_CONV_SPLIT=1: f32 plans run their GEMMs on the split-f16 MFMA path (f32-class accuracy, f16 matrix rate)
-        self.split = os.environ.get("OMNI_CONV_SPLIT", "0") == "1"
+        # f32 plans run their long-K GEMMs on the split-f16 MFMA path (f32-class accuracy at the f16 matrix rate;
+        # measured error vs f64 <= the exact-f32 MFMA path).  OMNI_CONV_SPLIT=0 selects v_mfma_f32_32x32x2_f32 everywhere.
+        self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
         self.split_weights = set()
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024

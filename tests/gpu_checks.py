@@ -439,6 +439,14 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
         in_bad = int((xin != dbg["input"][0]).sum()) if precision == "f32" else int(((xin - dbg["input"][0]).abs() > 1e-3).sum())
         rec = {"seed": s, "n_ref": len(rb), "n_gpu": len(gb), "input_mismatch": in_bad, "head_err(cls,dist)": errs,
                "oracle_noise(cls,dist,gpu_vs_f64)": noise, "cand_ref": int(dbg["valid"].sum())}
+        if len(rb) and len(gb):
+            # order-free matching (two boxes with near-equal scores may swap ranks under rounding noise)
+            x1 = torch.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = torch.maximum(rb[:, None, 1], gb[None, :, 1])
+            x2 = torch.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = torch.minimum(rb[:, None, 3], gb[None, :, 3])
+            inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+            ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+            iou = inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)
+            rec["matched_min_iou"] = iou.max(1).values.min().item()
         if len(rb) == len(gb) and len(rb) > 0:
             rec["min_iou"] = box_iou_pairs(gb, rb).min().item()
             rec["max_score_diff"] = (gs - rs).abs().max().item()

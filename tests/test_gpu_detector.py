@@ -36,4 +36,6 @@ def test_detector_full_width_boxes():
     for rec in out["images"]:
         assert rec["input_mismatch"] == 0
         _assert_network_within_oracle_noise(rec)
+        assert rec["n_ref"] == rec["n_gpu"] and rec["cls_equal"]
+        assert rec["matched_min_iou"] >= 0.999, rec
     print(out)
