@@ -161,7 +161,7 @@ def main():
         "metric": "screenshots/sec end-to-end (detect+caption) @1920x1080",
         "value": round(value, 4), "unit": "screenshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-        "dtype": args.precision,
+        "dtype": args.precision,   # activation / accumulate type (f32 = parity mode; its long-K GEMMs use split-f16 MFMA)
         "data": "synthetic 1920x1080 GUI-like screenshots (8 seeds) + synthetic OCR boxes; seeded random-weight YOLOv9-E blob "
                 "and Florence-2-base-shaped checkpoint",
         "config": {
@@ -170,6 +170,9 @@ def main():
             "conf": CONF, "nms_iou": NMS_IOU, "overlap_iou": OVERLAP_IOU, "max_det": MAX_DET,
             "parallelism": f"replicas x{world}, round-robin shards of steps, 1 all_gather/job",
             "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
+            "gemm_path": ("split-f16 x3 MFMA (f32-class accuracy)" if args.precision == "f32" and
+                          os.environ.get("OMNI_CONV_SPLIT", "1") == "1" else
+                          ("exact f32 MFMA" if args.precision == "f32" else "f16 MFMA")),
         },
     }
     if args.mode == "e2e":
@@ -228,10 +231,21 @@ def roofline(args, det, parser, dp, crop_counts, B):
                                                          "encode_gflop": round(cp.encode_flops / 1e9, 1),
                                                          "step_gflop": round(cp.step_flops / 1e9, 3)}
     achieved = flops / (ms * 1e-3) / 1e12
-    return {"bound": "mfma", "kernel": "conv_igemm_kernel<T,BM,BN,RB,ALIGNED> (+ splitk_reduce_kernel)",
-            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None,
+    split = args.precision == "f32" and os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
+    if split:
+        # f32 plans run their GEMMs as split-f16 MFMA: the matrix pipe bounding the kernel is the dense f16 one
+        # (2.5 PF/s); every algorithmic MAC issues 3 MFMA products, so pipe utilisation = 3 * achieved / peak.
+        peak = 2500.0
+    out = {"bound": "mfma", "kernel": ("conv_split_kernel<BM,BN,PW> (split-f16 x3 MFMA, f32 accumulate)" if split else
+                                       "conv_igemm_kernel<T,BM,BN,RB,ALIGNED,PW>") + " + splitk_reduce_kernel",
+           "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
+    if split:
+        out.update(mfma_products_per_mac=3, matrix_pipe_utilisation=round(3 * achieved / peak, 4),
+                   vs_f32_mfma_peak=round(achieved / 157.3, 3))
+    out.update({
             "flops_per_step": flops, "launches_per_step": launches, "kernel_ms_per_step": round(ms, 3),
-            "avg_launch_us": round(1000 * ms / max(launches, 1), 3), "parts": parts}
+            "avg_launch_us": round(1000 * ms / max(launches, 1), 3), "parts": parts})
+    return out
 
 
 def cpu_baseline(args, blob, imgsz, mean_crops):
