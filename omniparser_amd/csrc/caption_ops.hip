@@ -180,17 +180,36 @@ __global__ __launch_bounds__(NT) void attn_rows_kernel(AttnArgs a) {
     }
     __syncthreads();
     int lim = a.nk - k0 < KT ? a.nk - k0 : KT;
-    for (int kk = 0; kk < lim; ++kk) {
-      float s = 0.0f;
+    // online softmax in chunks of 8 keys: one running-max update / accumulator rescale per chunk
+    for (int kk0 = 0; kk0 < lim; kk0 += 8) {
+      float sc[8];
+      float cm = -INFINITY;
 #pragma unroll
-      for (int d = 0; d < D; ++d) s = fmaf(q[d], sk[kk][d], s);
-      s *= a.scale;
-      float mn = fmaxf(m, s);
-      float corr = expf(m - mn);
-      float p = expf(s - mn);
-      l = l * corr + p;
+      for (int u = 0; u < 8; ++u) {
+        float s = -INFINITY;
+        if (kk0 + u < lim) {
+          s = 0.0f;
 #pragma unroll
-      for (int d = 0; d < D; ++d) o[d] = fmaf(p, sv[kk][d], o[d] * corr);
+          for (int d = 0; d < D; ++d) s = fmaf(q[d], sk[kk0 + u][d], s);
+          s *= a.scale;
+        }
+        sc[u] = s;
+        cm = fmaxf(cm, s);
+      }
+      float mn = fmaxf(m, cm);
+      float corr = expf(m - mn);           // m = -inf on the first chunk -> 0
+      l *= corr;
+#pragma unroll
+      for (int d = 0; d < D; ++d) o[d] *= corr;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        if (kk0 + u < lim) {
+          float p = expf(sc[u] - mn);
+          l += p;
+#pragma unroll
+          for (int d = 0; d < D; ++d) o[d] = fmaf(p, sv[kk0 + u][d], o[d]);
+        }
+      }
       m = mn;
     }
   }
