@@ -348,17 +348,19 @@ __device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& 
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
-template <int BM, int BN, bool PW>
-__global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
-  constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = 32;
+template <int BM, int BN, int NW, bool DEEP, bool PW>
+__global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
+  // NW waves as 2 (M) x NW/2 (N); DEEP: global loads run two K slices ahead (second register stage)
+  constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
   constexpr int BKE = 32;                  // f32 elements of K per slice
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
-  constexpr int TM = BM / 64, TN = BN / 64;
+  constexpr int WN = NW / 2;
+  constexpr int TM = BM / 64, TN = BN / (32 * WN);
   constexpr int STAGE = (BM + BN) * ROWB;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 1, wn = wave & 1;
+  const int wm = wave / WN, wn = wave % WN;
   const int bid = blockIdx.x;
   int mt, nt;
   if (a.xcd_order) {
@@ -411,9 +413,9 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
     w_s = tap - w_r * a.KW;
   }
 
-  u32x4 ra[A_IT], rb[B_IT];
+  u32x4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];     // two register stages: loads run two K slices ahead
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  auto load_tile = [&](int kt) {
+  auto load_tile = [&](int kt, u32x4* ra, u32x4* rb) {
     if (PW) {
 #pragma unroll
       for (int it = 0; it < A_IT; ++it)
@@ -435,7 +437,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   };
   // LDS row = two 16-wide K blocks, each [16 hi halves | 16 lo halves]
   const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
-  auto store_tile = [&](int stage) {
+  auto store_tile = [&](int stage, const u32x4* ra, const u32x4* rb) {
     unsigned char* sA = lds + stage * STAGE;
     unsigned char* sB = sA + BM * ROWB;
 #pragma unroll
@@ -460,15 +462,10 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
       for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
 
   const int a_rd = (wm * (BM / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
-  const int b_rd = BM * ROWB + (wn * (BN / 2) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_rd = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB + (lane >> 5) * 16;
 
-  if (kt0 < kt1) { load_tile(kt0); store_tile(0); }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
-    const unsigned char* st = lds + cur * STAGE;
+  auto compute = [&](int stage) {
+    const unsigned char* st = lds + stage * STAGE;
 #pragma unroll
     for (int j16 = 0; j16 < 2; ++j16) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
@@ -491,9 +488,36 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
           accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
         }
     }
-    if (more) store_tile(cur ^ 1);
+  };
+
+  if constexpr (DEEP) {
+    // software pipeline: global loads run TWO K slices ahead (registers), LDS writes ONE slice ahead
+    if (kt0 < kt1) { load_tile(kt0, ra0, rb0); store_tile(0, ra0, rb0); }
+    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra1, rb1);
     __syncthreads();
-    cur ^= 1;
+    for (int kt = kt0; kt < kt1; kt += 2) {
+      if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
+      compute(0);
+      if (kt + 1 < kt1) store_tile(1, ra1, rb1);
+      __syncthreads();
+      if (kt + 1 >= kt1) break;
+      if (kt + 3 < kt1) load_tile(kt + 3, ra1, rb1);
+      compute(1);
+      if (kt + 2 < kt1) store_tile(0, ra0, rb0);
+      __syncthreads();
+    }
+  } else {
+    if (kt0 < kt1) { load_tile(kt0, ra0, rb0); store_tile(0, ra0, rb0); }
+    __syncthreads();
+    int cur = 0;
+    for (int kt = kt0; kt < kt1; ++kt) {
+      const bool more = kt + 1 < kt1;
+      if (more) load_tile(kt + 1, ra0, rb0);
+      compute(cur);
+      if (more) store_tile(cur ^ 1, ra0, rb0);
+      __syncthreads();
+      cur ^= 1;
+    }
   }
 
   const float inv = 1.0f / 2048.0f;
@@ -501,7 +525,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
     float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
       if (n >= a.Cout) continue;
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -520,7 +544,7 @@ __global__ __launch_bounds__(256, 2) void conv_split_kernel(ConvArgs a) {
   const float scale = a.scale;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+    int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
     bool nok = n < a.Cout;
     float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
 #pragma unroll
@@ -548,8 +572,27 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
   dim3 grid(a.xcd_order ? ((a.mtiles + 7) / 8) * 8 * a.ntiles : a.mtiles * a.ntiles, 1, a.splits);
   const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
-  if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, true>), grid, dim3(256), 0, s, a);
-  else hipLaunchKernelGGL((conv_split_kernel<BM, BN, false>), grid, dim3(256), 0, s, a);
+  // 128x128 tile variants (measured on MI355X, TF/s effective on the stage-2 GEMMs):
+  //   0 = 4 waves, 64x64 per wave, 2 waves/SIMD: 172-209   1 = 8 waves + two-slice-ahead loads, 1 block/CU: 142-177
+  //   2 = 8 waves, 64x32 per wave, 4 waves/SIMD: 191-229  (default)
+  int variant = 2;
+  if (const char* e = getenv("OMNI_SPLIT_VARIANT")) variant = atoi(e);
+  bool done = false;
+  if constexpr (BM == 128 && BN == 128) {
+    if (variant == 1) {
+      if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, false>), grid, dim3(512), 0, s, a);
+      done = true;
+    } else if (variant == 2) {
+      if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false, true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false, false>), grid, dim3(512), 0, s, a);
+      done = true;
+    }
+  }
+  if (!done) {
+    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false, false>), grid, dim3(256), 0, s, a);
+  }
   if (a.splits > 1) {
     long long total = (long long)a.M * a.Cout;
     hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);

@@ -22,8 +22,10 @@ def main():
     stream = torch.cuda.Stream()
     for variant in os.environ.get("VARIANTS", "f32,split:128x64,split:128x128").split(","):
         os.environ["OMNI_CONV_SPLIT"] = "1" if variant.startswith("split") else "0"
-        if ":" in variant:
-            os.environ["OMNI_SPLIT_TILE"] = variant.split(":")[1]
+        parts = variant.split(":")
+        if len(parts) > 1:
+            os.environ["OMNI_SPLIT_TILE"] = parts[1]
+        os.environ["OMNI_SPLIT_VARIANT"] = parts[2] if len(parts) > 2 else "0"
         print(f"--- variant {variant}")
         for name, M, N, K, act, res in SHAPES:
             pb = PlanBuilder("cuda", dtype)
