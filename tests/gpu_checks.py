@@ -445,8 +445,8 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
             x2 = torch.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = torch.minimum(rb[:, None, 3], gb[None, :, 3])
             inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
             ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
-            iou = inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)
-            rec["matched_min_iou"] = iou.max(1).values.min().item()
+            iou_mat = inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)
+            rec["matched_min_iou"] = iou_mat.max(1).values.min().item()
         if len(rb) == len(gb) and len(rb) > 0:
             rec["min_iou"] = box_iou_pairs(gb, rb).min().item()
             rec["max_score_diff"] = (gs - rs).abs().max().item()
