@@ -124,12 +124,10 @@ def decode(outputs):
     return torch.cat(class_logits, dim=1).sigmoid(), torch.cat(decoded, dim=1)
 
 
-@torch.inference_mode()
-def predict(model, source, conf=0.25, imgsz=640, iou=0.7, max_det=300, return_debug=False):
-    """ref:util/yolov9.py:115-136.  Returns (boxes[K,4], scores[K], class_ids[K])."""
-    image = load_image(source)
-    x, scale, pad_left, pad_top = preprocess(image, imgsz)
-    class_scores, boxes = decode(model(x))
+def postprocess(outputs, image_width, image_height, scale, pad_left, pad_top, conf, iou, max_det):
+    """ref:util/yolov9.py:121-136 after the network call: decode, max-class, threshold, un-letterbox,
+    batched_nms[:max_det], clamp.  Returns (boxes, scores, class_ids, debug)."""
+    class_scores, boxes = decode(outputs)
     scores, class_ids = class_scores[0].max(dim=-1)
     valid = scores > conf
     scores, class_ids, boxes = scores[valid], class_ids[valid], boxes[0][valid]
@@ -138,8 +136,18 @@ def predict(model, source, conf=0.25, imgsz=640, iou=0.7, max_det=300, return_de
     cand = (boxes.clone(), scores.clone(), class_ids.clone())
     keep = batched_nms(boxes, scores, class_ids, iou)[:max_det]
     boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
-    boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, image.width)
-    boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, image.height)
+    boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, image_width)
+    boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, image_height)
+    return boxes, scores, class_ids, {"cand": cand, "valid": valid, "keep": keep}
+
+
+@torch.inference_mode()
+def predict(model, source, conf=0.25, imgsz=640, iou=0.7, max_det=300, return_debug=False):
+    """ref:util/yolov9.py:115-136.  Returns (boxes[K,4], scores[K], class_ids[K])."""
+    image = load_image(source)
+    x, scale, pad_left, pad_top = preprocess(image, imgsz)
+    boxes, scores, class_ids, dbg = postprocess(model(x), image.width, image.height, scale, pad_left, pad_top, conf, iou, max_det)
     if return_debug:
-        return boxes, scores, class_ids, {"input": x, "cand": cand, "valid": valid, "keep": keep}
+        dbg.update(input=x, scale=scale, pad_left=pad_left, pad_top=pad_top)
+        return boxes, scores, class_ids, dbg
     return boxes, scores, class_ids

@@ -391,6 +391,14 @@ def check_nms_known_answers():
 
 
 # ------------------------------------------------------------------------------------------ whole detector
+def _matched_min_iou(a, b):
+    x1 = torch.maximum(a[:, None, 0], b[None, :, 0]); y1 = torch.maximum(a[:, None, 1], b[None, :, 1])
+    x2 = torch.minimum(a[:, None, 2], b[None, :, 2]); y2 = torch.minimum(a[:, None, 3], b[None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    aa = (a[:, 2] - a[:, 0]) * (a[:, 3] - a[:, 1]); ab = (b[:, 2] - b[:, 0]) * (b[:, 3] - b[:, 1])
+    return (inter / (aa[:, None] + ab[None, :] - inter).clamp_min(1e-12)).max(1).values.min().item()
+
+
 def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, precision="f32", conf=0.05, iou=0.1,
                    with_f64=True, iw=1920, ih=1080):
     """GPU detector (ref:util/yolov9.py API) vs oracle.detector_ref.predict on the same TorchScript blob."""
@@ -439,6 +447,12 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
         in_bad = int((xin != dbg["input"][0]).sum()) if precision == "f32" else int(((xin - dbg["input"][0]).abs() > 1e-3).sum())
         rec = {"seed": s, "n_ref": len(rb), "n_gpu": len(gb), "input_mismatch": in_bad, "head_err(cls,dist)": errs,
                "oracle_noise(cls,dist,gpu_vs_f64)": noise, "cand_ref": int(dbg["valid"].sum())}
+        if ref64 is not None:
+            # is the ORACLE itself well conditioned on this frame?  (f32 vs f64 network, same post-processing)
+            b64, s64, c64, _ = D.postprocess([t.float() for t in ref64], iw, ih, dbg["scale"], dbg["pad_left"], dbg["pad_top"],
+                                             conf, iou, 300)
+            rec["oracle_f64_kept"] = len(b64)
+            rec["oracle_self_consistent"] = bool(len(b64) == len(rb) and (len(rb) == 0 or _matched_min_iou(rb, b64) >= 0.999))
         if len(rb) and len(gb):
             # order-free matching (two boxes with near-equal scores may swap ranks under rounding noise)
             x1 = torch.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = torch.maximum(rb[:, None, 1], gb[None, :, 1])

@@ -30,12 +30,19 @@ def test_detector_native_resolution_path():
 
 
 def test_detector_full_width_boxes():
-    """Full YOLOv9-E: boxes/keep-list vs oracle on frames where the oracle itself is well conditioned."""
+    """Full YOLOv9-E: network within the oracle's own rounding noise on every frame; box-for-box parity
+    (same count, identical class ids, IoU >= 0.999) on every frame where the ORACLE is self-consistent,
+    i.e. its f32 and f64 evaluations keep the same boxes (the seeded random BN net is chaotic, so a
+    candidate sitting within 1e-3 of the score threshold can flip in either implementation)."""
     import gpu_checks as G
-    out, det = G.check_detector(width=1.0, image_seeds=(0, 1), imgsz=640)
+    out, det = G.check_detector(width=1.0, image_seeds=(0, 1, 2), imgsz=640)
+    consistent = 0
     for rec in out["images"]:
         assert rec["input_mismatch"] == 0
         _assert_network_within_oracle_noise(rec)
-        assert rec["n_ref"] == rec["n_gpu"] and rec["cls_equal"]
-        assert rec["matched_min_iou"] >= 0.999, rec
+        if rec["oracle_self_consistent"]:
+            consistent += 1
+            assert rec["n_ref"] == rec["n_gpu"] and rec["cls_equal"], rec
+            assert rec["matched_min_iou"] >= 0.999, rec
+    assert consistent >= 1, out
     print(out)
