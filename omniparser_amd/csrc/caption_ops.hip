@@ -17,6 +17,7 @@
 //                  ref:util/utils.py:97-105,120-123 + hf CLIP image processor
 // All softmax / LayerNorm statistics are f32; f16 tensors are converted on load.
 #include "omni_internal.h"
+#include <stdlib.h>
 
 #pragma clang fp contract(off)
 
@@ -218,6 +219,156 @@ __global__ __launch_bounds__(NT) void attn_rows_kernel(AttnArgs a) {
     float inv = 1.0f / l;
 #pragma unroll
     for (int d = 0; d < D; ++d) stf(O + d, o[d] * inv);
+  }
+}
+
+// ------------------------------------------------------------------------------------ window attention on MFMA
+// DaViT 12x12 window attention (hf:models/florence2/modeling_florence2.py:338-398) with both contractions on the
+// matrix cores at f32-class accuracy (split-f16 operands, see conv_igemm.hip):
+//   S^T = K Q^T  via v_mfma_f32_16x16x32_f16 (head_dim 32 = one K step): each lane ends up with ONE query
+//         (column = lane&15) and 4 keys per 16-key tile (rows 4*(lane>>4)+reg), so the softmax row reduction is
+//         in-register plus two xor-shuffles (16, 32) — no LDS round trip for the scores;
+//   O   = P V    the lane's exponentials ARE the A-operand fragment of P (8 keys per 32-key block in a fixed
+//         permuted order); V^T is staged in LDS so the matching B fragment is two 8-byte reads.
+// One workgroup (3 waves) per (window, head): K and V^T (hi|lo f16) live in LDS, Q fragments go straight from
+// HBM to registers; wave w owns query tiles w, w+3, w+6 of the 9 x 16 queries.
+typedef _Float16 h16x8 __attribute__((ext_vector_type(8)));
+typedef _Float16 h16x4 __attribute__((ext_vector_type(4)));
+
+__device__ __forceinline__ void split1(float a, half_t& h, half_t& l) {
+  h = (half_t)a;
+  l = (half_t)((a - (float)h) * 2048.0f);
+}
+
+template <typename T>
+__global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
+  constexpr int D = 32, NKP = 160;                    // 144 keys padded to 10 tiles of 16
+  constexpr int KROW = 80;                            // bytes per K row (32 halves + 16 pad)
+  constexpr int VROW = 336;                           // bytes per V^T row (160 halves + 16 pad)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
+  unsigned char* Kh = lds;
+  unsigned char* Kl = lds + NKP * KROW;
+  unsigned char* Vh = lds + 2 * NKP * KROW;
+  unsigned char* Vl = Vh + D * VROW;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const T* Qp = (const T*)a.q; const T* Kp = (const T*)a.k; const T* Vp = (const T*)a.v;
+
+  // ---- stage K (row-major) and V^T, split into hi|lo halves
+  for (int e = tid; e < NKP * (D / 4); e += 192) {
+    int key = e / (D / 4), d0 = (e - key * (D / 4)) * 4;
+    float kv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+    if (key < 144) {
+      long long row = window_row(a, g, key);
+      if (row >= 0) {
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          kv[u] = ldf(Kp + row * a.ldk + a.koff + h * D + d0 + u);
+          vv[u] = ldf(Vp + row * a.ldv + a.voff + h * D + d0 + u);
+        }
+      } else {                               // zero-padded window token: qkv(0) = bias, not masked
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          kv[u] = a.kbias ? a.kbias[h * D + d0 + u] : 0.0f;
+          vv[u] = a.vbias ? a.vbias[h * D + d0 + u] : 0.0f;
+        }
+      }
+    }
+    half_t kh[4], kl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      split1(kv[u], kh[u], kl[u]);
+      half_t vh, vl;
+      split1(vv[u], vh, vl);
+      *reinterpret_cast<half_t*>(Vh + (d0 + u) * VROW + key * 2) = vh;
+      *reinterpret_cast<half_t*>(Vl + (d0 + u) * VROW + key * 2) = vl;
+    }
+    h16x4 k4h = {kh[0], kh[1], kh[2], kh[3]}, k4l = {kl[0], kl[1], kl[2], kl[3]};
+    *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = k4h;
+    *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = k4l;
+  }
+  __syncthreads();
+
+  const int qc = lane & 15, grp = lane >> 4;
+  const float inv2048 = 1.0f / 2048.0f;
+  for (int qt = wave; qt < 9; qt += 3) {
+    // ---- Q fragment of this lane: query qt*16+qc, d = 8*grp .. 8*grp+7
+    const int qi = qt * 16 + qc;
+    const long long qrow = window_row(a, g, qi);
+    h16x8 qh, ql;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      float v = qrow >= 0 ? ldf(Qp + qrow * a.ldq + a.qoff + h * D + grp * 8 + u) : 0.0f;
+      half_t hh, ll;
+      split1(v, hh, ll);
+      qh[u] = hh; ql[u] = ll;
+    }
+    // ---- S^T tiles: 10 key tiles x (1 + 2) MFMAs
+    float sc[40];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
+      h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+      h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
+      f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 16 + grp * 4 + r;
+        float sv = (accM[r] + accC[r] * inv2048) * a.scale;
+        sv = key < 144 ? sv : -INFINITY;
+        sc[kt * 4 + r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 40; ++e) { sc[e] = expf(sc[e] - mx); sum += sc[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    // ---- O = P V : 5 key blocks of 32 x 2 d-tiles
+    f32x4 oM[2], oC[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { oM[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; oC[dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      h16x8 ph, pl;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        half_t hh, ll;
+        split1(sc[(2 * j + (u >> 2)) * 4 + (u & 3)], hh, ll);
+        ph[u] = hh; pl[u] = ll;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
+        h16x4 a0 = *reinterpret_cast<const h16x4*>(vr), a1 = *reinterpret_cast<const h16x4*>(vr + 32);
+        h16x4 b0 = *reinterpret_cast<const h16x4*>(vr + D * VROW), b1 = *reinterpret_cast<const h16x4*>(vr + D * VROW + 32);
+        h16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        h16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
+      }
+    }
+    // ---- normalise and store: this lane holds O[query 4*grp+r][d = dt*16+qc]
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int ql_ = grp * 4 + r;
+      float rs = __shfl(sum, ql_);                         // row sum of query ql_ (replicated in every lane group)
+      long long orow = window_row(a, g, qt * 16 + ql_);
+      if (orow >= 0) {
+        T* O = (T*)a.o + orow * a.ldo + a.ooff + h * D;
+        float inv = 1.0f / rs;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) stf(O + dt * 16 + qc, (oM[dt][r] + oC[dt][r] * inv2048) * inv);
+      }
+    }
   }
 }
 
@@ -626,7 +777,13 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
     OMNI_REQUIRE(a.groups % (a.wy * a.wx) == 0, "attn_rows: groups must be B * windows");
   } else { a.wy = a.wx = 0; }
   int rc;
-  if (a.mode == 1 && D == 32) {          // 12x12 window: 144 queries in one 192-thread workgroup
+  static const bool use_mfma = !(getenv("OMNI_ATTN_MFMA") && atoi(getenv("OMNI_ATTN_MFMA")) == 0);
+  if (a.mode == 1 && D == 32 && use_mfma) {       // 12x12 window attention on the matrix cores (split-f16)
+    dim3 grid(1, a.heads, a.groups);
+    rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<float>), grid, dim3(192), 0, s, a); },
+      [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
+  } else if (a.mode == 1 && D == 32) {    // VALU fallback path (OMNI_ATTN_MFMA=0): 144 queries in one 192-thread workgroup
     dim3 grid(1, a.heads, a.groups);
     rc = by_dtype(op->dtype, "attn_rows",
       [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32, 192>), grid, dim3(192), 0, s, a); },
