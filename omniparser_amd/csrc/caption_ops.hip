@@ -198,14 +198,14 @@ __global__ __launch_bounds__(NT) void attn_rows_kernel(AttnArgs a) {
         cm = fmaxf(cm, s);
       }
       float mn = fmaxf(m, cm);
-      float corr = expf(m - mn);           // m = -inf on the first chunk -> 0
+      float corr = __expf(m - mn);         // m = -inf on the first chunk -> 0
       l *= corr;
 #pragma unroll
       for (int d = 0; d < D; ++d) o[d] *= corr;
 #pragma unroll
       for (int u = 0; u < 8; ++u) {
         if (kk0 + u < lim) {
-          float p = expf(sc[u] - mn);
+          float p = __expf(sc[u] - mn);
           l += p;
 #pragma unroll
           for (int d = 0; d < D; ++d) o[d] = fmaf(p, sv[kk0 + u][d], o[d]);
@@ -261,10 +261,17 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
     if (key < 144) {
       long long row = window_row(a, g, key);
       if (row >= 0) {
+        if constexpr (sizeof(T) == 4) {      // 16-byte loads (qkv rows are 16-byte aligned: C % 4 == 0)
+          f32x4 k4 = *reinterpret_cast<const f32x4*>(Kp + row * a.ldk + a.koff + h * D + d0);
+          f32x4 v4 = *reinterpret_cast<const f32x4*>(Vp + row * a.ldv + a.voff + h * D + d0);
 #pragma unroll
-        for (int u = 0; u < 4; ++u) {
-          kv[u] = ldf(Kp + row * a.ldk + a.koff + h * D + d0 + u);
-          vv[u] = ldf(Vp + row * a.ldv + a.voff + h * D + d0 + u);
+          for (int u = 0; u < 4; ++u) { kv[u] = k4[u]; vv[u] = v4[u]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 4; ++u) {
+            kv[u] = ldf(Kp + row * a.ldk + a.koff + h * D + d0 + u);
+            vv[u] = ldf(Vp + row * a.ldv + a.voff + h * D + d0 + u);
+          }
         }
       } else {                               // zero-padded window token: qkv(0) = bias, not masked
 #pragma unroll
@@ -296,12 +303,25 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
     const int qi = qt * 16 + qc;
     const long long qrow = window_row(a, g, qi);
     h16x8 qh, ql;
+    {
+      float qv[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+      if (qrow >= 0) {
+        const T* qp = Qp + qrow * a.ldq + a.qoff + h * D + grp * 8;
+        if constexpr (sizeof(T) == 4) {
+          f32x4 q0 = *reinterpret_cast<const f32x4*>(qp), q1 = *reinterpret_cast<const f32x4*>(qp + 4);
 #pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      float v = qrow >= 0 ? ldf(Qp + qrow * a.ldq + a.qoff + h * D + grp * 8 + u) : 0.0f;
-      half_t hh, ll;
-      split1(v, hh, ll);
-      qh[u] = hh; ql[u] = ll;
+          for (int u = 0; u < 4; ++u) { qv[u] = q0[u]; qv[4 + u] = q1[u]; }
+        } else {
+#pragma unroll
+          for (int u = 0; u < 8; ++u) qv[u] = ldf(qp + u);
+        }
+      }
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        half_t hh, ll;
+        split1(qv[u], hh, ll);
+        qh[u] = hh; ql[u] = ll;
+      }
     }
     // ---- S^T tiles: 10 key tiles x (1 + 2) MFMAs
     float sc[40];
@@ -328,7 +348,7 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
     mx = fmaxf(mx, __shfl_xor(mx, 32));
     float sum = 0.0f;
 #pragma unroll
-    for (int e = 0; e < 40; ++e) { sc[e] = expf(sc[e] - mx); sum += sc[e]; }
+    for (int e = 0; e < 40; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }   // v_exp_f32: rel. error ~|x|*6e-8
     sum += __shfl_xor(sum, 16);
     sum += __shfl_xor(sum, 32);
     // ---- O = P V : 5 key blocks of 32 x 2 d-tiles
