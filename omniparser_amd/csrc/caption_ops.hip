@@ -392,6 +392,161 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ plain MHA on MFMA (BART encoder)
+// softmax(q k^T * scale) v for head_dim 64 and any key count (hf:models/bart/modeling_bart.py:143-257), flash-style:
+// keys are walked in blocks of 32 with an online softmax; both contractions use split-f16 MFMA exactly as in
+// window_attn_mfma_kernel (S^T = K Q^T so the lane owns one query; the lane's exponentials are the P fragment;
+// V^T staged in LDS).  One workgroup = 4 waves = 128 queries of one (batch, head); each wave owns two 16-query tiles.
+template <typename T>
+__global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
+  constexpr int D = 64, KB = 32;
+  constexpr int KROW = 144;                     // bytes per staged K row (64 halves + 16 pad)
+  constexpr int VROW = 80;                      // bytes per staged V^T row (32 halves + 16 pad)
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * KB * KROW + 2 * D * VROW];
+  unsigned char* Kh = lds;
+  unsigned char* Kl = lds + KB * KROW;
+  unsigned char* Vh = lds + 2 * KB * KROW;
+  unsigned char* Vl = Vh + D * VROW;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int qc = lane & 15, grp = lane >> 4;
+  const T* Qp = (const T*)a.q; const T* Kp = (const T*)a.k; const T* Vp = (const T*)a.v;
+  const float inv2048 = 1.0f / 2048.0f;
+
+  // Q fragments of the wave's two query tiles: query q0 + t*16 + qc, d = 32*ks + 8*grp .. +7
+  const int q0 = blockIdx.x * 128 + wave * 32;
+  h16x8 qh[2][2], ql[2][2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    int qi = q0 + t * 16 + qc;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        float v = qi < a.nq ? ldf(Qp + ((long long)g * a.nq + qi) * a.ldq + a.qoff + h * D + ks * 32 + grp * 8 + u) : 0.0f;
+        half_t hh, ll;
+        split1(v, hh, ll);
+        qh[t][ks][u] = hh; ql[t][ks][u] = ll;
+      }
+    }
+  }
+  f32x4 oM[2][4], oC[2][4];
+  float m[2], lsum[2];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    m[t] = -INFINITY; lsum[t] = 0.0f;
+#pragma unroll
+    for (int dt = 0; dt < 4; ++dt) { oM[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; oC[t][dt] = (f32x4){0.f, 0.f, 0.f, 0.f}; }
+  }
+
+  for (int k0 = 0; k0 < a.nk; k0 += KB) {
+    __syncthreads();
+    // ---- stage 32 keys: K row-major, V transposed, hi|lo halves
+    for (int e = tid; e < KB * (D / 4); e += 256) {
+      int key = e / (D / 4), d0 = (e - key * (D / 4)) * 4;
+      float kv[4] = {0.f, 0.f, 0.f, 0.f}, vv[4] = {0.f, 0.f, 0.f, 0.f};
+      if (k0 + key < a.nk) {
+        long long row = (long long)g * a.nk + k0 + key;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          kv[u] = ldf(Kp + row * a.ldk + a.koff + h * D + d0 + u);
+          vv[u] = ldf(Vp + row * a.ldv + a.voff + h * D + d0 + u);
+        }
+      }
+      half_t kh[4], kl[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        split1(kv[u], kh[u], kl[u]);
+        half_t vh, vl;
+        split1(vv[u], vh, vl);
+        *reinterpret_cast<half_t*>(Vh + (d0 + u) * VROW + key * 2) = vh;
+        *reinterpret_cast<half_t*>(Vl + (d0 + u) * VROW + key * 2) = vl;
+      }
+      h16x4 k4h = {kh[0], kh[1], kh[2], kh[3]}, k4l = {kl[0], kl[1], kl[2], kl[3]};
+      *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = k4h;
+      *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = k4l;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      // ---- S^T for 2 key tiles x 2 d-steps
+      float sc[8];
+      float bm = -INFINITY;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt) {
+        f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int ks = 0; ks < 2; ++ks) {
+          const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + ks * 64 + grp * 16;
+          h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+          h16x8 kl = *reinterpret_cast<const h16x8*>(kr + KB * KROW);
+          accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh[t][ks], accM, 0, 0, 0);
+          accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql[t][ks], accC, 0, 0, 0);
+          accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh[t][ks], accC, 0, 0, 0);
+        }
+#pragma unroll
+        for (int r = 0; r < 4; ++r) {
+          int key = k0 + kt * 16 + grp * 4 + r;
+          float sv = (accM[r] + accC[r] * inv2048) * a.scale;
+          sv = key < a.nk ? sv : -INFINITY;
+          sc[kt * 4 + r] = sv;
+          bm = fmaxf(bm, sv);
+        }
+      }
+      bm = fmaxf(bm, __shfl_xor(bm, 16));
+      bm = fmaxf(bm, __shfl_xor(bm, 32));
+      float mn = fmaxf(m[t], bm);
+      float corr = __expf(m[t] - mn);
+      m[t] = mn;
+      float ps = 0.0f;
+#pragma unroll
+      for (int e = 0; e < 8; ++e) { sc[e] = __expf(sc[e] - mn); ps += sc[e]; }
+      lsum[t] = lsum[t] * corr + ps;            // per-lane partial (this lane's keys); reduced at the end
+      // rescale O rows: this lane holds O[query 4*grp+r][.] -> need that query's corr
+      float cr[4];
+#pragma unroll
+      for (int r = 0; r < 4; ++r) cr[r] = __shfl(corr, grp * 4 + r);
+      h16x8 ph, pl;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        half_t hh, ll;
+        split1(sc[u], hh, ll);
+        ph[u] = hh; pl[u] = ll;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 4; ++dt) {
+#pragma unroll
+        for (int r = 0; r < 4; ++r) { oM[t][dt][r] *= cr[r]; oC[t][dt][r] *= cr[r]; }
+        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (4 * grp) * 2;
+        h16x4 a0 = *reinterpret_cast<const h16x4*>(vr), a1 = *reinterpret_cast<const h16x4*>(vr + 32);
+        h16x4 b0 = *reinterpret_cast<const h16x4*>(vr + D * VROW), b1 = *reinterpret_cast<const h16x4*>(vr + D * VROW + 32);
+        h16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        h16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        oM[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[t][dt], 0, 0, 0);
+        oC[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[t][dt], 0, 0, 0);
+        oC[t][dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[t][dt], 0, 0, 0);
+      }
+    }
+  }
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    float tot = lsum[t];
+    tot += __shfl_xor(tot, 16);
+    tot += __shfl_xor(tot, 32);
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      int qi = q0 + t * 16 + grp * 4 + r;
+      float rs = __shfl(tot, grp * 4 + r);
+      if (qi < a.nq) {
+        T* O = (T*)a.o + ((long long)g * a.nq + qi) * a.ldo + a.ooff + h * D;
+        float inv = 1.0f / rs;
+#pragma unroll
+        for (int dt = 0; dt < 4; ++dt) stf(O + dt * 16 + qc, (oM[t][dt][r] + oC[t][dt][r] * inv2048) * inv);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ channel attention
 struct ChanArgs {
   const void* qkv; void* o; float* ws;    // qkv [B*N, 3C]; ws [B][G][chunks][32][32]
@@ -808,6 +963,11 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
     rc = by_dtype(op->dtype, "attn_rows",
       [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32, 192>), grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32, 192>), grid, dim3(192), 0, s, a); });
+  } else if (a.mode == 0 && D == 64 && use_mfma) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
+    dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
+    rc = by_dtype(op->dtype, "attn_rows",
+      [&] { hipLaunchKernelGGL((mha_mfma_kernel<float>), grid, dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL((mha_mfma_kernel<half_t>), grid, dim3(256), 0, s, a); });
   } else {
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
     if (D == 32) rc = by_dtype(op->dtype, "attn_rows",
