@@ -565,6 +565,174 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
   }
 }
 
+// 128x128 tile, 8 waves (2 x 4, 64x32 per wave), weights NOT staged through LDS: every wave reads its B fragments
+// (32 output channels x 16 k, hi|lo) straight from the packed weight matrix into registers, one K slice ahead.  The
+// weight matrix is small and L2/MALL-resident; skipping its LDS round trip removes ~40 % of the LDS traffic that
+// co-limits conv_split_kernel (LDS then carries only the split activation tile).
+template <bool PW>
+__global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
+  constexpr int BM = 128, BN = 128, RB = 128, ROWB = RB + 16, VPR = 8, RPP = 64, BKE = 32;
+  constexpr int A_IT = BM / RPP, TM = 2;
+  constexpr int STAGE = BM * ROWB;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave >> 2, wn = wave & 3;
+  const int bid = blockIdx.x;
+  int mt, nt;
+  if (a.xcd_order) {
+    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
+    nt = (bid >> 3) % a.ntiles;
+    if (mt >= a.mtiles) return;
+  } else { mt = bid % a.mtiles; nt = bid / a.mtiles; }
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int vec = tid % VPR, r0 = tid / VPR;
+  const int kt0 = blockIdx.z * a.kt_per_split;
+  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(a.w);
+
+  long long a_base[A_IT];
+  int a_hi0[A_IT], a_wi0[A_IT];
+  bool a_ok[A_IT];
+  const float* a_row[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    int m = m0 + r0 + it * RPP;
+    a_ok[it] = m < a.M;
+    int mm = a_ok[it] ? m : 0;
+    int wo = mm % a.Wo;
+    int t = mm / a.Wo;
+    int ho = t % a.Ho;
+    int b = t / a.Ho;
+    a_hi0[it] = ho * a.stride - a.pad;
+    a_wi0[it] = wo * a.stride - a.pad;
+    a_base[it] = (long long)b * a.H * a.W * a.ldi + a.in_coff;
+    a_row[it] = X + (long long)mm * a.ldi + a.in_coff + vec * 4;
+  }
+  // this lane's weight row (output channel) and its 16-byte column inside each [16 hi | 16 lo] block
+  const int bn = n0 + wn * 32 + (lane & 31);
+  const bool bn_ok = bn < a.Cout;
+  const unsigned char* b_row = Wb + (long long)(bn_ok ? bn : 0) * a.K * 4 + (lane >> 5) * 16;
+  int w_r = 0, w_s = 0, w_c = 0;
+  if (!PW) {
+    int tap = kt0 / a.cin_tiles;
+    w_c = (kt0 - tap * a.cin_tiles) * BKE;
+    w_r = tap / a.KW;
+    w_s = tap - w_r * a.KW;
+  }
+  u32x4 ra[A_IT];
+  u32x4 nbh[2], nbl[2];                         // next slice's B fragments (two 16-wide k blocks)
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  auto load_tile = [&](int kt) {
+    if (PW) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
+    } else {
+      int r = w_r, s = w_s, c = w_c + vec * 4;
+      w_c += BKE;
+      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
+        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
+      }
+    }
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const unsigned char* p = b_row + ((long long)kt * 2 + j) * 64;
+      nbh[j] = bn_ok ? *reinterpret_cast<const u32x4*>(p) : zero4;
+      nbl[j] = bn_ok ? *reinterpret_cast<const u32x4*>(p + 32) : zero4;
+    }
+  };
+  const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
+  auto store_tile = [&](int stage) {
+    unsigned char* sA = lds + stage * STAGE;
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      uint2 hi, lo;
+      split_f16x4(ra[it], hi, lo);
+      unsigned char* p = sA + (r0 + it * RPP) * ROWB + a_wr;
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + 32) = lo;
+    }
+  };
+  f32x16 accM[TM], accC[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accM[i][e] = 0.0f; accC[i][e] = 0.0f; }
+  const int a_rd = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  u32x4 cbh[2], cbl[2];
+  if (kt0 < kt1) { load_tile(kt0); store_tile(0); }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) { cbh[j] = nbh[j]; cbl[j] = nbl[j]; }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1);
+    const unsigned char* st = lds + cur * STAGE;
+#pragma unroll
+    for (int j16 = 0; j16 < 2; ++j16) {
+      f16x8 bh = __builtin_bit_cast(f16x8, cbh[j16]), bl = __builtin_bit_cast(f16x8, cbl[j16]);
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        f16x8 ah = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64);
+        f16x8 al = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64 + 32);
+        accM[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accM[i], 0, 0, 0);
+        accC[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accC[i], 0, 0, 0);
+        accC[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accC[i], 0, 0, 0);
+      }
+    }
+    if (more) {
+      store_tile(cur ^ 1);
+#pragma unroll
+      for (int j = 0; j < 2; ++j) { cbh[j] = nbh[j]; cbl[j] = nbl[j]; }
+    }
+    __syncthreads();
+    cur ^= 1;
+  }
+  const float inv = 1.0f / 2048.0f;
+  const int n = n0 + wn * 32 + (lane & 31);
+  const bool nok = n < a.Cout;
+  if (a.splits > 1) {
+    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+    if (nok) {
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][e] + accC[i][e] * inv;
+        }
+      }
+    }
+    return;
+  }
+  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
+  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
+  const float scale = a.scale;
+  const float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int m = mb + (e & 3) + 8 * (e >> 2);
+      if (nok && m < a.M) {
+        float v = (accM[i][e] + accC[i][e] * inv) + bias;
+        if (scale != 0.0f) v *= scale;
+        v = act_apply(v, a.act);
+        if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
+        Y[(long long)m * a.ldo + a.out_coff + n] = v;
+      }
+    }
+  }
+}
+
 template <int BM, int BN>
 void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
@@ -579,7 +747,11 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   if (const char* e = getenv("OMNI_SPLIT_VARIANT")) variant = atoi(e);
   bool done = false;
   if constexpr (BM == 128 && BN == 128) {
-    if (variant == 1) {
+    if (variant == 3) {
+      if (pw) hipLaunchKernelGGL((conv_split_breg_kernel<true>), grid, dim3(512), 0, s, a);
+      else hipLaunchKernelGGL((conv_split_breg_kernel<false>), grid, dim3(512), 0, s, a);
+      done = true;
+    } else if (variant == 1) {
       if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, true>), grid, dim3(512), 0, s, a);
       else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, false>), grid, dim3(512), 0, s, a);
       done = true;
