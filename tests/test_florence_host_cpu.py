@@ -1,0 +1,97 @@
+"""Host-side captioner pieces that need no GPU: checkpoint key mapping, processor, generation config."""
+import json
+
+import numpy as np
+import pytest
+import torch
+
+
+@pytest.fixture(scope="module")
+def ckpt_dir():
+    from tools.make_weights import ensure_caption_checkpoint
+    return ensure_caption_checkpoint(0)
+
+
+def _native_to_legacy(sd):
+    """inverse of omniparser_amd.florence._legacy_to_native (remote-code Florence-2 naming)."""
+    out = {}
+    for k, v in sd.items():
+        if k.startswith("model.vision_tower."):
+            nk = k[len("model."):]
+            if ".convs." in nk:
+                nk = nk.replace(".conv.", ".proj.")
+            for a, b in ((".spatial_block.conv1.", ".spatial_block.conv1.fn.dw."), (".spatial_block.conv2.", ".spatial_block.conv2.fn.dw."),
+                         (".channel_block.conv1.", ".channel_block.conv1.fn.dw."), (".channel_block.conv2.", ".channel_block.conv2.fn.dw."),
+                         (".spatial_block.norm1.", ".spatial_block.window_attn.norm."), (".channel_block.norm1.", ".channel_block.channel_attn.norm."),
+                         (".window_attn.qkv.", ".window_attn.fn.qkv."), (".window_attn.proj.", ".window_attn.fn.proj."),
+                         (".channel_attn.qkv.", ".channel_attn.fn.qkv."), (".channel_attn.proj.", ".channel_attn.fn.proj."),
+                         (".norm2.", ".ffn.norm."), (".ffn.fc1.", ".ffn.fn.net.fc1."), (".ffn.fc2.", ".ffn.fn.net.fc2.")):
+                nk = nk.replace(a, b)
+        elif k == "model.multi_modal_projector.image_projection.weight":
+            nk, v = "image_projection", v.t().contiguous()
+        elif k.startswith("model.multi_modal_projector.image_proj_norm."):
+            nk = k[len("model.multi_modal_projector."):]
+        elif k.startswith("model.multi_modal_projector.image_position_embed."):
+            nk = "image_pos_embed." + k[len("model.multi_modal_projector.image_position_embed."):]
+        elif k.startswith("model.multi_modal_projector.visual_temporal_embed."):
+            nk = k[len("model.multi_modal_projector."):]
+        elif k.startswith("model.language_model."):
+            nk = "language_model.model." + k[len("model.language_model."):]
+        else:
+            nk = k
+        out[nk] = v
+    return out
+
+
+def test_legacy_checkpoint_names_map_onto_native(ckpt_dir):
+    from safetensors.torch import load_file
+    from omniparser_amd.florence import _legacy_to_native
+    native = load_file(str(ckpt_dir / "model.safetensors"))
+    legacy = _native_to_legacy(native)
+    assert any(k.startswith("vision_tower.convs.0.proj") for k in legacy) and "image_projection" in legacy
+    back = _legacy_to_native(legacy)
+    assert set(back) == set(native)
+    for k in native:
+        assert torch.equal(back[k], native[k]), k
+
+
+def test_weights_and_generation_config(ckpt_dir):
+    from omniparser_amd.florence import FlorenceWeights
+    w = FlorenceWeights(ckpt_dir)
+    assert (w.embed_dim, w.depths, w.heads) == ([128, 256, 512, 1024], [1, 1, 9, 1], [4, 8, 16, 32])
+    assert (w.d_model, w.n_heads, w.enc_layers, w.dec_layers, w.vocab) == (768, 12, 6, 6, 51290)
+    assert (w.ngram, w.forced_bos, w.forced_eos, w.start, w.pad, w.eos) == (3, 0, 2, 2, 1, 2)
+    assert "lm_head.weight" in w.sd and w.embed_scale == 1.0
+
+
+def test_processor_matches_hf_image_transforms():
+    """FlorenceProcessor pixel_values == PIL bicubic + transformers' numpy rescale/normalize."""
+    from PIL import Image
+    from transformers.image_transforms import normalize, rescale
+    from omniparser_amd.util.utils import FlorenceProcessor
+    rng = np.random.default_rng(0)
+    imgs = [Image.fromarray(rng.integers(0, 256, size=(64, 64, 3), dtype=np.uint8)) for _ in range(2)]
+    proc = FlorenceProcessor(None)
+    for do_resize, R in ((True, 768), (False, 64)):
+        out = proc(images=imgs, text=["<CAPTION>"] * 2, return_tensors="pt", do_resize=do_resize)
+        assert out["pixel_values"].shape == (2, 3, R, R)
+        assert out["input_ids"].shape == (2, (R // 32) ** 2 + 1 + 8)
+        im = imgs[0].resize((768, 768), Image.Resampling.BICUBIC) if do_resize else imgs[0]
+        ref = normalize(rescale(np.asarray(im), 1 / 255), mean=[0.485, 0.456, 0.406], std=[0.229, 0.224, 0.225])
+        assert np.array_equal(out["pixel_values"][0].numpy(), ref.transpose(2, 0, 1).astype(np.float32))
+    moved = out.to(device="cpu", dtype=torch.float16)
+    assert moved["pixel_values"].dtype == torch.float16 and moved["input_ids"].dtype == torch.int64
+    assert proc.batch_decode(torch.tensor([[2, 0, 100, 200, 2, 1]])) == ["tok100 tok200"]
+
+
+def test_product_constructors_fail_loudly_without_gpu(ckpt_dir):
+    if torch.cuda.is_available():
+        pytest.skip("GPU present")
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    with pytest.raises(RuntimeError):
+        Florence2Captioner(ckpt_dir, "cpu")
+    with pytest.raises(RuntimeError):
+        YOLOv9Detector(model_path="does-not-matter.pt", device="cuda")
+    with pytest.raises(RuntimeError):
+        YOLOv9Detector(model_path="does-not-matter.pt", device="cpu")
