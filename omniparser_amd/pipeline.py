@@ -21,7 +21,7 @@ class ScreenParser:
     def __init__(self, detector: YOLOv9Detector, captioner: Florence2Captioner, processor=None,
                  box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640, batch_size=128):
         self.det, self.cap = detector, captioner
-        self.proc = processor or U.FlorenceProcessor(captioner.w.dir)
+        self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, batch_size
         self.stats = {}
@@ -37,6 +37,60 @@ class ScreenParser:
             counts = dp.out_count.cpu()                     # sync
             boxes = dp.out_boxes.cpu()
         return [boxes[bi, : int(counts[bi])] for bi in range(len(frames))]
+
+    # ---- stage 1b: tiled detection for frames larger than 1080p (BASELINE configs[4]; policy is OURS, the
+    #      reference letterboxes the whole image: SURVEY 0.7).  Tiles overlap by 64 px, each tile goes through the
+    #      ordinary detector (one batch), boxes are shifted back and a global batched_nms(nms_iou)[:max_det] + clamp
+    #      merges them (same NMS kernel as inside the detector).  oracle/tiling_ref.py is the CPU statement.
+    @staticmethod
+    def tile_origins(iw, ih, tile_w=1952, tile_h=1112, overlap=64):
+        def axis(n, t):
+            if n <= t:
+                return [0]
+            k = -(-(n - overlap) // (t - overlap))
+            step = (n - t) / (k - 1)
+            return [int(round(i * step)) for i in range(k)]
+        return [(x, y) for y in axis(ih, tile_h) for x in axis(iw, tile_w)], min(tile_w, iw), min(tile_h, ih)
+
+    def detect_tiled(self, frame: torch.Tensor):
+        ih, iw = frame.shape[:2]
+        origins, tw, th = self.tile_origins(iw, ih)
+        tiles = [frame[y:y + th, x:x + tw].contiguous() for (x, y) in origins]
+        dp = self.det.get_plan(tw, th, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=len(tiles))
+        with torch.cuda.stream(self.det.stream):
+            for bi, t in enumerate(tiles):
+                dp.img[bi].copy_(t, non_blocking=True)
+            dp.launch(self.det)
+            counts = dp.out_count.cpu()
+            boxes, scores, cls = dp.out_boxes.cpu(), dp.out_scores.cpu(), dp.out_cls.cpu()
+        recs = []
+        for bi, (x0, y0) in enumerate(origins):
+            k = int(counts[bi])
+            b = boxes[bi, :k].numpy() + np.asarray([x0, y0, x0, y0], dtype=np.float32)
+            r = np.zeros((k, 8), dtype=np.float32)
+            r[:, :4] = b
+            r[:, 4] = scores[bi, :k].numpy()
+            ri = r.view(np.int32)
+            ri[:, 5] = cls[bi, :k].numpy()
+            recs.append(r)
+        rec = np.concatenate(recs, 0) if recs else np.zeros((0, 8), dtype=np.float32)
+        n = rec.shape[0]
+        rec.view(np.int32)[:, 6] = np.arange(n)               # stable tie-break = concatenation order (tile-major)
+        dev = self.det.device
+        cap_n = max(n, 1)
+        cand = torch.from_numpy(np.concatenate([rec, np.zeros((cap_n - n, 8), dtype=np.float32)], 0)).to(dev)
+        count = torch.tensor([n], dtype=torch.int32, device=dev)
+        srt = torch.zeros((cap_n + 1) * 8, dtype=torch.float32, device=dev)
+        mask = torch.empty(cap_n * ((cap_n + 63) // 64), dtype=torch.int64, device=dev)
+        ob = torch.zeros(self.max_det, 4, device=dev); osc = torch.zeros(self.max_det, device=dev)
+        oc = torch.zeros(self.max_det, dtype=torch.int32, device=dev); on = torch.zeros(1, dtype=torch.int32, device=dev)
+        op = L.make_op(L.OP_NMS, L.F32, p=[cand.data_ptr(), count.data_ptr(), srt.data_ptr(), mask.data_ptr(), ob.data_ptr(),
+                                          osc.data_ptr(), oc.data_ptr(), on.data_ptr()],
+                       i={0: cap_n, 1: self.max_det, 2: iw, 3: ih}, f={0: self.nms_iou})
+        with torch.cuda.stream(self.det.stream):
+            L.launch(op, self.det.stream)
+            k = int(on.cpu())
+            return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long()
 
     # ---- stage 2: host glue (reference semantics) -> elements + crop boxes
     def glue(self, xyxy_px: torch.Tensor, w: int, h: int, ocr_bbox, ocr_text):

@@ -46,3 +46,44 @@ def test_detector_full_width_boxes():
             assert rec["matched_min_iou"] >= 0.999, rec
     assert consistent >= 1, out
     print(out)
+
+
+def test_tiled_detection_4k_matches_oracle_policy():
+    """3840x2160 frame -> 2x2 overlapping tiles -> global NMS (BASELINE configs[4]; policy is ours).  The merge
+    (shift + global NMS + clamp) must be exact given the per-tile boxes; end to end the result must match the
+    oracle policy wherever the per-tile detections match."""
+    import numpy as np
+    import torch
+    import gpu_checks as G
+    from oracle import detector_ref as D
+    from oracle import tiling_ref as TR
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob
+    blob = ensure_blob(seed=0, nc=1, width=0.5)
+    det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
+    sp = ScreenParser(det, captioner=None, processor=object())
+    img = synthetic_screenshot(4, 3840, 2160)
+    origins, tw, th = sp.tile_origins(3840, 2160)
+    assert origins == TR.tile_origins(3840, 2160)[0] and len(origins) == 4 and (tw, th) == (1952, 1112)
+    gb, gs, gc = sp.detect_tiled(torch.from_numpy(img).cuda())
+    # exactness of the merge: feed the GPU's own per-tile boxes to the restated batched_nms
+    dp = det.get_plan(tw, th, 640, 0.05, 0.1, 300, batch=4)
+    cnt = dp.out_count.cpu(); bx = dp.out_boxes.cpu(); sc = dp.out_scores.cpu(); cl = dp.out_cls.cpu()
+    bs = torch.cat([bx[i, :int(cnt[i])] + torch.tensor([x, y, x, y], dtype=torch.float32) for i, (x, y) in enumerate(origins)])
+    ss = torch.cat([sc[i, :int(cnt[i])] for i in range(4)]); cs = torch.cat([cl[i, :int(cnt[i])] for i in range(4)]).long()
+    keep = D.batched_nms(bs, ss, cs, 0.1)[:300]
+    eb = bs[keep].clone(); eb[:, [0, 2]] = eb[:, [0, 2]].clamp(0, 3840); eb[:, [1, 3]] = eb[:, [1, 3]].clamp(0, 2160)
+    assert len(gb) == len(eb) and torch.equal(gb, eb) and torch.equal(gs, ss[keep]) and torch.equal(gc, cs[keep])
+    # end to end vs the oracle policy (chaotic random net: compare counts loosely, boxes by best match)
+    cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
+    rb, rs, rc = TR.predict_tiled(cpu_model, img)
+    assert abs(len(rb) - len(gb)) <= max(3, len(rb) // 20)
+    if len(rb) and len(gb):
+        x1 = torch.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = torch.maximum(rb[:, None, 1], gb[None, :, 1])
+        x2 = torch.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = torch.minimum(rb[:, None, 3], gb[None, :, 3])
+        inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+        ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+        best = (inter / (ar[:, None] + ag[None, :] - inter)).max(1).values
+        assert (best >= 0.999).float().mean() >= 0.9
