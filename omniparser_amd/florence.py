@@ -430,12 +430,17 @@ class Florence2Captioner:
         return self._plans[key]
 
     # ---- decode loop shared by both entry points
-    def _run(self, cp: _CaptionPlans, n: int, max_new: int) -> torch.Tensor:
+    def _run(self, cp: _CaptionPlans, n: int, max_new: int, defer: bool = False) -> torch.Tensor:
         run = (lambda p: p.replay(self.stream)) if self.use_graph else (lambda p: p.run(self.stream))
         run(cp.encode_plan)
         for _ in range(max_new):
             run(cp.step_plan)
-        ids = cp.ids[:n].cpu().long()     # synchronises the stream
+        if defer:                          # stream-ordered snapshot; the caller reads it back later (no sync here)
+            return cp.ids[:n].clone()
+        return self._finish_ids(cp.ids[:n].cpu().long())     # synchronises the stream
+
+    def _finish_ids(self, ids: torch.Tensor) -> torch.Tensor:
+        n = ids.shape[0]
         # hf stops as soon as every row has emitted EOS (generation/utils.py:2936): trim the all-pad tail
         T = ids.shape[1]
         done_at = T

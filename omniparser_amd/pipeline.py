@@ -157,7 +157,8 @@ class ScreenParser:
                         f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
                     L.launch(op, cap.stream)
                     o = e
-                ids_all.append(cap._run(cp, n, max_new_tokens))
+                ids_all.append(cap._run(cp, n, max_new_tokens, defer=True))   # keep the GPU fed: no sync between micro-batches
+        ids_all = [cap._finish_ids(t.cpu().long()) for t in ids_all]     # single read-back point
         out = [[] for _ in frames]
         k = 0
         for ids in ids_all:
