@@ -139,6 +139,10 @@ enum {
    *  p4 y [n,R,R,ldo] p5 bounds i32[R,2] p6 coef i32[R,ksize] p7 lut f32[256]
    *  i0 n i1 H i2 W i3 R i4 ksize i13 ldo; f0..2 mean f3..5 std */
   OMNI_OP_CROP_RESIZE = 17,
+  /* fused x1 = x + depthwise3x3(x) + bias ; h = LayerNorm(x1) (DaViT half-block prologue, hf florence2 :432-441).
+   *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p3 h [B,H,W,C] p4 x1 [B,H,W,C] p5 gamma f32 p6 beta f32
+   *  i0 B i1 H i2 W i3 C (<= 1024); f0 eps */
+  OMNI_OP_DWCONV3_LN = 18,
   OMNI_OP__COUNT
 };
 

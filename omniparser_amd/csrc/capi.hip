@@ -42,6 +42,7 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
     case OMNI_OP_NMS: return omni_launch_nms(op, s);
     case OMNI_OP_DWCONV3: return omni_launch_dwconv3(op, s);
     case OMNI_OP_LAYERNORM: return omni_launch_layernorm(op, s);
+    case OMNI_OP_DWCONV3_LN: return omni_launch_dwconv3_ln(op, s);
     case OMNI_OP_ATTN_ROWS: case OMNI_OP_CHAN_ATTN: case OMNI_OP_ATTN_DECODE: return omni_launch_attention(op, s);
     case OMNI_OP_PROJ_PREP: case OMNI_OP_ASSEMBLE: case OMNI_OP_EMBED_STEP: case OMNI_OP_GREEDY_STEP:
     case OMNI_OP_CROP_RESIZE: return omni_launch_misc(op, s);

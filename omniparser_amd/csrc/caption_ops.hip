@@ -122,6 +122,87 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   }
 }
 
+// ------------------------------------------------------------------------------------ dwconv3 + layernorm fused
+// x1 = x + depthwise3x3(x) + bias ; h = LayerNorm(x1).  One wave per pixel (C <= 1024): the conv result stays in
+// registers for the statistics, so x1 is written once and never re-read (saves one full tensor read per DaViT
+// half-block compared with dwconv3_kernel followed by layernorm_kernel).
+struct DwLnArgs { const void* x; const void* w; const float* bias; const float* g; const float* b; void* y1; void* h;
+                  int B, H, W, C; long long pixels; float eps; };
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_ln_kernel(DwLnArgs a) {
+  constexpr int V = ElemTraits<T>::kVec;
+  constexpr int MAXI = 1024 / (64 * V);          // channel vectors per lane (4 for f32, 2 for f16)
+  struct Vec { T v[V]; };
+  const int lane = threadIdx.x & 63;
+  const long long pix = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
+  if (pix >= a.pixels) return;
+  const int w = (int)(pix % a.W);
+  const long long t = pix / a.W;
+  const int hh = (int)(t % a.H);
+  const long long b = t / a.H;
+  const T* __restrict__ X = (const T*)a.x;
+  const T* __restrict__ Wt = (const T*)a.w;
+  float y[MAXI][V];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + i * 64) * V;
+#pragma unroll
+    for (int e = 0; e < V; ++e) y[i][e] = 0.0f;
+    if (c < a.C) {
+      float acc[V];
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+      Vec ctr;
+#pragma unroll
+      for (int r = 0; r < 3; ++r) {
+        int hi = hh + r - 1;
+        if (hi < 0 || hi >= a.H) continue;
+#pragma unroll
+        for (int q = 0; q < 3; ++q) {
+          int wi = w + q - 1;
+          if (wi < 0 || wi >= a.W) continue;
+          Vec xv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(X + ((b * a.H + hi) * a.W + wi) * a.C + c));
+          Vec wv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(Wt + (r * 3 + q) * a.C + c));
+          if (r == 1 && q == 1) ctr = xv;
+#pragma unroll
+          for (int e = 0; e < V; ++e) acc[e] += ElemTraits<T>::to_f32(wv.v[e]) * ElemTraits<T>::to_f32(xv.v[e]);
+        }
+      }
+      Vec out;
+#pragma unroll
+      for (int e = 0; e < V; ++e) {
+        out.v[e] = ElemTraits<T>::from_f32((acc[e] + a.bias[c + e]) + ElemTraits<T>::to_f32(ctr.v[e]));
+        y[i][e] = ElemTraits<T>::to_f32(out.v[e]);      // statistics on the value as stored (matches the unfused path)
+        s += y[i][e];
+      }
+      *reinterpret_cast<u32x4*>((T*)a.y1 + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
+    }
+  }
+  const float mean = wave_sum(s) / (float)a.C;
+  float q2 = 0.0f;
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + i * 64) * V;
+    if (c < a.C) {
+#pragma unroll
+      for (int e = 0; e < V; ++e) { float d = y[i][e] - mean; q2 += d * d; }
+    }
+  }
+  const float rstd = 1.0f / sqrtf(wave_sum(q2) / (float)a.C + a.eps);
+#pragma unroll
+  for (int i = 0; i < MAXI; ++i) {
+    const int c = (lane + i * 64) * V;
+    if (c < a.C) {
+      Vec out;
+#pragma unroll
+      for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((y[i][e] - mean) * rstd * a.g[c + e] + a.b[c + e]);
+      *reinterpret_cast<u32x4*>((T*)a.h + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ attn_rows
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o; const float* kbias; const float* vbias;
@@ -914,6 +995,24 @@ int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
   int rc = by_dtype(op->dtype, "dwconv3",
       [&] { hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); },
       [&] { hipLaunchKernelGGL(dwconv3_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
+  DwLnArgs a;
+  a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.h = op->p[3]; a.y1 = op->p[4];
+  a.g = (const float*)op->p[5]; a.b = (const float*)op->p[6];
+  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3]; a.eps = op->f[0];
+  const int V = op->dtype == OMNI_F32 ? 4 : 8;
+  OMNI_REQUIRE(a.x && a.w && a.bias && a.h && a.y1 && a.g && a.b, "dwconv3_ln: null pointer");
+  OMNI_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= 1024 && a.C % V == 0, "dwconv3_ln: bad shape (C <= 1024, C %% %d == 0)", V);
+  a.pixels = (long long)a.B * a.H * a.W;
+  unsigned blocks = (unsigned)((a.pixels + 3) / 4);
+  int rc = by_dtype(op->dtype, "dwconv3_ln",
+      [&] { hipLaunchKernelGGL(dwconv3_ln_kernel<float>, dim3(blocks), dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(dwconv3_ln_kernel<half_t>, dim3(blocks), dim3(256), 0, s, a); });
   if (rc) return rc;
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;

@@ -55,5 +55,6 @@ int omni_launch_detect_decode(const omni_op_t* op, hipStream_t s);
 int omni_launch_nms(const omni_op_t* op, hipStream_t s);
 int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s);
 int omni_launch_layernorm(const omni_op_t* op, hipStream_t s);
+int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s);
 int omni_launch_attention(const omni_op_t* op, hipStream_t s);
 int omni_launch_misc(const omni_op_t* op, hipStream_t s);

@@ -150,6 +150,25 @@ class _CaptionPlans:
                                 i={0: x.B, 1: x.H, 2: x.W, 3: x.C}))
             return out
 
+        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "1") != "0"
+
+        def dwconv_ln(conv_key, norm_key, x: View, y1: View, hout: View):
+            """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
+            if not fuse_dwln:
+                dwconv(conv_key, x, y1)
+                return layernorm(norm_key, y1, hout)
+            ck = (conv_key, dt)
+            if ck not in wc:
+                wt = sd[conv_key + ".weight"]
+                wc[ck] = (pb.upload(wt[:, 0].permute(1, 2, 0).contiguous().to(torch_dtype(dt))), pb.upload(sd[conv_key + ".bias"].float()))
+            wp, bp = wc[ck]
+            pb.keep += [wp, bp]
+            pb.add_op(L.make_op(L.OP_DWCONV3_LN, dt,
+                                p=[x.ptr, wp.data_ptr(), bp.data_ptr(), hout.ptr, y1.ptr,
+                                   f32(norm_key + ".weight").data_ptr(), f32(norm_key + ".bias").data_ptr()],
+                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C}, f={0: 1e-5}))
+            return hout
+
         # ---------------- input + vision tower
         self.x_in = pb.alloc(B, R, R, V, zero=True)
         x = self.x_in
@@ -188,8 +207,7 @@ class _CaptionPlans:
             for blk in range(w.depths[s]):
                 for kind in ("spatial_block", "channel_block"):
                     pre = f"{vt}blocks.{s}.{blk}.{kind}."
-                    dwconv(pre + "conv1", A_, B_)
-                    layernorm(pre + "norm1", B_, hbuf)
+                    dwconv_ln(pre + "conv1", pre + "norm1", A_, B_, hbuf)
                     if kind == "spatial_block":
                         linear(pre + "window_attn.qkv", hbuf, qkv)
                         qb = f32(pre + "window_attn.qkv.bias")
@@ -206,8 +224,7 @@ class _CaptionPlans:
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
                                             i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens}))
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
-                    dwconv(pre + "conv2", B_, A_)
-                    layernorm(pre + "norm2", A_, hbuf)
+                    dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
                     linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU)
                     linear(pre + "ffn.fc2", ffn, A_, res=A_)
             x = A_

@@ -506,6 +506,15 @@ def check_caption_ops(dtype=L.F32, seed=0):
     t = {"x": R(B, H, W, C).to(tdt), "w": (R(3, 3, C) * 0.3).to(tdt), "b": R(C), "y": torch.zeros(B, H, W, C, dtype=tdt)}
     c, gq = _op_pair(t, lambda P: L.make_op(L.OP_DWCONV3, dtype, p=[P("x"), P("w"), P("b"), None, P("y")], i={0: B, 1: H, 2: W, 3: C}))
     res["dwconv3"] = _cmp(gq["y"], c["y"], tol, "dwconv3")
+    # fused dwconv3 + layernorm (C = 128 uses half a wave, C = 1024 all four vectors per lane)
+    for Cc in (128, 512, 1024):
+        Bq, Hq, Wq = 2, 7, 9
+        t = {"x": R(Bq, Hq, Wq, Cc).to(tdt), "w": (R(3, 3, Cc) * 0.3).to(tdt), "b": R(Cc), "g": R(Cc), "be": R(Cc),
+             "y1": torch.zeros(Bq, Hq, Wq, Cc, dtype=tdt), "h": torch.zeros(Bq, Hq, Wq, Cc, dtype=tdt)}
+        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_DWCONV3_LN, dtype, p=[P("x"), P("w"), P("b"), P("h"), P("y1"), P("g"), P("be")],
+                                                i={0: Bq, 1: Hq, 2: Wq, 3: Cc}, f={0: 1e-5}))
+        res[f"dwconv3_ln{Cc}_y1"] = _cmp(gq["y1"], c["y1"], tol, f"dwconv3_ln y1 C={Cc}")
+        res[f"dwconv3_ln{Cc}_h"] = _cmp(gq["h"], c["h"], tol * 5, f"dwconv3_ln h C={Cc}")
     # layernorm (+ add table), several widths
     for Cc in (128, 768, 1024):
         rows, period = 24, 6

@@ -95,6 +95,14 @@ def run_op(op, m):
         b = m.at(p[2], torch.float32)[:C]
         y = F.conv2d(x, w, b, padding=1, groups=C) + x
         m.at(p[4], dt)[: B * H * W * C].view(B, H, W, C).copy_(y.permute(0, 2, 3, 1).to(dt))
+    elif k == L.OP_DWCONV3_LN:
+        B, H, W, C = i[0], i[1], i[2], i[3]
+        x = m.at(p[0], dt)[: B * H * W * C].view(B, H, W, C).permute(0, 3, 1, 2).float()
+        w = m.at(p[1], dt)[: 9 * C].view(3, 3, C).permute(2, 0, 1).unsqueeze(1).float()
+        y1 = (F.conv2d(x, w, m.at(p[2], torch.float32)[:C], padding=1, groups=C) + x).permute(0, 2, 3, 1).to(dt)
+        m.at(p[4], dt)[: B * H * W * C].view(B, H, W, C).copy_(y1)
+        hn = F.layer_norm(y1.float(), (C,), m.at(p[5], torch.float32)[:C], m.at(p[6], torch.float32)[:C], f[0])
+        m.at(p[3], dt)[: B * H * W * C].view(B, H, W, C).copy_(hn.to(dt))
     elif k == L.OP_LAYERNORM:
         rows, C, period = i[0] * max(i[1], 1), i[3], i[5]
         x = m.at(p[0], dt)[: rows * C].view(rows, C).float()
