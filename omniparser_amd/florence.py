@@ -150,7 +150,7 @@ class _CaptionPlans:
                                 i={0: x.B, 1: x.H, 2: x.W, 3: x.C}))
             return out
 
-        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "1") != "0"
+        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "0") == "1"    # measured neutral on MI355X (6.87 vs 6.90 screenshots/s): opt-in
 
         def dwconv_ln(conv_key, norm_key, x: View, y1: View, hout: View):
             """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
