@@ -35,3 +35,33 @@ def test_end_to_end_get_som_labeled_img():
     out = G.check_end_to_end(width=0.5, R=64, image_seed=1)
     assert out["n_gpu"] == out["n_ref"] and out["min_iou"] >= 0.999
     assert out["identical_crops_token_exact"] >= 0.8 * out["captioned"]
+
+
+def test_omniparser_facade_parse_roundtrip():
+    """ref:util/omniparser.py contract: Omniparser(config).parse(base64) -> (base64 PNG, element list)."""
+    import base64
+    import io
+    from PIL import Image
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.omniparser import Omniparser
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    import os
+    os.environ["OMNI_CAPTION_RES"] = "64"
+    try:
+        cfg = {"som_model_path": str(ensure_blob(seed=0, nc=1, width=0.5)), "caption_model_name": "florence2",
+               "caption_model_path": str(ensure_caption_checkpoint(0)), "BOX_TRESHOLD": 0.05,
+               "ocr_provider": lambda image: synthetic_ocr(2, image.size[0], image.size[1], 24)}
+        op = Omniparser(cfg)
+        buf = io.BytesIO()
+        Image.fromarray(synthetic_screenshot(2, 1280, 800)).save(buf, format="PNG")
+        png_b64, elems = op.parse(base64.b64encode(buf.getvalue()).decode("ascii"))
+    finally:
+        os.environ.pop("OMNI_CAPTION_RES", None)
+    img = Image.open(io.BytesIO(base64.b64decode(png_b64)))
+    assert img.size == (1280, 800)
+    assert len(elems) > 10
+    for e in elems:
+        assert set(e) == {"type", "bbox", "interactivity", "content", "source"}
+        assert e["type"] in ("text", "icon") and len(e["bbox"]) == 4 and isinstance(e["content"], str)
+        assert all(0.0 <= v <= 1.0 for v in e["bbox"])
+    assert any(e["source"] == "box_yolo_content_yolo" for e in elems) and any(e["type"] == "text" for e in elems)

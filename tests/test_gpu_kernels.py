@@ -13,9 +13,18 @@ def test_mfma_fragment_layout():
 
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])
 def test_conv_igemm(dtype):
+    """default paths: split-f16 MFMA for long-K f32 GEMMs, exact-f32 / f16 MFMA otherwise."""
     import gpu_checks as G
     r = G.check_conv(dtype)
     assert r["cases"] >= 6
+
+
+def test_conv_igemm_exact_f32_path(monkeypatch):
+    """OMNI_CONV_SPLIT=0: every f32 GEMM on v_mfma_f32_32x32x2_f32."""
+    import gpu_checks as G
+    monkeypatch.setenv("OMNI_CONV_SPLIT", "0")
+    r = G.check_conv(L.F32)
+    assert r["cases"] >= 6 and r["worst_rel_err"] < 2e-5
 
 
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])
