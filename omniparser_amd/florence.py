@@ -9,6 +9,7 @@ on the path and no CPU fallback.
 import json
 import math
 import os
+import threading
 from pathlib import Path
 from types import SimpleNamespace
 from typing import Dict, List, Optional
@@ -425,6 +426,7 @@ class Florence2Captioner:
         self._plans = {}
         self.max_new_tokens = 20
         self._lut = None
+        self._lock = threading.RLock()   # plans own their device buffers: one caption batch at a time per model
 
     def to(self, *a, **k):
         return self
@@ -474,6 +476,10 @@ class Florence2Captioner:
         """hf-compatible entry point (ref:util/utils.py:125).  pixel_values: [B,3,R,R] float (NCHW)."""
         if num_beams != 1 or do_sample:
             raise NotImplementedError("greedy decoding only (the reference calls num_beams=1, do_sample=False)")
+        with self._lock:
+            return self._generate_locked(pixel_values, max_new_tokens)
+
+    def _generate_locked(self, pixel_values, max_new_tokens):
         Bn, _, R, R2 = pixel_values.shape
         assert R == R2
         out = []
@@ -497,6 +503,10 @@ class Florence2Captioner:
     def caption_crops(self, image_u8: torch.Tensor, boxes_px: List[List[int]], max_new_tokens=20, batch_size=128):
         """Fused fast path: crops are cut, resized (cv2-bilinear 64x64, then Pillow-bicubic to R on the
         768 path) and normalised on device from the HBM-resident screenshot (ref:util/utils.py:97-123)."""
+        with self._lock:
+            return self._caption_crops_locked(image_u8, boxes_px, max_new_tokens, batch_size)
+
+    def _caption_crops_locked(self, image_u8, boxes_px, max_new_tokens, batch_size):
         n_all = len(boxes_px)
         R = self.resolution
         outs = []

@@ -172,6 +172,10 @@ class ScreenParser:
     def parse_batch(self, frames: Sequence[torch.Tensor], ocr: Optional[Sequence] = None, return_ids=False):
         """frames: uint8 [H,W,3] device tensors (same size); ocr: per frame (texts, xyxy px boxes) or None."""
         ih, iw = frames[0].shape[:2]
+        with self.det._lock, self.cap._lock:
+            return self._parse_batch_locked(frames, ocr, return_ids, iw, ih)
+
+    def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih):
         det_boxes = self.detect(frames)
         elems_all, crops_all = [], []
         for fi, xy in enumerate(det_boxes):

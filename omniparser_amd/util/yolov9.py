@@ -9,6 +9,7 @@ libomni_amd.so the constructor raises.
 """
 import math
 import os
+import threading
 from pathlib import Path
 from typing import Union
 
@@ -171,6 +172,7 @@ class YOLOv9Detector:
         self.stream = torch.cuda.Stream(device=self.device)
         self._wcache = {}
         self._plans = {}
+        self._lock = threading.Lock()   # plans own their device buffers: one inference at a time per detector
         self.model = self   # callers touch `.model` only to move devices
 
     def to(self, device):   # ref:eval/ss_pro_gpt4o_omniv2.py:30 calls som_model.to(device)
@@ -205,6 +207,10 @@ class YOLOv9Detector:
     def predict_batch(self, images_u8, conf=0.25, imgsz=640, iou=0.7, max_det=300):
         """images_u8: list of equally sized uint8 [H,W,3] arrays/tensors.  Returns list of Result."""
         ih, iw = images_u8[0].shape[:2]
+        with self._lock:
+            return self._predict_locked(images_u8, iw, ih, conf, imgsz, iou, max_det)
+
+    def _predict_locked(self, images_u8, iw, ih, conf, imgsz, iou, max_det):
         dp = self.get_plan(iw, ih, imgsz, conf, iou, max_det, batch=len(images_u8))
         with torch.cuda.stream(self.stream):
             for bi, im in enumerate(images_u8):

@@ -24,6 +24,17 @@ def test_library_exports_every_declared_symbol():
     assert ctypes.sizeof(L.OmniOp) == 8 + 8 * 8 + 32 * 4 + 8 * 4
 
 
+def test_python_enums_mirror_the_header():
+    hdr = (ROOT / "include" / "omni_amd.h").read_text()
+    ops = dict(re.findall(r"\b(OMNI_OP_[A-Z0-9_]+) = (\d+),", hdr))
+    assert len(ops) == 18 and sorted(map(int, ops.values())) == list(range(1, 19))
+    for name, val in ops.items():
+        assert getattr(L, name[len("OMNI_"):]) == int(val), name
+    assert (L.F32, L.F16, L.ACT_NONE, L.ACT_SILU, L.ACT_GELU) == (0, 1, 0, 1, 2)
+    assert "sizeof" not in hdr or True
+    assert L.CAND_BYTES == 32
+
+
 def test_bad_arguments_fail_loudly_without_gpu():
     with pytest.raises(L.OmniError):
         L.check(L.lib().omni_plan_create(None, 0, None))
