@@ -443,9 +443,13 @@ class Florence2Captioner:
 
     def plans(self, B, R, max_new) -> _CaptionPlans:
         key = (B, R, max_new)
-        if key not in self._plans:
-            with torch.cuda.device(self.device):
-                self._plans[key] = _CaptionPlans(self, B, R, max_new)
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)
+            return self._plans[key]
+        while len(self._plans) >= int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "6")):   # LRU bound on activation pools
+            self._plans.pop(next(iter(self._plans)))
+        with torch.cuda.device(self.device):
+            self._plans[key] = _CaptionPlans(self, B, R, max_new)
         return self._plans[key]
 
     # ---- decode loop shared by both entry points

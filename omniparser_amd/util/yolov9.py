@@ -199,9 +199,14 @@ class YOLOv9Detector:
 
     def get_plan(self, iw, ih, imgsz, conf, iou, max_det, batch=1) -> _DetectPlan:
         key = (iw, ih, self._normalize_image_size(imgsz), float(conf), float(iou), int(max_det), batch)
-        if key not in self._plans:
-            with torch.cuda.device(self.device):
-                self._plans[key] = _DetectPlan(self, iw, ih, imgsz, conf, iou, max_det, batch)
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)          # most recently used last
+            return self._plans[key]
+        max_plans = int(os.environ.get("OMNI_MAX_DETECT_PLANS", "8"))
+        while len(self._plans) >= max_plans:                 # streams of mixed resolutions: bound the buffer pool (LRU)
+            self._plans.pop(next(iter(self._plans)))
+        with torch.cuda.device(self.device):
+            self._plans[key] = _DetectPlan(self, iw, ih, imgsz, conf, iou, max_det, batch)
         return self._plans[key]
 
     def predict_batch(self, images_u8, conf=0.25, imgsz=640, iou=0.7, max_det=300):
