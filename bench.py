@@ -67,20 +67,23 @@ def main():
     from omniparser_amd import dist as OD
     from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    from tools.make_weights import caption_dir, default_path, ensure_via_subprocess   # imports nothing from oracle/
 
     rank, world, local_rank = OD.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
     dev = torch.device("cuda", local_rank)
     imgsz = 640 if args.imgsz == "640" else (IH, IW)
+    # stand-in checkpoints are INPUT FILES (the reference downloads its weights): generated once, in a separate
+    # process, by tools/make_weights.py — this process never imports oracle/ outside cpu_baseline()
     if rank == 0:
-        ensure_blob(seed=0, nc=1, width=args.width)
+        ensure_via_subprocess("detector", seed=0, nc=1, width=args.width)
         if args.mode == "e2e":
-            ensure_caption_checkpoint(0)
+            ensure_via_subprocess("caption", seed=0)
     if world > 1:
         dist.barrier()
-    blob = ensure_blob(seed=0, nc=1, width=args.width)
+    blob = default_path(0, 1, args.width)
+    assert blob.exists(), blob
     det = YOLOv9Detector(model_path=blob, device=dev, precision=args.precision)
     B = args.batch
     frames = [torch.from_numpy(synthetic_screenshot(s, IW, IH)).to(dev) for s in range(8)]
@@ -93,7 +96,7 @@ def main():
     if args.mode == "e2e":
         from omniparser_amd.florence import Florence2Captioner
         from omniparser_amd.pipeline import ScreenParser
-        cap = Florence2Captioner(ensure_caption_checkpoint(0), dev, precision=args.precision, resolution=args.caption_res)
+        cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
         parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
     else:
         dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=B)

@@ -39,18 +39,6 @@ def ensure_blob(seed=0, nc=1, width=1.0):
     return p
 
 
-if __name__ == "__main__":
-    ap = argparse.ArgumentParser()
-    ap.add_argument("--seed", type=int, default=0)
-    ap.add_argument("--nc", type=int, default=1)
-    ap.add_argument("--width", type=float, default=1.0)
-    ap.add_argument("--out", default=None)
-    a = ap.parse_args()
-    out = a.out or default_path(a.seed, a.nc, a.width)
-    make_blob(out, a.seed, a.nc, a.width)
-    print(out)
-
-
 # ------------------------------------------------------------------------------------------------
 # Florence-2-base-shaped caption checkpoint (random weights): config.json + model.safetensors +
 # generation_config.json in the layout `get_caption_model_processor` loads (ref:util/utils.py:63-68).
@@ -111,3 +99,35 @@ def ensure_caption_checkpoint(seed=0):
             {"no_repeat_ngram_size": 3, "forced_bos_token_id": 0, "forced_eos_token_id": 2, "num_beams": 3,
              "bos_token_id": 0, "eos_token_id": 2, "pad_token_id": 1, "decoder_start_token_id": 2}))
     return d
+
+
+def ensure_via_subprocess(kind: str, seed=0, nc=1, width=1.0):
+    """Generate the stand-in checkpoint in a SEPARATE process (so the caller's process never imports oracle/)
+    and return its path.  kind: 'detector' | 'caption'."""
+    import subprocess
+    path = default_path(seed, nc, width) if kind == "detector" else caption_dir(seed)
+    marker = path if kind == "detector" else path / "model.safetensors"
+    if not marker.exists():
+        cmd = [sys.executable, str(Path(__file__).resolve()), "--ensure", kind, "--seed", str(seed), "--nc", str(nc), "--width", str(width)]
+        r = subprocess.run(cmd, capture_output=True, text=True)
+        if r.returncode != 0 or not marker.exists():
+            raise RuntimeError(f"weight generation failed ({' '.join(cmd)}):\n{r.stderr[-2000:]}")
+    return path
+
+
+if __name__ == "__main__":
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--nc", type=int, default=1)
+    ap.add_argument("--width", type=float, default=1.0)
+    ap.add_argument("--out", default=None)
+    ap.add_argument("--ensure", choices=["detector", "caption"], default=None)
+    a = ap.parse_args()
+    if a.ensure == "caption":
+        print(ensure_caption_checkpoint(a.seed))
+    elif a.ensure == "detector":
+        print(ensure_blob(a.seed, a.nc, a.width))
+    else:
+        out = a.out or default_path(a.seed, a.nc, a.width)
+        make_blob(out, a.seed, a.nc, a.width)
+        print(out)
