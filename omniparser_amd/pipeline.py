@@ -19,8 +19,10 @@ from .util.yolov9 import YOLOv9Detector
 
 class ScreenParser:
     def __init__(self, detector: YOLOv9Detector, captioner: Florence2Captioner, processor=None,
-                 box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640, batch_size=128):
+                 box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640, batch_size=128,
+                 tile_large=False):
         self.det, self.cap = detector, captioner
+        self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, batch_size
@@ -176,7 +178,10 @@ class ScreenParser:
             return self._parse_batch_locked(frames, ocr, return_ids, iw, ih)
 
     def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih):
-        det_boxes = self.detect(frames)
+        if self.tile_large and (iw > 1952 or ih > 1112):
+            det_boxes = [self.detect_tiled(f)[0] for f in frames]      # >1080p: overlapping tiles + global NMS (our policy)
+        else:
+            det_boxes = self.detect(frames)
         elems_all, crops_all = [], []
         for fi, xy in enumerate(det_boxes):
             texts, boxes = ocr[fi] if ocr is not None else ([], [])
