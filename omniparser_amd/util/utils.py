@@ -269,7 +269,7 @@ def get_parsed_content_icon(filtered_boxes, starting_idx, image_source, caption_
         boxes_px.append([x0, y0, min(x1, W), min(y1, H)])
     if not boxes_px:
         return []
-    img_dev = image_source if isinstance(image_source, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(image_source))
+    img_dev = image_source if isinstance(image_source, torch.Tensor) else torch.from_numpy(np.array(image_source, order="C"))   # writable copy (PIL views are read-only)
     img_dev = img_dev.to(model.device)
     ids = model.caption_crops(img_dev, boxes_px, max_new_tokens=20, batch_size=batch_size)
     texts = processor.batch_decode(ids, skip_special_tokens=True)

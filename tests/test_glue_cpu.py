@@ -122,3 +122,38 @@ def test_vectorised_overlap_removal_equals_simple_restatement():
         a = remove_overlap_new(copy.deepcopy(icons), thr, copy.deepcopy(ocr) if (ocr and trial % 5) else None)
         b = _remove_overlap_new_simple(copy.deepcopy(icons), thr, copy.deepcopy(ocr) if (ocr and trial % 5) else None)
         assert a == b, trial
+
+
+def test_omniparser_facade_on_fake_adapters(monkeypatch):
+    """ref:util/omniparser.py:7-32 contract with the device adapters stubbed out: config keys, base64 in,
+    (base64 PNG, element list) out, overlay style arithmetic, OCR provider hand-over."""
+    import base64
+    import io
+    from PIL import Image
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util import omniparser as F
+    from omniparser_amd.util import utils as U
+    xyxy = torch.tensor([[10., 10., 50., 50.], [100., 100., 160., 150.], [300., 40., 340., 90.]])
+    seen = {}
+    monkeypatch.setattr(U, "get_yolo_model", lambda model_path, device: seen.setdefault("det", (model_path, device)) and _FakeDet(xyxy))
+    monkeypatch.setattr(U, "get_caption_model_processor",
+                        lambda model_name, model_name_or_path, device: {"model": _FakeCap(), "processor": _FakeProc()})
+    for size in [(1920, 1080), (3840, 2160), (640, 480), (3200, 100)]:
+        r = max(size) / 3200
+        assert F.overlay_style(size) == {"text_scale": 0.8 * r, "text_thickness": max(int(2 * r), 1),
+                                         "text_padding": max(int(3 * r), 1), "thickness": max(int(3 * r), 1)}
+    cfg = {"som_model_path": "blob.pt", "caption_model_name": "florence2", "caption_model_path": "dir", "BOX_TRESHOLD": 0.05,
+           "ocr_provider": lambda image: synthetic_ocr(3, image.size[0], image.size[1], 6)}
+    op = F.Omniparser(cfg)
+    assert seen["det"][0] == "blob.pt"
+    buf = io.BytesIO()
+    Image.fromarray(synthetic_screenshot(1, 640, 400)).save(buf, format="PNG")
+    b64 = base64.b64encode(buf.getvalue()).decode("ascii")
+    png, elems = op.parse(b64)
+    assert Image.open(io.BytesIO(base64.b64decode(png))).size == (640, 400)
+    assert sum(e["type"] == "text" for e in elems) >= 1 and sum(e["type"] == "icon" for e in elems) >= 1
+    assert all(isinstance(e["content"], str) for e in elems)
+    assert op.parse_many([b64, b64])[1][1] == elems
+    cfg.pop("ocr_provider")
+    _, icons_only = F.Omniparser(cfg).parse(b64)
+    assert [e["type"] for e in icons_only] == ["icon"] * 3
