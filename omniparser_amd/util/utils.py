@@ -17,7 +17,7 @@ from typing import List, Optional, Union
 
 import numpy as np
 import torch
-from PIL import Image, ImageDraw
+from PIL import Image
 
 from ..florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS, Florence2Captioner
 from .yolov9 import YOLOv9Detector
@@ -283,21 +283,21 @@ def _box_convert_xyxy_to_cxcywh(b: torch.Tensor) -> torch.Tensor:
 
 def annotate(image_source: np.ndarray, boxes: torch.Tensor, logits, phrases, text_scale=0.4, text_padding=5,
              text_thickness=2, thickness=3):
-    """ref:util/utils.py:336-364: returns (annotated RGB frame, {str(i): xywh}).  Drawing uses PIL
-    (cv2/supervision are absent); the image is a visual aid, not parity-gated (SURVEY 2.1 #4)."""
+    """ref:util/utils.py:336-364: boxes cxcywh ratios -> (annotated RGB frame, {str(phrase): xywh px}).  Labels are
+    the running box indices (not `phrases`), exactly as the reference; layout = util/overlay.py (pinned to the
+    reference's cv2 call sequence), raster = Pillow (cv2/supervision are absent)."""
+    from .overlay import BoxAnnotator
     h, w, _ = image_source.shape
-    b = boxes * torch.tensor([w, h, w, h], dtype=boxes.dtype)
+    b = boxes * torch.Tensor([w, h, w, h])
     cx, cy, bw, bh = b.unbind(-1)
-    xyxy = torch.stack((cx - bw / 2, cy - bh / 2, cx + bw / 2, cy + bh / 2), -1).numpy()
-    xywh = torch.stack((cx - bw / 2, cy - bh / 2, bw, bh), -1).numpy()
+    xyxy = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh), -1).numpy()    # torchvision box_convert
+    xywh = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, bw, bh), -1).numpy()
+    labels = [f"{i}" for i in range(b.shape[0])]
+    frame = np.array(image_source, order="C")
+    BoxAnnotator(text_scale=text_scale, text_padding=text_padding, text_thickness=text_thickness, thickness=thickness).annotate(
+        frame, xyxy, labels=labels, image_size=(w, h))
     label_coordinates = {f"{phrase}": v for phrase, v in zip(phrases, xywh)}
-    im = Image.fromarray(image_source.copy())
-    draw = ImageDraw.Draw(im)
-    for i, (x1, y1, x2, y2) in enumerate(xyxy.tolist()):
-        col = ((37 * i) % 200 + 30, (91 * i) % 200 + 30, (151 * i) % 200 + 30)
-        draw.rectangle([x1, y1, x2, y2], outline=col, width=max(int(thickness), 1))
-        draw.text((x1 + 2, max(y1 - 10, 0)), str(phrases[i]), fill=col)
-    return np.asarray(im), label_coordinates
+    return frame, label_coordinates
 
 
 def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_TRESHOLD=0.01, output_coord_in_ratio=False,
@@ -347,7 +347,7 @@ def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_T
         cfg = draw_bbox_config or {"text_scale": text_scale, "text_padding": text_padding}
         frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)
         buf = io.BytesIO()
-        Image.fromarray(frame).save(buf, format="PNG")
+        Image.fromarray(frame).save(buf, format="PNG", compress_level=int(os.environ.get("OMNI_PNG_LEVEL", "6")))   # 6 = Pillow default
         encoded = base64.b64encode(buf.getvalue()).decode("ascii")
     if output_coord_in_ratio:
         label_coordinates = {k: [v[0] / w, v[1] / h, v[2] / w, v[3] / h] for k, v in label_coordinates.items()}
