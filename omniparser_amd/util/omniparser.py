@@ -43,20 +43,21 @@ class Omniparser(object):
             model_name=config["caption_model_name"], model_name_or_path=config["caption_model_path"], device=device)
         self.ocr_provider: Optional[Callable] = config.get("ocr_provider")
 
-    def _ocr(self, image: Image.Image):
-        found = self.ocr_provider(image) if self.ocr_provider is not None else None
+    def _ocr(self, image: Image.Image, ocr=None):
+        """`ocr` = (texts, xyxy px boxes) handed over by the caller for THIS image; else the configured provider."""
+        found = ocr if ocr is not None else (self.ocr_provider(image) if self.ocr_provider is not None else None)
         (texts, boxes), _ = U.check_ocr_box(image, ocr_result=found, **_OCR_ARGS)
         return texts, boxes
 
-    def parse_image(self, image: Image.Image):
-        texts, boxes = self._ocr(image)
+    def parse_image(self, image: Image.Image, ocr=None):
+        texts, boxes = self._ocr(image, ocr)
         labeled, _coords, elements = U.get_som_labeled_img(
             image, self.som_model, BOX_TRESHOLD=self.config["BOX_TRESHOLD"], ocr_bbox=boxes, ocr_text=texts,
             draw_bbox_config=overlay_style(image.size), caption_model_processor=self.caption_model_processor, **_SOM_ARGS)
         return labeled, elements
 
-    def parse(self, image_base64: str):
-        return self.parse_image(decode_image(image_base64))
+    def parse(self, image_base64: str, ocr=None):
+        return self.parse_image(decode_image(image_base64), ocr)
 
     def parse_many(self, images_base64: Sequence[str]):
         """Service helper: parse several screenshots with the same models (sequentially; the batched device path

@@ -300,6 +300,13 @@ def annotate(image_source: np.ndarray, boxes: torch.Tensor, logits, phrases, tex
     return frame, label_coordinates
 
 
+def encode_png_b64(frame: np.ndarray) -> str:
+    """ref:util/utils.py:485-488: RGB frame -> PNG -> base64 ascii (OMNI_PNG_LEVEL: zlib effort, 6 = Pillow's default)."""
+    buf = io.BytesIO()
+    Image.fromarray(frame).save(buf, format="PNG", compress_level=int(os.environ.get("OMNI_PNG_LEVEL", "6")))
+    return base64.b64encode(buf.getvalue()).decode("ascii")
+
+
 def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_TRESHOLD=0.01, output_coord_in_ratio=False,
                         ocr_bbox=None, text_scale=0.4, text_padding=5, draw_bbox_config=None, caption_model_processor=None,
                         ocr_text=[], use_local_semantics=True, iou_threshold=0.9, prompt=None, scale_img=False, imgsz=None,
@@ -346,9 +353,7 @@ def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_T
     else:
         cfg = draw_bbox_config or {"text_scale": text_scale, "text_padding": text_padding}
         frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)
-        buf = io.BytesIO()
-        Image.fromarray(frame).save(buf, format="PNG", compress_level=int(os.environ.get("OMNI_PNG_LEVEL", "6")))   # 6 = Pillow default
-        encoded = base64.b64encode(buf.getvalue()).decode("ascii")
+        encoded = encode_png_b64(frame)
     if output_coord_in_ratio:
         label_coordinates = {k: [v[0] / w, v[1] / h, v[2] / w, v[3] / h] for k, v in label_coordinates.items()}
     return encoded, label_coordinates, elems
