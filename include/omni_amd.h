@@ -181,6 +181,14 @@ int omni_resample_coeffs(int in_size, int out_size, int filter, int32_t* h_bound
  * stop, synchronises and returns mean milliseconds per iteration in *ms. */
 int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms);
 
+/* Host mirror of the GEMM kernels' block -> output-tile permutation (XCD-aware order with an optional N partition
+ * over XCD groups; csrc/conv_igemm.hip::tile_of_block).  Test/diagnostic entry point, no device work: for block
+ * `bid` of a grid over mtiles x ntiles tiles writes the tile (or -1/-1 for a padding block), the grid size and the
+ * N-partition count used.  weight_bytes >= 0: choose the partition like the launcher (L2-residency rule);
+ * weight_bytes < 0: use `xcd_n` (1, 2, 4 or 8, must divide ntiles). */
+int omni_debug_tile_map(int mtiles, int ntiles, int xcd_n, long long weight_bytes, int bid, int* mt, int* nt, int* grid,
+                        int* xcd_n_used);
+
 #ifdef __cplusplus
 }
 #endif

@@ -19,7 +19,7 @@ CAND_BYTES = 32
 EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
-    "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time",
+    "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
 ]
 
 
@@ -68,6 +68,9 @@ def lib():
     L.omni_resample_coeffs.restype = c_int
     L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
     L.omni_plan_time.restype = c_int
+    L.omni_debug_tile_map.argtypes = [c_int, c_int, c_int, ctypes.c_longlong, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
+                                      POINTER(c_int)]
+    L.omni_debug_tile_map.restype = c_int
     if L.omni_abi_version() != 1:
         raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
     _lib = L
@@ -160,3 +163,11 @@ def resample_coeffs(in_size: int, out_size: int, filt: int):
     if rc <= 0:
         check(rc)
     return bounds, coef
+
+
+def tile_map(mtiles: int, ntiles: int, bid: int, xcd_n: int = 1, weight_bytes: int = -1):
+    """Host mirror of the GEMM block -> tile permutation: returns (mt, nt, grid, xcd_n_used); mt = nt = -1 for padding blocks."""
+    mt, nt, grid, used = c_int(), c_int(), c_int(), c_int()
+    check(lib().omni_debug_tile_map(mtiles, ntiles, xcd_n, weight_bytes, bid, ctypes.byref(mt), ctypes.byref(nt), ctypes.byref(grid),
+                                    ctypes.byref(used)))
+    return mt.value, nt.value, grid.value, used.value

@@ -35,10 +35,57 @@ struct ConvArgs {
   int B, H, W, Cin, ldi, in_coff, KH, KW, stride, pad, Ho, Wo;
   int Cout, ldo, out_coff, act, ldr, res_coff;
   int M, K, ktiles, cin_tiles;
-  int splits, kt_per_split, mtiles, ntiles, xcd_order;
+  int splits, kt_per_split, mtiles, ntiles, xcd_order, xcd_n;
   float* ws; long long ws_bytes;
   float scale;
 };
+
+// Block -> output tile.  MI355X dispatches consecutive workgroups round-robin over its 8 XCDs (bid & 7), each with
+// a private 4 MiB L2.  With xcd_order the grid is laid out per XCD:
+//   * xcd_n == 1: XCD x owns row blocks mt = x (mod 8) and walks all N tiles of one row block back to back, so the
+//     activation tile is fetched once per row block and re-used from L2 by its N-tile neighbours;
+//   * xcd_n  > 1: the N tiles are additionally partitioned over xcd_n XCD groups (XCD x serves N partition x % xcd_n
+//     and row blocks = x / xcd_n (mod 8 / xcd_n)).  Each XCD then touches only ntiles/xcd_n weight panels — chosen so
+//     that slab (<= ~1.25 MiB) stays resident in its L2 while activations stream through — instead of the whole weight
+//     matrix being re-fetched from Infinity Cache / HBM by every row block (measured in round 1: weight re-fetch was
+//     ~75 % of this kernel's L2-miss traffic, profiles/r1_gemm_traffic_model.md).
+// Pure index permutation: every (mt, nt) is produced exactly once for bid in [0, omni_tile_grid), results are
+// bit-identical for any xcd_n.  Host mirror + exhaustive bijection test: omni_debug_tile_map / tests/test_host_cpu.py.
+__host__ __device__ __forceinline__ bool tile_of_block(int bid, int mtiles, int ntiles, int xcd_order, int xcd_n, int& mt, int& nt) {
+  if (xcd_order) {
+    const int x = bid & 7, s = bid >> 3;
+    const int gn = ntiles / xcd_n;               // N tiles per XCD group (xcd_n divides ntiles)
+    const int ml = s / gn;
+    mt = ml * (8 / xcd_n) + x / xcd_n;
+    nt = (x % xcd_n) * gn + (s - ml * gn);
+    return mt < mtiles;
+  }
+  mt = bid % mtiles;                             // few M tiles: plain order keeps all 8 XCDs busy
+  nt = bid / mtiles;
+  return true;
+}
+
+__host__ inline unsigned tile_grid(int mtiles, int ntiles, int xcd_order, int xcd_n) {
+  if (!xcd_order) return (unsigned)(mtiles * ntiles);
+  const int mper = 8 / xcd_n;
+  return (unsigned)(((mtiles + mper - 1) / mper) * (ntiles / xcd_n) * 8);
+}
+
+// N-partition choice: smallest xcd_n in {2, 4, 8} dividing ntiles whose per-XCD weight slab fits the L2 budget;
+// 1 (row-block mapping) when the whole matrix already fits or no divisor achieves residency.
+__host__ inline int choose_xcd_n(int ntiles, long long weight_bytes) {
+  static int enabled = -1;
+  static long long budget = 5ll << 18;           // 1.25 MiB of the 4 MiB L2 (OMNI_XCD_L2_BUDGET_KB overrides: tuning knob)
+  if (enabled < 0) {
+    const char* e = getenv("OMNI_XCD_NSPLIT");
+    enabled = (e && atoi(e) == 0) ? 0 : 1;
+    if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
+  }
+  if (!enabled || weight_bytes <= budget) return 1;
+  for (int xn = 2; xn <= 8; xn *= 2)
+    if (ntiles % xn == 0 && weight_bytes / xn <= budget) return xn;
+  return 1;
+}
 
 __device__ __forceinline__ float act_apply(float v, int act) {
   if (act == OMNI_ACT_SILU) {
@@ -74,16 +121,8 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
   // walks all N tiles of ONE M tile back to back, so the activation tile stays in that XCD's 4 MiB L2
   // and is fetched from HBM once instead of once per N tile; the (small) weight matrix is shared via
   // L2/Infinity Cache by everybody.
-  const int bid = blockIdx.x;
   int mt, nt;
-  if (a.xcd_order) {
-    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
-    nt = (bid >> 3) % a.ntiles;
-    if (mt >= a.mtiles) return;
-  } else {               // few M tiles: plain order keeps all 8 XCDs busy
-    mt = bid % a.mtiles;
-    nt = bid / a.mtiles;
-  }
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
   const int m0 = mt * BM;
   const int n0 = nt * BN;
   const int vec = tid % VPR;
@@ -361,16 +400,8 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
 
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave / WN, wn = wave % WN;
-  const int bid = blockIdx.x;
   int mt, nt;
-  if (a.xcd_order) {
-    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
-    nt = (bid >> 3) % a.ntiles;
-    if (mt >= a.mtiles) return;
-  } else {
-    mt = bid % a.mtiles;
-    nt = bid / a.mtiles;
-  }
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
   const int m0 = mt * BM, n0 = nt * BN;
   const int vec = tid % VPR, r0 = tid / VPR;
   const int kt0 = blockIdx.z * a.kt_per_split;
@@ -577,13 +608,8 @@ __global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
   const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
   const int wm = wave >> 2, wn = wave & 3;
-  const int bid = blockIdx.x;
   int mt, nt;
-  if (a.xcd_order) {
-    mt = ((bid >> 3) / a.ntiles) * 8 + (bid & 7);
-    nt = (bid >> 3) % a.ntiles;
-    if (mt >= a.mtiles) return;
-  } else { mt = bid % a.mtiles; nt = bid / a.mtiles; }
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
   const int m0 = mt * BM, n0 = nt * BN;
   const int vec = tid % VPR, r0 = tid / VPR;
   const int kt0 = blockIdx.z * a.kt_per_split;
@@ -733,12 +759,230 @@ __global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------------------
+// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4; NOT the default): the same staging / MFMA scheme as
+// conv_split_kernel with a WM x WN wave grid, so a 256x128 block tile (4 x 2 waves, 64x64 per wave: 0.67 LDS reads
+// per MFMA instead of 1.0, 25 % fewer operand bytes per MFMA from L2) can be measured against the default.
+// Static resources (tools/isa_report.py): 201-212 registers, no scratch, 108 KB LDS -> one 8-wave block per CU.
+// Dropped on paper: 256x256 (two f32 accumulator sets = 256 VGPRs, spills) and an "A-deep" pipeline with activation
+// loads two K slices ahead (needs > 128 registers at 4 waves/SIMD: 420 B of scratch; at 2 waves/SIMD it is the
+// measured-slower variant 1).
+template <int BM, int BN, int WM, int WN, bool PW, int MINB>
+__global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArgs a) {
+  constexpr int NW = WM * WN;
+  constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
+  constexpr int BKE = 32;
+  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int STAGE = (BM + BN) * ROWB;
+  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile / wave grid mismatch");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int wm = wave / WN, wn = wave % WN;
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+  const int vec = tid % VPR, r0 = tid / VPR;
+  const int kt0 = blockIdx.z * a.kt_per_split;
+  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
+
+  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
+  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(a.w);
+
+  long long a_base[A_IT];
+  int a_hi0[A_IT], a_wi0[A_IT];
+  bool a_ok[A_IT];
+  const float* a_row[A_IT];
+#pragma unroll
+  for (int it = 0; it < A_IT; ++it) {
+    int m = m0 + r0 + it * RPP;
+    a_ok[it] = m < a.M;
+    int mm = a_ok[it] ? m : 0;
+    int wo = mm % a.Wo;
+    int t = mm / a.Wo;
+    int ho = t % a.Ho;
+    int b = t / a.Ho;
+    a_hi0[it] = ho * a.stride - a.pad;
+    a_wi0[it] = wo * a.stride - a.pad;
+    a_base[it] = (long long)b * a.H * a.W * a.ldi + a.in_coff;
+    a_row[it] = X + (long long)mm * a.ldi + a.in_coff + vec * 4;
+  }
+  const unsigned char* b_ptr[B_IT];
+  bool b_ok[B_IT];
+#pragma unroll
+  for (int it = 0; it < B_IT; ++it) {
+    int n = n0 + r0 + it * RPP;
+    b_ok[it] = n < a.Cout;
+    b_ptr[it] = Wb + (long long)(b_ok[it] ? n : 0) * a.K * 4 + vec * 16;
+  }
+  int w_r = 0, w_s = 0, w_c = 0;
+  if (!PW) {
+    int tap = kt0 / a.cin_tiles;
+    w_c = (kt0 - tap * a.cin_tiles) * BKE;
+    w_r = tap / a.KW;
+    w_s = tap - w_r * a.KW;
+  }
+
+  u32x4 ra0[A_IT], rb[B_IT];
+  const u32x4 zero4 = {0u, 0u, 0u, 0u};
+  // load_a MUST be called once per K slice in increasing order (it advances the (r, s, c) walker)
+  auto load_a = [&](int kt, u32x4* ra) {
+    if (PW) {
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it)
+        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
+    } else {
+      int r = w_r, s = w_s, c = w_c + vec * 4;
+      w_c += BKE;
+      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
+#pragma unroll
+      for (int it = 0; it < A_IT; ++it) {
+        int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
+        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
+      }
+    }
+  };
+  auto load_b = [&](int kt) {
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + (long long)kt * RB) : zero4;
+  };
+  const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
+  auto store_tile = [&](int stage, const u32x4* ra) {
+    unsigned char* sA = lds + stage * STAGE;
+    unsigned char* sB = sA + BM * ROWB;
+#pragma unroll
+    for (int it = 0; it < B_IT; ++it)
+      *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
+#pragma unroll
+    for (int it = 0; it < A_IT; ++it) {
+      uint2 hi, lo;
+      split_f16x4(ra[it], hi, lo);
+      unsigned char* p = sA + (r0 + it * RPP) * ROWB + a_wr;
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + 32) = lo;
+    }
+  };
+
+  f32x16 accM[TM][TN], accC[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
+
+  const int a_rd = (wm * (BM / WM) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_rd = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+
+  auto compute = [&](int stage) {
+    const unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+    for (int j16 = 0; j16 < 2; ++j16) {
+      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        ah[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64);
+        al[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64 + 32);
+      }
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64);
+        bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64 + 32);
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) {
+          accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
+          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
+        }
+    }
+  };
+
+  if (kt0 < kt1) { load_b(kt0); load_a(kt0, ra0); store_tile(0, ra0); }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) { load_b(kt + 1); load_a(kt + 1, ra0); }
+    compute(cur);
+    if (more) store_tile(cur ^ 1, ra0);
+    __syncthreads();
+    cur ^= 1;
+  }
+
+  const float inv = 1.0f / 2048.0f;
+  if (a.splits > 1) {
+    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      if (n >= a.Cout) continue;
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+        int mb = m0 + wm * (BM / WM) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+        for (int e = 0; e < 16; ++e) {
+          int m = mb + (e & 3) + 8 * (e >> 2);
+          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][j][e] + accC[i][j][e] * inv;
+        }
+      }
+    }
+    return;
+  }
+  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
+  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
+  const float scale = a.scale;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+    bool nok = n < a.Cout;
+    float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+      int mb = m0 + wm * (BM / WM) + i * 32 + 4 * (lane >> 5);
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = mb + (e & 3) + 8 * (e >> 2);
+        if (nok && m < a.M) {
+          float v = (accM[i][j][e] + accC[i][j][e] * inv) + bias;
+          if (scale != 0.0f) v *= scale;
+          v = act_apply(v, a.act);
+          if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
+          Y[(long long)m * a.ldo + a.out_coff + n] = v;
+        }
+      }
+    }
+  }
+}
+
+template <int BM, int BN, int WM, int WN, int MINB>
+void launch_split2(ConvArgs& a, hipStream_t s) {
+  a.mtiles = (a.M + BM - 1) / BM;
+  a.ntiles = (a.Cout + BN - 1) / BN;
+  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
+  a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
+  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
+  const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
+  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB>), grid, dim3(WM * WN * 64), 0, s, a);
+  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB>), grid, dim3(WM * WN * 64), 0, s, a);
+  if (a.splits > 1) {
+    long long total = (long long)a.M * a.Cout;
+    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
+  }
+}
+
 template <int BM, int BN>
 void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
   a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
-  dim3 grid(a.xcd_order ? ((a.mtiles + 7) / 8) * 8 * a.ntiles : a.mtiles * a.ntiles, 1, a.splits);
+  a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
+  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
   const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
   // 128x128 tile variants (measured on MI355X, TF/s effective on the stage-2 GEMMs):
   //   0 = 4 waves, 64x64 per wave, 2 waves/SIMD: 172-209   1 = 8 waves + two-slice-ahead loads, 1 block/CU: 142-177
@@ -797,6 +1041,13 @@ void launch_split(ConvArgs& a, hipStream_t s) {
     if (bm == 128 && !strcmp(e, "128x64")) bn = 64;
     if (bm == 128 && !strcmp(e, "128x128") && a.Cout > 64) bn = 128;
   }
+  // opt-in experiment variant 4 (conv_split2_kernel, 256x128 tile); default stays variant 2
+  if (const char* e = getenv("OMNI_SPLIT_VARIANT")) {
+    if (atoi(e) == 4 && bm == 128 && bn == 128 && a.splits == 1 && blocks(256, 128) >= 256) {
+      launch_split2<256, 128, 4, 2, 2>(a, s);
+      return;
+    }
+  }
   if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
   else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);
   else launch_split_cfg<64, 64>(a, s);
@@ -807,7 +1058,8 @@ void launch_cfg(ConvArgs& a, bool aligned, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
   a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
-  dim3 grid(a.xcd_order ? ((a.mtiles + 7) / 8) * 8 * a.ntiles : a.mtiles * a.ntiles, 1, a.splits);
+  a.xcd_n = 1;                                  // exact-f32 / f16 kernels: row-block mapping only
+  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
   const bool pw = aligned && a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
   if (pw)
     hipLaunchKernelGGL((conv_igemm_kernel<T, BM, BN, RB, true, true>), grid, dim3(256), 0, s, a);
@@ -915,5 +1167,23 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   } else if (op->dtype == OMNI_F32) launch_typed<float>(a, s);
   else launch_typed<half_t>(a, s);
   OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+// Host mirror of the block -> tile mapping (same inline function the kernels use) so the permutation can be checked
+// exhaustively without a GPU.  weight_bytes < 0: take xcd_n as given; otherwise it is chosen like the launcher does.
+extern "C" int omni_debug_tile_map(int mtiles, int ntiles, int xcd_n, long long weight_bytes, int bid, int* mt, int* nt, int* grid,
+                                   int* xcd_n_used) {
+  if (mtiles <= 0 || ntiles <= 0 || !mt || !nt) return OMNI_E_ARG;
+  const int xcd_order = (mtiles >= 64 && ntiles > 1) ? 1 : 0;
+  int xn = xcd_order ? (weight_bytes >= 0 ? choose_xcd_n(ntiles, weight_bytes) : xcd_n) : 1;
+  if (xn != 1 && xn != 2 && xn != 4 && xn != 8) return OMNI_E_ARG;
+  if (ntiles % xn) return OMNI_E_ARG;
+  if (grid) *grid = (int)tile_grid(mtiles, ntiles, xcd_order, xn);
+  if (xcd_n_used) *xcd_n_used = xn;
+  int a = -1, b = -1;
+  bool ok = tile_of_block(bid, mtiles, ntiles, xcd_order, xn, a, b);
+  *mt = ok ? a : -1;
+  *nt = ok ? b : -1;
   return OMNI_OK;
 }

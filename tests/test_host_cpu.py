@@ -123,3 +123,51 @@ def test_oracle_nms_known_answers():
     c = torch.tensor([0, 0, 0, 1])
     assert D.batched_nms(b, s, c, 0.49).tolist() == [0, 3, 2]
     assert D.batched_nms(b[:0], s[:0], c[:0], 0.5).numel() == 0
+
+
+def test_gemm_tile_permutation_is_a_bijection():
+    """csrc/conv_igemm.hip::tile_of_block (XCD-aware order + N partition over XCD groups) through its host mirror:
+    every tile exactly once, padding blocks only beyond mtiles, each XCD (bid & 7) sees only its N partition and
+    walks the N tiles of a row block in consecutive slots; xcd_n == 1 reproduces the round-1 row-block mapping."""
+    from omniparser_amd import _lib as L
+    cases = [(2304, 16, -1, 4 * 2048 * 512), (2304, 12, -1, 4 * 1536 * 512), (2304, 4, -1, 4 * 512 * 2048), (585, 24, -1, 4 * 3072 * 768),
+             (585, 6, -1, 4 * 768 * 3072), (577, 8, 8, -1), (64, 2, 2, -1), (67, 8, 4, -1), (1000, 3, 1, -1), (63, 5, 1, -1), (400, 4, -1, 4 * 512 * 4608),
+             (2304, 4, -1, 4 * 512 * 512), (100, 1, 1, -1)]
+    for mtiles, ntiles, xn, wbytes in cases:
+        _, _, grid, used = L.tile_map(mtiles, ntiles, 0, xcd_n=max(xn, 1), weight_bytes=wbytes)
+        xcd_order = mtiles >= 64 and ntiles > 1
+        if wbytes >= 0 and xcd_order:
+            slab = wbytes / used
+            assert used in (1, 2, 4, 8) and ntiles % used == 0
+            assert used == 1 or slab <= 1.25 * 2 ** 20            # a partition is only chosen when its slab fits
+            if used == 1 and wbytes > 1.25 * 2 ** 20:
+                assert all(ntiles % k or wbytes / k > 1.25 * 2 ** 20 for k in (2, 4, 8))
+        seen = {}
+        per_xcd = [[] for _ in range(8)]
+        for bid in range(grid):
+            mt, nt, g2, u2 = L.tile_map(mtiles, ntiles, bid, xcd_n=max(xn, 1), weight_bytes=wbytes)
+            assert (g2, u2) == (grid, used)
+            if mt < 0:
+                assert nt < 0
+                continue
+            assert 0 <= mt < mtiles and 0 <= nt < ntiles and (mt, nt) not in seen
+            seen[(mt, nt)] = bid
+            per_xcd[bid & 7].append((mt, nt))
+        assert len(seen) == mtiles * ntiles
+        assert grid - len(seen) < 8 * ntiles                       # padding is at most one row-block round
+        if not xcd_order:
+            assert grid == mtiles * ntiles and used == 1
+            continue
+        gn = ntiles // used
+        for x, tiles in enumerate(per_xcd):
+            assert {nt for _, nt in tiles} <= set(range((x % used) * gn, (x % used + 1) * gn))
+            assert {mt % (8 // used) for mt, _ in tiles} == {x // used}
+            for k in range(0, len(tiles) - gn + 1, gn):            # consecutive slots = the N tiles of ONE row block
+                blk = tiles[k:k + gn]
+                if len({m for m, _ in blk}) == 1:
+                    assert [n for _, n in blk] == list(range((x % used) * gn, (x % used + 1) * gn))
+        if used == 1:                                              # round-1 formula
+            for (mt, nt), bid in list(seen.items())[:200]:
+                assert mt == ((bid >> 3) // ntiles) * 8 + (bid & 7) and nt == (bid >> 3) % ntiles
+    assert L.tile_map(2304, 16, 0, weight_bytes=4 * 2048 * 512)[3] == 4        # DaViT stage-2 fc1: 4 MiB of weights -> 4 groups
+    assert L.tile_map(2304, 4, 0, weight_bytes=4 * 512 * 512)[3] == 1          # 1 MiB: already resident

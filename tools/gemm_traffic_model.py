@@ -1,0 +1,120 @@
+"""Operand-traffic model of the split-f16 GEMM kernel on the captioner's 768x768 encode (no GPU needed).
+
+For every conv/linear op of the encode plan (built on CPU tensors) it takes M, N, K at a 128-crop micro-batch and
+the tile grid the launcher would choose, and evaluates three traffic figures per crop:
+  ideal     A once + W once + Y once (+ residual)                      = the algorithmic bytes
+  no-reuse  every block fetches its own A and W slices: A x ntiles + W x mtiles
+  tile 256  the same with a 256x128 block tile (OMNI_SPLIT_VARIANT=4): W x mtiles/2
+and compares them with the HBM traffic rocprofv3 measured for conv_split_kernel<128,128> in round 1
+(profiles/r1_pmc_traffic_conv_split.json: FETCH_SIZE x2-corrected + WRITE_SIZE over one 368-crop step).
+Writes profiles/r1_gemm_traffic_model.md."""
+import json
+import os
+import sys
+from pathlib import Path
+from types import SimpleNamespace
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+os.environ.setdefault("OMNI_CONV_SPLIT", "0")
+
+
+def choose_xn(ntiles: int, n: int, k: int, slab_limit=1.25 * 2 ** 20) -> int:
+    """Mirror of conv_igemm.hip::choose_xcd_n: number of XCD groups along N (1 = row-block mapping)."""
+    w_total = 4.0 * n * k
+    if w_total <= slab_limit:
+        return 1
+    for xn in (2, 4, 8):
+        if ntiles % xn == 0 and w_total / xn <= slab_limit:
+            return xn
+    return 1
+
+
+def main():
+    import torch
+    from omniparser_amd import _lib as L
+    from omniparser_amd import florence as FL
+    from tools.make_weights import ensure_via_subprocess
+    cdir = ensure_via_subprocess("caption", 0)
+    cap = SimpleNamespace(w=FL.FlorenceWeights(cdir), device=torch.device("cpu"), dtype=L.F32, _wcache={}, use_graph=False, stream=None)
+    cp = FL._CaptionPlans(cap, 1, 768, 20)
+    MB = 128                                   # crops per micro-batch
+    rows = []
+    for op in cp.encode_plan.ops:
+        if op.kind != 1:
+            continue
+        i = op.i
+        M1, N, K = i[0] * i[10] * i[11], i[12], i[6] * i[7] * i[3]
+        if i[3] % 32 or K < 128:
+            continue                           # exact-f32 kernel (first conv), not the split kernel
+        M = M1 * MB
+        bn = 128 if N > 64 else 64
+        bm = 128
+        blocks = lambda m, n: -(-M // m) * -(-N // n)
+        if blocks(bm, bn) < 512 and bn == 128:
+            bn = 64
+        if blocks(bm, bn) < 512:
+            bm = 64
+        rows.append(dict(M=M, N=N, K=K, bm=bm, bn=bn, mt=-(-M // bm), nt=-(-N // bn), res=bool(op.p[3])))
+    big = [r for r in rows if (r["bm"], r["bn"]) == (128, 128)]
+    def traffic(r, bm=None, reuse_a=False, reuse_w=False):
+        bm = bm or r["bm"]
+        mt = -(-r["M"] // bm)
+        a = 4 * r["M"] * r["K"] * (1 if reuse_a else r["nt"])
+        w = 4 * r["N"] * r["K"] * (1 if reuse_w else mt)
+        y = 4 * r["M"] * r["N"] * (2 if r["res"] else 1)
+        return a, w, y
+    def total(rs, **kw):
+        t = [0, 0, 0]
+        for r in rs:
+            for k, v in enumerate(traffic(r, **kw)):
+                t[k] += v
+        return [v / MB / 1e9 for v in t]       # GB per crop
+    meas = json.loads((ROOT / "profiles" / "r1_pmc_traffic_conv_split.json").read_text())["conv_split_128x128"]
+    crops = 368
+    mf, mw = meas["fetch_bytes_corrected"] / crops / 1e9, meas["write_bytes"] / crops / 1e9
+    flops = sum(2 * r["M"] * r["N"] * r["K"] for r in big) / MB / 1e9
+    L_ = []
+    L_.append("# Operand traffic of conv_split_kernel<128,128> on the 768x768 captioner encode (model vs PMC)\n")
+    L_.append(f"GEMMs routed to the 128x128 split kernel at a 128-crop micro-batch: {len(big)} of {len(rows)} split GEMMs, "
+              f"{flops:.1f} GFLOP per crop.\n")
+    L_.append("| traffic per crop (GB) | activations A | weights W | outputs Y (+residual read) | total |")
+    L_.append("|---|---|---|---|---|")
+    for name, kw in (("ideal (every operand once)", dict(reuse_a=True, reuse_w=True)),
+                     ("A shared by the N-tiles of a row block (L2), W re-fetched by every row block", dict(reuse_a=True)),
+                     ("no reuse at all (A x ntiles, W x mtiles)", dict()),
+                     ("no reuse, 256-row block tile (variant 4)", dict(bm=256)),
+                     ("A shared, W re-fetched, 256-row block tile", dict(bm=256, reuse_a=True))):
+        a, w, y = total(big, **kw)
+        L_.append(f"| {name} | {a:.2f} | {w:.2f} | {y:.2f} | {a + w + y:.2f} |")
+    def xcd_model(r, partition):
+        """row-block mapping: A once, W per row block unless the whole matrix (<= 1.25 MiB) is L2-resident;
+        N partition: A once per XCD group, W once per XCD when its slab is resident."""
+        A, W = 4 * r["M"] * r["K"], 4 * r["N"] * r["K"]
+        xn = choose_xn(r["nt"], r["N"], r["K"]) if partition else 1
+        resident = W / xn <= 1.25 * 2 ** 20
+        return A * xn, (W * 8 / xn if resident else W * r["mt"]), 4 * r["M"] * r["N"] * (2 if r["res"] else 1)
+    for name, part in (("L2 model, round-1 mapping (A shared in L2, W resident only if <= 1.25 MiB)", False),
+                       ("L2 model, N partition over XCD groups (default from now on)", True)):
+        t = [sum(xcd_model(r, part)[k] for r in big) / MB / 1e9 for k in range(3)]
+        L_.append(f"| {name} | {t[0]:.2f} | {t[1]:.2f} | {t[2]:.2f} | {sum(t):.2f} |")
+    L_.append(f"| **measured (rocprofv3 PMC, round 1 mapping)** | fetch {mf:.2f} | | write {mw:.2f} | {mf + mw:.2f} |")
+    L_.append("")
+    L_.append("Per-GEMM shapes (128-crop micro-batch) and their no-reuse operand bytes per MAC:\n")
+    L_.append("| M | N | K | ntiles | count | A GB/crop x ntiles | W GB/crop x mtiles |")
+    L_.append("|---|---|---|---|---|---|---|")
+    agg = {}
+    for r in big:
+        key = (r["M"], r["N"], r["K"], r["nt"])
+        a, w, _ = traffic(r)
+        e = agg.setdefault(key, [0, 0.0, 0.0])
+        e[0] += 1; e[1] += a / MB / 1e9; e[2] += w / MB / 1e9
+    for (M, N, K, nt), (c, a, w) in sorted(agg.items(), key=lambda kv: -(kv[1][1] + kv[1][2])):
+        L_.append(f"| {M} | {N} | {K} | {nt} | {c} | {a:.2f} | {w:.2f} |")
+    out = "\n".join(L_) + "\n"
+    (ROOT / "profiles" / "r1_gemm_traffic_model.md").write_text(out)
+    print(out)
+
+
+if __name__ == "__main__":
+    main()
