@@ -173,6 +173,8 @@ def main():
             "conf": CONF, "nms_iou": NMS_IOU, "overlap_iou": OVERLAP_IOU, "max_det": MAX_DET,
             "parallelism": f"replicas x{world}, round-robin shards of steps, 1 all_gather/job",
             "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
+            "gemm_tile_order": ("xcd row blocks + N partition (L2-resident weight slabs)"
+                                if os.environ.get("OMNI_XCD_NSPLIT", "1") != "0" else "xcd row blocks (round-1 order)"),
             "gemm_path": ("split-f16 x3 MFMA (f32-class accuracy)" if args.precision == "f32" and
                           os.environ.get("OMNI_CONV_SPLIT", "1") == "1" else
                           ("exact f32 MFMA" if args.precision == "f32" else "f16 MFMA")),
@@ -251,7 +253,8 @@ def roofline(args, det, parser, dp, crop_counts, B):
     if split and args.mode == "e2e" and args.caption_res == 768 and tfile.exists():
         t = json.loads(tfile.read_text())["conv_split_128x128"]
         out["traffic"] = round((t["fetch_bytes_corrected"] + t["write_bytes"]) / t["launches"])
-        out["traffic_note"] = "mean HBM bytes per conv_split_kernel<128,128> launch (PMC, profiles/r1_pmc_traffic_conv_split.json)"
+        out["traffic_note"] = ("mean HBM bytes per conv_split_kernel<128,128> launch (PMC, profiles/r1_pmc_traffic_conv_split.json; "
+                               "collected with the round-1 tile order, i.e. OMNI_XCD_NSPLIT=0)")
     out.update({
             "flops_per_step": flops, "launches_per_step": launches, "kernel_ms_per_step": round(ms, 3),
             "avg_launch_us": round(1000 * ms / max(launches, 1), 3), "parts": parts})
