@@ -74,13 +74,11 @@ __host__ inline unsigned tile_grid(int mtiles, int ntiles, int xcd_order, int xc
 // N-partition choice: smallest xcd_n in {2, 4, 8} dividing ntiles whose per-XCD weight slab fits the L2 budget;
 // 1 (row-block mapping) when the whole matrix already fits or no divisor achieves residency.
 __host__ inline int choose_xcd_n(int ntiles, long long weight_bytes) {
-  static int enabled = -1;
-  static long long budget = 5ll << 18;           // 1.25 MiB of the 4 MiB L2 (OMNI_XCD_L2_BUDGET_KB overrides: tuning knob)
-  if (enabled < 0) {
-    const char* e = getenv("OMNI_XCD_NSPLIT");
-    enabled = (e && atoi(e) == 0) ? 0 : 1;
-    if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
-  }
+  // read per launch (like the other tuning knobs) so one process can A/B the orders; captured graphs keep theirs
+  const char* e = getenv("OMNI_XCD_NSPLIT");
+  const bool enabled = !(e && atoi(e) == 0);
+  long long budget = 5ll << 18;                  // 1.25 MiB of the 4 MiB L2 (OMNI_XCD_L2_BUDGET_KB overrides: tuning knob)
+  if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
   if (!enabled || weight_bytes <= budget) return 1;
   for (int xn = 2; xn <= 8; xn *= 2)
     if (ntiles % xn == 0 && weight_bytes / xn <= budget) return xn;

@@ -1,4 +1,8 @@
-"""Micro-benchmark of conv_igemm on the captioner's dominant GEMM shapes (HIP events, per variant)."""
+"""Micro-benchmark of conv_igemm on the captioner's dominant GEMM shapes (HIP events, per variant).
+
+VARIANTS="f32,split:128x128:2,split:128x128:2+OMNI_XCD_NSPLIT=0,split:128x128:4" — kind[:tile[:split variant]] and
+optional +ENV=value pairs applied for that variant only.  Accuracy is checked on 2048 rows sampled over the whole
+M range (a wrong block -> tile permutation would leave rows unwritten or doubly written)."""
 import os
 import sys
 from pathlib import Path
@@ -22,11 +26,17 @@ def main():
     stream = torch.cuda.Stream()
     for variant in os.environ.get("VARIANTS", "f32,split:128x64,split:128x128").split(","):
         os.environ["OMNI_CONV_SPLIT"] = "1" if variant.startswith("split") else "0"
+        variant, *envs = variant.split("+")
+        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB"):
+            os.environ.pop(k, None)
+        for kv in envs:
+            k, v = kv.split("=")
+            os.environ[k] = v
         parts = variant.split(":")
         if len(parts) > 1:
             os.environ["OMNI_SPLIT_TILE"] = parts[1]
         os.environ["OMNI_SPLIT_VARIANT"] = parts[2] if len(parts) > 2 else "0"
-        print(f"--- variant {variant}")
+        print(f"--- variant {variant} {' '.join(envs)}")
         for name, M, N, K, act, res in SHAPES:
             pb = PlanBuilder("cuda", dtype)
             x = View(torch.randn(1, M, 1, K, device="cuda").to(tdt), 0, K)
@@ -39,10 +49,11 @@ def main():
             plan = pb.build()
             plan.run(stream); stream.synchronize()
             ms = plan.time(5, stream)
-            # accuracy on the first 256 rows vs f64
-            xs = x.t[0, :256, 0, :].double().cpu()
+            # accuracy vs f64 on rows sampled over the whole M range (incl. the first and last tiles)
+            rows = torch.cat([torch.arange(128), torch.arange(M - 128, M), torch.randint(0, M, (1792,))]).cuda()
+            xs = x.t[0, rows, 0, :].double().cpu()
             ref = xs @ wcpu.double().t()
-            got = y.t[0, :256, 0, :].double().cpu()
+            got = y.t[0, rows, 0, :].double().cpu()
             if act == 0 and not res:
                 err = ((got - (ref + bias.double())).abs().max() / ref.abs().max()).item()
             else:
