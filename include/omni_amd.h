@@ -189,6 +189,11 @@ int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms);
 int omni_debug_tile_map(int mtiles, int ntiles, int xcd_n, long long weight_bytes, int bid, int* mt, int* nt, int* grid,
                         int* xcd_n_used);
 
+/* Host emulation of one op on HOST pointers, running the same per-thread source the kernel runs (only kinds whose
+ * bodies need no LDS / cross-lane ops: OMNI_OP_DWCONV3; variant 0 = point kernel, 1 = strip kernel).  Test
+ * infrastructure for boxes without a GPU; never used by omni_op_launch or plans. */
+int omni_debug_host_op(const omni_op_t* op, int variant);
+
 #ifdef __cplusplus
 }
 #endif

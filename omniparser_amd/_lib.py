@@ -20,6 +20,7 @@ EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
+    "omni_debug_host_op",
 ]
 
 
@@ -71,6 +72,8 @@ def lib():
     L.omni_debug_tile_map.argtypes = [c_int, c_int, c_int, ctypes.c_longlong, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                       POINTER(c_int)]
     L.omni_debug_tile_map.restype = c_int
+    L.omni_debug_host_op.argtypes = [POINTER(OmniOp), c_int]
+    L.omni_debug_host_op.restype = c_int
     if L.omni_abi_version() != 1:
         raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
     _lib = L
@@ -171,3 +174,8 @@ def tile_map(mtiles: int, ntiles: int, bid: int, xcd_n: int = 1, weight_bytes: i
     check(lib().omni_debug_tile_map(mtiles, ntiles, xcd_n, weight_bytes, bid, ctypes.byref(mt), ctypes.byref(nt), ctypes.byref(grid),
                                     ctypes.byref(used)))
     return mt.value, nt.value, grid.value, used.value
+
+
+def host_op(op, variant: int = 1):
+    """Run the host emulation of `op` (host pointers!) — the same per-thread source the GPU kernel runs."""
+    check(lib().omni_debug_host_op(ctypes.byref(op), variant))

@@ -40,67 +40,159 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------------------------ dwconv3
 struct DwArgs { const void* x; const void* w; const float* bias; void* y; int B, H, W, C; long long total; };
 
+// Per-output body of the original kernel (one 16-byte channel vector of one pixel); host-callable so the CPU
+// suite can run the very same code (omni_debug_host_op).  Kept as the fallback for channel counts whose vector
+// count per pixel is not a power of two, and as the bit-exact reference of the strip kernel below.
 template <typename T>
-__global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
-  // w layout: [3][3][C] (tap-major) in T; y = x + bias + sum_taps w*x   (conv(x) + x).
-  // One 16-byte channel vector per lane: consecutive lanes walk consecutive channels of a pixel, the
-  // 3x3 neighbourhood is re-read through L1/L2, HBM sees x once and y once.
+__host__ __device__ __forceinline__ void dwconv3_point_body(const DwArgs& a, long long idx) {
   constexpr int V = ElemTraits<T>::kVec;
   struct Vec { T v[V]; };
   const T* __restrict__ X = (const T*)a.x;
   const T* __restrict__ Wt = (const T*)a.w;
   T* __restrict__ Y = (T*)a.y;
   const int cv = a.C / V;
-  const long long total = a.total / V;
+  int c = (int)(idx % cv) * V;
+  long long pix = idx / cv;
+  int w = (int)(pix % a.W);
+  long long t = pix / a.W;
+  int h = (int)(t % a.H);
+  long long b = t / a.H;
+  float acc[V];
+#pragma unroll
+  for (int e = 0; e < V; ++e) acc[e] = 0.0f;
+  Vec ctr;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    int hi = h + r - 1;
+    if (hi < 0 || hi >= a.H) continue;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      int wi = w + s - 1;
+      if (wi < 0 || wi >= a.W) continue;
+      Vec xv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(X + ((b * a.H + hi) * a.W + wi) * a.C + c));
+      Vec wv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(Wt + (r * 3 + s) * a.C + c));
+      if (r == 1 && s == 1) ctr = xv;
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] += ElemTraits<T>::to_f32(wv.v[e]) * ElemTraits<T>::to_f32(xv.v[e]);
+    }
+  }
+  Vec out;
+#pragma unroll
+  for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((acc[e] + a.bias[c + e]) + ElemTraits<T>::to_f32(ctr.v[e]));
+  *reinterpret_cast<u32x4*>(Y + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_kernel(DwArgs a) {
+  // w layout: [3][3][C] (tap-major) in T; y = x + bias + sum_taps w*x   (conv(x) + x).
+  // One 16-byte channel vector per lane: consecutive lanes walk consecutive channels of a pixel, the
+  // 3x3 neighbourhood is re-read through L1/L2, HBM sees x once and y once.
+  const long long total = a.total / ElemTraits<T>::kVec;
   for (long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x; idx < total;
-       idx += (long long)gridDim.x * blockDim.x) {
-    int c = (int)(idx % cv) * V;
-    long long pix = idx / cv;
-    int w = (int)(pix % a.W);
-    long long t = pix / a.W;
-    int h = (int)(t % a.H);
-    long long b = t / a.H;
-    float acc[V];
+       idx += (long long)gridDim.x * blockDim.x)
+    dwconv3_point_body<T>(a, idx);
+}
+
+// Strip version (default when C / vector width is a power of two, i.e. every DaViT stage): the round-1 kernel above
+// spends ~800 instructions per output vector, most of them 64-bit div/mod index arithmetic (static count:
+// tools/isa_report-style dump, 461 VALU + 347 SALU for 72 useful mul/add) — it was issue-bound at ~2.3 TB/s, not
+// memory-bound.  Here the grid is (row chunk, strip of DW_ROWS output rows, image): no division at all (w and c come
+// from shifts), the 9 weight vectors and the bias are loaded once per thread, and each thread slides down DW_ROWS
+// output rows so an input row is loaded once per 3 taps instead of 3 times ((R+2)/R loads per output row instead
+// of 3).  The accumulation order per output element is exactly the original's (tap rows ascending, then columns),
+// so results are bit-identical to dwconv3_kernel — checked on the host by tests/test_host_cpu.py.
+constexpr int DW_ROWS = 4;
+
+template <typename T>
+__host__ __device__ __forceinline__ void dwconv3_strip_body(const DwArgs& a, int b, int h0, unsigned r, int cv_log2) {
+  constexpr int V = ElemTraits<T>::kVec;
+  struct Vec { T v[V]; };
+  const int w = (int)(r >> cv_log2);
+  if (w >= a.W) return;
+  const int c = (int)(r & ((1u << cv_log2) - 1u)) * V;
+  const T* __restrict__ X = (const T*)a.x + (long long)b * a.H * a.W * a.C + c;
+  const T* __restrict__ Wt = (const T*)a.w + c;
+  T* __restrict__ Y = (T*)a.y + (long long)b * a.H * a.W * a.C + c;
+  float wt[9][V];
 #pragma unroll
-    for (int e = 0; e < V; ++e) acc[e] = 0.0f;
-    Vec ctr;
+  for (int k = 0; k < 9; ++k) {
+    Vec wv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(Wt + k * a.C));
 #pragma unroll
-    for (int r = 0; r < 3; ++r) {
-      int hi = h + r - 1;
-      if (hi < 0 || hi >= a.H) continue;
+    for (int e = 0; e < V; ++e) wt[k][e] = ElemTraits<T>::to_f32(wv.v[e]);
+  }
+  float acc[DW_ROWS][V];
+  Vec ctr[DW_ROWS];
 #pragma unroll
-      for (int s = 0; s < 3; ++s) {
-        int wi = w + s - 1;
-        if (wi < 0 || wi >= a.W) continue;
-        Vec xv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(X + ((b * a.H + hi) * a.W + wi) * a.C + c));
-        Vec wv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(Wt + (r * 3 + s) * a.C + c));
-        if (r == 1 && s == 1) ctr = xv;
+  for (int o = 0; o < DW_ROWS; ++o)
 #pragma unroll
-        for (int e = 0; e < V; ++e) acc[e] += ElemTraits<T>::to_f32(wv.v[e]) * ElemTraits<T>::to_f32(xv.v[e]);
+    for (int e = 0; e < V; ++e) acc[o][e] = 0.0f;
+#pragma unroll
+  for (int i = 0; i < DW_ROWS + 2; ++i) {            // input rows h0-1 .. h0+DW_ROWS
+    const int hi = h0 + i - 1;
+    if (hi < 0 || hi >= a.H) continue;
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      const int wi = w + s - 1;
+      if (wi < 0 || wi >= a.W) continue;
+      Vec xv = __builtin_bit_cast(Vec, *reinterpret_cast<const u32x4*>(X + ((long long)hi * a.W + wi) * a.C));
+#pragma unroll
+      for (int rr = 0; rr < 3; ++rr) {               // tap row rr of output row hi - rr + 1
+        const int o = i - rr;                        // output index within the strip
+        if (o < 0 || o >= DW_ROWS) continue;
+        if (rr == 1 && s == 1) ctr[o] = xv;
+#pragma unroll
+        for (int e = 0; e < V; ++e) acc[o][e] += wt[rr * 3 + s][e] * ElemTraits<T>::to_f32(xv.v[e]);
       }
     }
+  }
+#pragma unroll
+  for (int o = 0; o < DW_ROWS; ++o) {
+    const int ho = h0 + o;
+    if (ho >= a.H) break;
     Vec out;
 #pragma unroll
-    for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((acc[e] + a.bias[c + e]) + ElemTraits<T>::to_f32(ctr.v[e]));
-    *reinterpret_cast<u32x4*>(Y + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
+    for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((acc[o][e] + a.bias[c + e]) + ElemTraits<T>::to_f32(ctr[o].v[e]));
+    *reinterpret_cast<u32x4*>(Y + ((long long)ho * a.W + w) * a.C) = __builtin_bit_cast(u32x4, out);
   }
+}
+
+template <typename T>
+__global__ __launch_bounds__(256) void dwconv3_strip_kernel(DwArgs a, int cv_log2) {
+  dwconv3_strip_body<T>(a, (int)blockIdx.z, (int)blockIdx.y * DW_ROWS, blockIdx.x * 256u + threadIdx.x, cv_log2);
+}
+
+// launch geometry shared by the device launcher and the host emulation
+struct DwStripGrid { unsigned gx, gy, gz; int cv_log2; bool ok; };
+inline DwStripGrid dwconv3_strip_grid(const DwArgs& a, int V) {
+  DwStripGrid g{0, 0, 0, 0, false};
+  const int cv = a.C / V;
+  if (cv <= 0 || (cv & (cv - 1))) return g;                                   // power-of-two vector count only
+  while ((1 << g.cv_log2) < cv) ++g.cv_log2;
+  const long long row_vecs = (long long)a.W * cv;
+  g.gx = (unsigned)((row_vecs + 255) / 256);
+  g.gy = (unsigned)((a.H + DW_ROWS - 1) / DW_ROWS);
+  g.gz = (unsigned)a.B;
+  g.ok = g.gy <= 65535u && g.gz <= 65535u && row_vecs < (1ll << 31);
+  return g;
 }
 
 // ------------------------------------------------------------------------------------ layernorm
 struct LnArgs { const void* x; const void* add; const float* g; const float* b; void* y; long long rows; int C, period; float eps; };
 
-template <typename T>
+template <typename T, int NIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
-  // one wave per row; two-pass mean / variance in f32 (row cached in registers, C <= 64*16)
+  // one wave per row; two-pass mean / variance in f32 (row cached in registers, C <= 64*NIT).  NIT is the number of
+  // 64-channel slices actually needed (2/4/8/12/16): the round-1 kernel always ran 16 predicated slices, i.e. 8x the
+  // instructions a C = 128 row needs (it was issue-bound on DaViT stages 0-1).  Same loads, same summation order.
   const int lane = threadIdx.x & 63;
   const long long row = (long long)blockIdx.x * 4 + (threadIdx.x >> 6);
   if (row >= a.rows) return;
   const T* x = (const T*)a.x + row * a.C;
   const T* ad = a.add ? (const T*)a.add + (row % a.period) * a.C : nullptr;
-  float v[16];
+  float v[NIT];
   float s = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     int c = lane + i * 64;
     float t = 0.0f;
     if (c < a.C) { t = ldf(x + c); if (ad) t += ldf(ad + c); }
@@ -109,17 +201,27 @@ __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
   float mean = wave_sum(s) / (float)a.C;
   float q = 0.0f;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     int c = lane + i * 64;
     if (c < a.C) { float d = v[i] - mean; q += d * d; }
   }
   float rstd = 1.0f / sqrtf(wave_sum(q) / (float)a.C + a.eps);
   T* y = (T*)a.y + row * a.C;
 #pragma unroll
-  for (int i = 0; i < 16; ++i) {
+  for (int i = 0; i < NIT; ++i) {
     int c = lane + i * 64;
     if (c < a.C) stf(y + c, (v[i] - mean) * rstd * a.g[c] + a.b[c]);
   }
+}
+
+template <typename T>
+void launch_layernorm_typed(const LnArgs& a, unsigned blocks, hipStream_t s) {
+  const int nit = (a.C + 63) / 64;
+  if (nit <= 2) hipLaunchKernelGGL((layernorm_kernel<T, 2>), dim3(blocks), dim3(256), 0, s, a);
+  else if (nit <= 4) hipLaunchKernelGGL((layernorm_kernel<T, 4>), dim3(blocks), dim3(256), 0, s, a);
+  else if (nit <= 8) hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, a);
+  else if (nit <= 12) hipLaunchKernelGGL((layernorm_kernel<T, 12>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((layernorm_kernel<T, 16>), dim3(blocks), dim3(256), 0, s, a);
 }
 
 // ------------------------------------------------------------------------------------ dwconv3 + layernorm fused
@@ -991,10 +1093,20 @@ int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
   OMNI_REQUIRE(a.C % (op->dtype == OMNI_F32 ? 4 : 8) == 0, "dwconv3: C must be a multiple of the 16-byte vector width");
   a.total = (long long)a.B * a.H * a.W * a.C;
-  long long blocks = (a.total / (op->dtype == OMNI_F32 ? 4 : 8) + 255) / 256; if (blocks > 65536) blocks = 65536;
-  int rc = by_dtype(op->dtype, "dwconv3",
-      [&] { hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); },
-      [&] { hipLaunchKernelGGL(dwconv3_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
+  const int V = op->dtype == OMNI_F32 ? 4 : 8;
+  const DwStripGrid g = dwconv3_strip_grid(a, V);
+  const char* e = getenv("OMNI_DWCONV_STRIP");
+  int rc;
+  if (g.ok && !(e && atoi(e) == 0)) {
+    rc = by_dtype(op->dtype, "dwconv3",
+        [&] { hipLaunchKernelGGL(dwconv3_strip_kernel<float>, dim3(g.gx, g.gy, g.gz), dim3(256), 0, s, a, g.cv_log2); },
+        [&] { hipLaunchKernelGGL(dwconv3_strip_kernel<half_t>, dim3(g.gx, g.gy, g.gz), dim3(256), 0, s, a, g.cv_log2); });
+  } else {
+    long long blocks = (a.total / V + 255) / 256; if (blocks > 65536) blocks = 65536;
+    rc = by_dtype(op->dtype, "dwconv3",
+        [&] { hipLaunchKernelGGL(dwconv3_kernel<float>, dim3((unsigned)blocks), dim3(256), 0, s, a); },
+        [&] { hipLaunchKernelGGL(dwconv3_kernel<half_t>, dim3((unsigned)blocks), dim3(256), 0, s, a); });
+  }
   if (rc) return rc;
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
@@ -1026,8 +1138,8 @@ int omni_launch_layernorm(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.x && a.g && a.b && a.y && a.rows > 0 && a.C > 0 && a.C <= 1024, "layernorm: bad arguments (C <= 1024)");
   unsigned blocks = (unsigned)((a.rows + 3) / 4);
   int rc = by_dtype(op->dtype, "layernorm",
-      [&] { hipLaunchKernelGGL(layernorm_kernel<float>, dim3(blocks), dim3(256), 0, s, a); },
-      [&] { hipLaunchKernelGGL(layernorm_kernel<half_t>, dim3(blocks), dim3(256), 0, s, a); });
+      [&] { launch_layernorm_typed<float>(a, blocks, s); },
+      [&] { launch_layernorm_typed<half_t>(a, blocks, s); });
   if (rc) return rc;
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
@@ -1204,4 +1316,37 @@ int omni_launch_misc(const omni_op_t* op, hipStream_t s) {
     case OMNI_OP_PROJ_PREP: case OMNI_OP_ASSEMBLE: case OMNI_OP_EMBED_STEP: return launch_glue(op, s);
     default: omni_set_error("misc: bad kind %d", op->kind); return OMNI_E_ARG;
   }
+}
+
+// ---------------------------------------------------------------------------------------------------------
+// Host emulation of kernels whose per-thread bodies are plain __host__ __device__ code (no LDS, no cross-lane ops):
+// the CPU test-suite runs the SAME source the GPU runs, block by block, on host pointers.  Test infrastructure
+// only — never reached from omni_op_launch / plans.   variant: 0 = round-1 point kernel, 1 = strip kernel.
+extern "C" int omni_debug_host_op(const omni_op_t* op, int variant) {
+  if (!op) { omni_set_error("debug_host_op: null op"); return OMNI_E_ARG; }
+  if (op->kind != OMNI_OP_DWCONV3) { omni_set_error("debug_host_op: kind %d has no host emulation", op->kind); return OMNI_E_ARG; }
+  DwArgs a;
+  a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
+  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
+  OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
+  OMNI_REQUIRE(op->dtype == OMNI_F32 || op->dtype == OMNI_F16, "dwconv3: bad dtype");
+  const int V = op->dtype == OMNI_F32 ? 4 : 8;
+  OMNI_REQUIRE(a.C % V == 0, "dwconv3: C must be a multiple of the 16-byte vector width");
+  a.total = (long long)a.B * a.H * a.W * a.C;
+  if (variant == 0) {
+    for (long long idx = 0; idx < a.total / V; ++idx) {
+      if (op->dtype == OMNI_F32) dwconv3_point_body<float>(a, idx); else dwconv3_point_body<half_t>(a, idx);
+    }
+    return OMNI_OK;
+  }
+  const DwStripGrid g = dwconv3_strip_grid(a, V);
+  OMNI_REQUIRE(g.ok, "dwconv3 strip kernel does not apply to C = %d", a.C);
+  for (unsigned bz = 0; bz < g.gz; ++bz)
+    for (unsigned by = 0; by < g.gy; ++by)
+      for (unsigned bx = 0; bx < g.gx; ++bx)
+        for (unsigned t = 0; t < 256; ++t) {
+          if (op->dtype == OMNI_F32) dwconv3_strip_body<float>(a, (int)bz, (int)by * DW_ROWS, bx * 256u + t, g.cv_log2);
+          else dwconv3_strip_body<half_t>(a, (int)bz, (int)by * DW_ROWS, bx * 256u + t, g.cv_log2);
+        }
+  return OMNI_OK;
 }

@@ -36,13 +36,13 @@ typedef uint32_t u32x4 __attribute__((ext_vector_type(4)));
 template <typename T> struct ElemTraits;
 template <> struct ElemTraits<float> {
   static constexpr int kVec = 4;   // elements per 16-byte vector
-  static __device__ __forceinline__ float to_f32(float v) { return v; }
-  static __device__ __forceinline__ float from_f32(float v) { return v; }
+  static __host__ __device__ __forceinline__ float to_f32(float v) { return v; }
+  static __host__ __device__ __forceinline__ float from_f32(float v) { return v; }
 };
 template <> struct ElemTraits<half_t> {
   static constexpr int kVec = 8;
-  static __device__ __forceinline__ float to_f32(half_t v) { return (float)v; }
-  static __device__ __forceinline__ half_t from_f32(float v) { return (half_t)v; }
+  static __host__ __device__ __forceinline__ float to_f32(half_t v) { return (float)v; }
+  static __host__ __device__ __forceinline__ half_t from_f32(float v) { return (half_t)v; }
 };
 
 // per-kind launchers (each lives in its own .hip file)
