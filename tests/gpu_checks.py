@@ -44,6 +44,9 @@ CONV_CASES = [
     (1, 20, 20, 1024, 1024, 1, 1, 1024, 0, 1024, 0, False, L.ACT_GELU), # small M, large K
     (1, 9, 9, 256, 1, 1, 1, 256, 0, 1, 0, False, L.ACT_NONE),            # Cout = 1 (class head)
     (3, 12, 12, 64, 64, 3, 1, 192, 64, 64, 0, True, L.ACT_NONE),
+    # >= 64 row blocks and > 1.25 MiB of weights: the N tiles are partitioned over XCD groups (xcd_n = 2 / 4), ragged M
+    (2, 50, 93, 512, 1024, 1, 1, 512, 0, 1024, 0, True, L.ACT_GELU),
+    (1, 95, 97, 128, 1024, 3, 1, 128, 0, 1024, 0, False, L.ACT_SILU),
 ]
 
 
@@ -88,6 +91,17 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
         assert (full[..., mask] == 7.0).all(), f"conv wrote outside its channel slice: {case}"
         tol = 2e-5 if dtype == L.F32 else 4e-3
         details.append((case, e))
+        if B * Ho * Wo >= 64 * 128 and Cout >= 256:       # tile order must not change a single bit
+            import os
+            ov2 = View(torch.full((B, Ho, Wo, old), 7.0, dtype=tdt, device=DEV), ooff, Cout)
+            pb2 = PlanBuilder(DEV, dtype)
+            pb2.conv(xv, pb2.pack_weight(w), b, ov2, k, s, act=act, res=rv)
+            os.environ["OMNI_XCD_NSPLIT"] = "0"
+            try:
+                L.launch(pb2.ops[0]); _sync()
+            finally:
+                os.environ.pop("OMNI_XCD_NSPLIT", None)
+            assert torch.equal(ov2.t.view(torch.uint8), ov.t.view(torch.uint8)), f"tile order changed the result: {case}"
         assert e < tol, f"conv case {case}: rel err {e:.3e} >= {tol}"
         worst = max(worst, e)
     return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), e) for c, e in details]}
@@ -506,6 +520,19 @@ def check_caption_ops(dtype=L.F32, seed=0):
     t = {"x": R(B, H, W, C).to(tdt), "w": (R(3, 3, C) * 0.3).to(tdt), "b": R(C), "y": torch.zeros(B, H, W, C, dtype=tdt)}
     c, gq = _op_pair(t, lambda P: L.make_op(L.OP_DWCONV3, dtype, p=[P("x"), P("w"), P("b"), None, P("y")], i={0: B, 1: H, 2: W, 3: C}))
     res["dwconv3"] = _cmp(gq["y"], c["y"], tol, "dwconv3")
+    # strip kernel (power-of-two vector counts: every DaViT stage) vs the CPU interpreter AND bitwise vs the point kernel
+    import os
+    for (B, H, W, C) in [(2, 9, 11, 128), (1, 6, 50, 64), (1, 5, 3, 1024), (3, 1, 9, 256), (1, 13, 1, 512)]:
+        t = {"x": R(B, H, W, C).to(tdt), "w": (R(3, 3, C) * 0.3).to(tdt), "b": R(C), "y": torch.zeros(B, H, W, C, dtype=tdt)}
+        mk = lambda P: L.make_op(L.OP_DWCONV3, dtype, p=[P("x"), P("w"), P("b"), None, P("y")], i={0: B, 1: H, 2: W, 3: C})
+        c, g_strip = _op_pair(t, mk)
+        res[f"dwconv3_strip{C}"] = _cmp(g_strip["y"], c["y"], tol, f"dwconv3 strip C={C}")
+        os.environ["OMNI_DWCONV_STRIP"] = "0"
+        try:
+            _, g_point = _op_pair(t, mk)
+        finally:
+            os.environ.pop("OMNI_DWCONV_STRIP", None)
+        assert torch.equal(g_strip["y"].view(torch.uint8), g_point["y"].view(torch.uint8)), f"dwconv3 strip != point kernel, C={C}"
     # fused dwconv3 + layernorm (C = 128 uses half a wave, C = 1024 all four vectors per lane)
     for Cc in (128, 512, 1024):
         Bq, Hq, Wq = 2, 7, 9
@@ -516,7 +543,7 @@ def check_caption_ops(dtype=L.F32, seed=0):
         res[f"dwconv3_ln{Cc}_y1"] = _cmp(gq["y1"], c["y1"], tol, f"dwconv3_ln y1 C={Cc}")
         res[f"dwconv3_ln{Cc}_h"] = _cmp(gq["h"], c["h"], tol * 5, f"dwconv3_ln h C={Cc}")
     # layernorm (+ add table), several widths
-    for Cc in (128, 768, 1024):
+    for Cc in (128, 256, 512, 768, 1024):
         rows, period = 24, 6
         t = {"x": R(rows, Cc).to(tdt) * 3 + 1, "add": R(period, Cc).to(tdt), "g": R(Cc), "b": R(Cc), "y": torch.zeros(rows, Cc, dtype=tdt)}
         c, gq = _op_pair(t, lambda P: L.make_op(L.OP_LAYERNORM, dtype, p=[P("x"), P("add"), P("g"), P("b"), P("y")],

@@ -23,6 +23,7 @@ step "bench e2e, round-1 order" env OMNI_XCD_NSPLIT=0 timeout 300 python bench.p
 cp "$OUT/log.txt" "$OUT/log_after_bench0.txt"
 step "bench e2e, N partition (default)" timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
 step "bench e2e, N partition + 256x128 tile" env OMNI_SPLIT_VARIANT=4 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+step "bench e2e, default but round-1 dwconv kernel" env OMNI_DWCONV_STRIP=0 timeout 300 python bench.py --steps 3 --warmup 1 --no-cpu-baseline
 
 # 4. PMC evidence for the dominant kernel (separate passes, counters only: no sys/hip trace domains with --pmc)
 for ctr in "FETCH_SIZE" "WRITE_SIZE" "SQ_VALU_MFMA_BUSY_CYCLES SQ_BUSY_CYCLES" "SQ_WAIT_INST_LDS SQ_WAIT_ANY SQ_WAVE_CYCLES" "TCC_HIT_sum TCC_MISS_sum"; do
