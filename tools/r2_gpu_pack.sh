@@ -37,5 +37,6 @@ step "pmc FETCH_SIZE, round-1 order" env OMNI_XCD_NSPLIT=0 timeout 420 rocprofv3
 # 5. kernel-time summary of the default configuration
 step "kernel stats" timeout 420 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- \
   python bench.py --steps 3 --warmup 1 --no-cpu-baseline
+step "stream bench (configs[3] stand-in, 1 GPU, 64x64 crops)" timeout 420 python tools/stream_bench.py --items 48 --caption-res 64
 find "$OUT" -name "*.csv" -size +8M -delete      # merged-back budget is 64 MiB: keep summaries, drop raw traces
 ls -la "$OUT" | tee -a "$OUT/log.txt"
