@@ -29,9 +29,11 @@ class ScreenParser:
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
-    def detect(self, frames: Sequence[torch.Tensor]):
+    def detect(self, frames: Sequence[torch.Tensor], pad_to: Optional[int] = None):
+        """`pad_to`: run the plan of that batch size even for fewer frames (the unused slots keep whatever they held
+        and their results are ignored) — streams with ragged batches then need ONE plan per resolution."""
         ih, iw = frames[0].shape[:2]
-        dp = self.det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=len(frames))
+        dp = self.det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
         with torch.cuda.stream(self.det.stream):
             for bi, f in enumerate(frames):
                 dp.img[bi].copy_(f, non_blocking=True)
@@ -171,17 +173,19 @@ class ScreenParser:
         return out
 
     @torch.inference_mode()
-    def parse_batch(self, frames: Sequence[torch.Tensor], ocr: Optional[Sequence] = None, return_ids=False):
-        """frames: uint8 [H,W,3] device tensors (same size); ocr: per frame (texts, xyxy px boxes) or None."""
+    def parse_batch(self, frames: Sequence[torch.Tensor], ocr: Optional[Sequence] = None, return_ids=False,
+                    pad_to: Optional[int] = None):
+        """frames: uint8 [H,W,3] device tensors (same size); ocr: per frame (texts, xyxy px boxes) or None;
+        pad_to: detector plan batch size to use when fewer frames arrive (see `detect`)."""
         ih, iw = frames[0].shape[:2]
         with self.det._lock, self.cap._lock:
-            return self._parse_batch_locked(frames, ocr, return_ids, iw, ih)
+            return self._parse_batch_locked(frames, ocr, return_ids, iw, ih, pad_to)
 
-    def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih):
+    def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih, pad_to=None):
         if self.tile_large and (iw > 1952 or ih > 1112):
             det_boxes = [self.detect_tiled(f)[0] for f in frames]      # >1080p: overlapping tiles + global NMS (our policy)
         else:
-            det_boxes = self.detect(frames)
+            det_boxes = self.detect(frames, pad_to)
         elems_all, crops_all = [], []
         for fi, xy in enumerate(det_boxes):
             texts, boxes = ocr[fi] if ocr is not None else ([], [])

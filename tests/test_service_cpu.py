@@ -54,7 +54,7 @@ class _Proc:
 class _Screen(ScreenParser):
     """Real glue + real batch bookkeeping; device stages replaced by the same stubs the single-image path uses."""
     calls = 0
-    def detect(self, frames):
+    def detect(self, frames, pad_to=None):
         type(self).calls += 1
         return [_boxes_for(f.numpy()) for f in frames]
     def caption(self, frames, crops_per_frame, max_new_tokens=20):
