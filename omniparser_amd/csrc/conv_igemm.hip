@@ -46,7 +46,7 @@ struct ConvArgs {
 //     activation tile is fetched once per row block and re-used from L2 by its N-tile neighbours;
 //   * xcd_n  > 1: the N tiles are additionally partitioned over xcd_n XCD groups (XCD x serves N partition x % xcd_n
 //     and row blocks = x / xcd_n (mod 8 / xcd_n)).  Each XCD then touches only ntiles/xcd_n weight panels — chosen so
-//     that slab (<= ~1.25 MiB) stays resident in its L2 while activations stream through — instead of the whole weight
+//     that slab (<= 2 MiB) stays resident in its L2 while activations stream through — instead of the whole weight
 //     matrix being re-fetched from Infinity Cache / HBM by every row block (measured in round 1: weight re-fetch was
 //     ~75 % of this kernel's L2-miss traffic, profiles/r1_gemm_traffic_model.md).
 // Pure index permutation: every (mt, nt) is produced exactly once for bid in [0, omni_tile_grid), results are
@@ -77,7 +77,7 @@ __host__ inline int choose_xcd_n(int ntiles, long long weight_bytes) {
   // read per launch (like the other tuning knobs) so one process can A/B the orders; captured graphs keep theirs
   const char* e = getenv("OMNI_XCD_NSPLIT");
   const bool enabled = !(e && atoi(e) == 0);
-  long long budget = 5ll << 18;                  // 1.25 MiB of the 4 MiB L2 (OMNI_XCD_L2_BUDGET_KB overrides: tuning knob)
+  long long budget = 2ll << 20;                  // half of the 4 MiB L2 (tools/l2_sim.py; OMNI_XCD_L2_BUDGET_KB overrides)
   if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
   if (!enabled || weight_bytes <= budget) return 1;
   for (int xn = 2; xn <= 8; xn *= 2)

@@ -44,9 +44,9 @@ CONV_CASES = [
     (1, 20, 20, 1024, 1024, 1, 1, 1024, 0, 1024, 0, False, L.ACT_GELU), # small M, large K
     (1, 9, 9, 256, 1, 1, 1, 256, 0, 1, 0, False, L.ACT_NONE),            # Cout = 1 (class head)
     (3, 12, 12, 64, 64, 3, 1, 192, 64, 64, 0, True, L.ACT_NONE),
-    # >= 64 row blocks and > 1.25 MiB of weights: the N tiles are partitioned over XCD groups (xcd_n = 2 / 4), ragged M
-    (2, 50, 93, 512, 1024, 1, 1, 512, 0, 1024, 0, True, L.ACT_GELU),
-    (1, 95, 97, 128, 1024, 3, 1, 128, 0, 1024, 0, False, L.ACT_SILU),
+    # >= 64 row blocks and > 2 MiB of weights: the N tiles are partitioned over XCD groups (xcd_n = 2 / 4), ragged M
+    (2, 50, 93, 1024, 1024, 1, 1, 1024, 0, 1024, 0, True, L.ACT_GELU),      # 4 MiB -> 2 groups
+    (1, 95, 97, 64, 2048, 3, 1, 64, 0, 2048, 0, False, L.ACT_SILU),         # 4.5 MiB, 16 N tiles -> 4 groups
 ]
 
 

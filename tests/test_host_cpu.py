@@ -131,7 +131,7 @@ def test_gemm_tile_permutation_is_a_bijection():
     walks the N tiles of a row block in consecutive slots; xcd_n == 1 reproduces the round-1 row-block mapping."""
     from omniparser_amd import _lib as L
     cases = [(2304, 16, -1, 4 * 2048 * 512), (2304, 12, -1, 4 * 1536 * 512), (2304, 4, -1, 4 * 512 * 2048), (585, 24, -1, 4 * 3072 * 768),
-             (585, 6, -1, 4 * 768 * 3072), (577, 8, 8, -1), (64, 2, 2, -1), (67, 8, 4, -1), (1000, 3, 1, -1), (63, 5, 1, -1), (400, 4, -1, 4 * 512 * 4608),
+             (585, 6, -1, 4 * 768 * 3072), (577, 8, 8, -1), (64, 2, 2, -1), (67, 8, 4, -1), (2304, 16, 4, -1), (1000, 3, 1, -1), (63, 5, 1, -1), (400, 4, -1, 4 * 512 * 4608),
              (2304, 4, -1, 4 * 512 * 512), (100, 1, 1, -1)]
     for mtiles, ntiles, xn, wbytes in cases:
         _, _, grid, used = L.tile_map(mtiles, ntiles, 0, xcd_n=max(xn, 1), weight_bytes=wbytes)
@@ -139,9 +139,9 @@ def test_gemm_tile_permutation_is_a_bijection():
         if wbytes >= 0 and xcd_order:
             slab = wbytes / used
             assert used in (1, 2, 4, 8) and ntiles % used == 0
-            assert used == 1 or slab <= 1.25 * 2 ** 20            # a partition is only chosen when its slab fits
-            if used == 1 and wbytes > 1.25 * 2 ** 20:
-                assert all(ntiles % k or wbytes / k > 1.25 * 2 ** 20 for k in (2, 4, 8))
+            assert used == 1 or slab <= 2.0 * 2 ** 20            # a partition is only chosen when its slab fits
+            if used == 1 and wbytes > 2.0 * 2 ** 20:
+                assert all(ntiles % k or wbytes / k > 2.0 * 2 ** 20 for k in (2, 4, 8))
         seen = {}
         per_xcd = [[] for _ in range(8)]
         for bid in range(grid):
@@ -169,7 +169,7 @@ def test_gemm_tile_permutation_is_a_bijection():
         if used == 1:                                              # round-1 formula
             for (mt, nt), bid in list(seen.items())[:200]:
                 assert mt == ((bid >> 3) // ntiles) * 8 + (bid & 7) and nt == (bid >> 3) % ntiles
-    assert L.tile_map(2304, 16, 0, weight_bytes=4 * 2048 * 512)[3] == 4        # DaViT stage-2 fc1: 4 MiB of weights -> 4 groups
+    assert L.tile_map(2304, 16, 0, weight_bytes=4 * 2048 * 512)[3] == 2        # DaViT stage-2 fc1: 4 MiB of weights -> 2 groups of 2 MiB
     assert L.tile_map(2304, 4, 0, weight_bytes=4 * 512 * 512)[3] == 1          # 1 MiB: already resident
 
 

@@ -19,7 +19,7 @@ sys.path.insert(0, str(ROOT))
 os.environ.setdefault("OMNI_CONV_SPLIT", "0")
 
 
-def choose_xn(ntiles: int, n: int, k: int, slab_limit=1.25 * 2 ** 20) -> int:
+def choose_xn(ntiles: int, n: int, k: int, slab_limit=2.0 * 2 ** 20) -> int:
     """Mirror of conv_igemm.hip::choose_xcd_n: number of XCD groups along N (1 = row-block mapping)."""
     w_total = 4.0 * n * k
     if w_total <= slab_limit:
@@ -88,13 +88,13 @@ def main():
         a, w, y = total(big, **kw)
         L_.append(f"| {name} | {a:.2f} | {w:.2f} | {y:.2f} | {a + w + y:.2f} |")
     def xcd_model(r, partition):
-        """row-block mapping: A once, W per row block unless the whole matrix (<= 1.25 MiB) is L2-resident;
+        """row-block mapping: A once, W per row block unless the whole matrix (<= 2 MiB) is L2-resident;
         N partition: A once per XCD group, W once per XCD when its slab is resident."""
         A, W = 4 * r["M"] * r["K"], 4 * r["N"] * r["K"]
         xn = choose_xn(r["nt"], r["N"], r["K"]) if partition else 1
-        resident = W / xn <= 1.25 * 2 ** 20
+        resident = W / xn <= 2.0 * 2 ** 20
         return A * xn, (W * 8 / xn if resident else W * r["mt"]), 4 * r["M"] * r["N"] * (2 if r["res"] else 1)
-    for name, part in (("L2 model, round-1 mapping (A shared in L2, W resident only if <= 1.25 MiB)", False),
+    for name, part in (("L2 model, round-1 mapping (A shared in L2, W resident only if <= 2 MiB)", False),
                        ("L2 model, N partition over XCD groups (default from now on)", True)):
         t = [sum(xcd_model(r, part)[k] for r in big) / MB / 1e9 for k in range(3)]
         L_.append(f"| {name} | {t[0]:.2f} | {t[1]:.2f} | {t[2]:.2f} | {sum(t):.2f} |")
