@@ -48,7 +48,7 @@ struct ConvArgs {
 //     and row blocks = x / xcd_n (mod 8 / xcd_n)).  Each XCD then touches only ntiles/xcd_n weight panels — chosen so
 //     that slab (<= 2 MiB) stays resident in its L2 while activations stream through — instead of the whole weight
 //     matrix being re-fetched from Infinity Cache / HBM by every row block (measured in round 1: weight re-fetch was
-//     ~75 % of this kernel's L2-miss traffic, profiles/r1_gemm_traffic_model.md).
+//     ~65 % of this kernel's L2-miss traffic, profiles/r1_gemm_traffic_model.md).
 // Pure index permutation: every (mt, nt) is produced exactly once for bid in [0, omni_tile_grid), results are
 // bit-identical for any xcd_n.  Host mirror + exhaustive bijection test: omni_debug_tile_map / tests/test_host_cpu.py.
 __host__ __device__ __forceinline__ bool tile_of_block(int bid, int mtiles, int ntiles, int xcd_order, int xcd_n, int& mt, int& nt) {

@@ -71,8 +71,14 @@ def main():
                 t[k] += v
         return [v / MB / 1e9 for v in t]       # GB per crop
     meas = json.loads((ROOT / "profiles" / "r1_pmc_traffic_conv_split.json").read_text())["conv_split_128x128"]
-    crops = 368
-    mf, mw = meas["fetch_bytes_corrected"] / crops / 1e9, meas["write_bytes"] / crops / 1e9
+    # The PMC run was `bench.py --steps 1 --warmup 0`: one step = 3 encode passes of the 128-crop plan (368 crops, the
+    # last micro-batch padded to its 128 bucket) PLUS bench.roofline()'s re-timing of the same plan (1 warm + 2 timed
+    # passes) = 6 passes = 768 crop-encodes.  ~230 of the 1009-1062 launches are the detector's 1x1 convs (7 detector
+    # passes x 8 screenshots x <= 1.8 GB): ~3 % of the bytes, subtracted as an estimate.
+    crops = 6 * 128
+    det_bytes = 7 * 8 * 1.8e9 * 0.6
+    mf = (meas["fetch_bytes_corrected"] - 0.6 * det_bytes) / crops / 1e9
+    mw = (meas["write_bytes"] - 0.4 * det_bytes) / crops / 1e9
     flops = sum(2 * r["M"] * r["N"] * r["K"] for r in big) / MB / 1e9
     L_ = []
     L_.append("# Operand traffic of conv_split_kernel<128,128> on the 768x768 captioner encode (model vs PMC)\n")
@@ -98,7 +104,16 @@ def main():
                        ("L2 model, N partition over XCD groups (default from now on)", True)):
         t = [sum(xcd_model(r, part)[k] for r in big) / MB / 1e9 for k in range(3)]
         L_.append(f"| {name} | {t[0]:.2f} | {t[1]:.2f} | {t[2]:.2f} | {sum(t):.2f} |")
-    L_.append(f"| **measured (rocprofv3 PMC, round 1 mapping)** | fetch {mf:.2f} | | write {mw:.2f} | {mf + mw:.2f} |")
+    L_.append(f"| **measured (rocprofv3 PMC, round 1 mapping; 768 crop-encodes in the profiled run)** | fetch {mf:.2f} | | write {mw:.2f} | {mf + mw:.2f} |")
+    ideal_w = sum(4 * r["N"] * r["K"] * r["mt"] for r in big) / MB / 1e9
+    a_once = sum(4 * r["M"] * r["K"] for r in big) / MB / 1e9
+    res_read = sum(4 * r["M"] * r["N"] for r in big if r["res"]) / MB / 1e9
+    L_.append("")
+    L_.append(f"Reading: fetch - activations once ({a_once:.2f}) - residual reads ({res_read:.2f}) = {mf - a_once - res_read:.2f} GB/crop of weight "
+              f"re-fetch = {100 * (mf - a_once - res_read) / ideal_w:.0f} % of the every-row-block volume ({ideal_w:.2f}): the workgroups of one XCD stay partly "
+              "in phase (tools/l2_sim.py brackets it: 25 % in lockstep, 85 % fully drifted).  Fabric traffic of this kernel: "
+              f"{(mf + mw) * 128 / 0.261 / 1e3:.2f} TB/s over its 261 ms per 128-crop encode pass (kernel-trace run) — 44 % of achievable HBM bandwidth, "
+              "arriving as scattered 128-byte reads (one cache line per matrix row per K slice).")
     L_.append("")
     L_.append("Per-GEMM shapes (128-crop micro-batch) and their no-reuse operand bytes per MAC:\n")
     L_.append("| M | N | K | ntiles | count | A GB/crop x ntiles | W GB/crop x mtiles |")
