@@ -758,18 +758,23 @@ __global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4; NOT the default): the same staging / MFMA scheme as
-// conv_split_kernel with a WM x WN wave grid, so a 256x128 block tile (4 x 2 waves, 64x64 per wave: 0.67 LDS reads
-// per MFMA instead of 1.0, 25 % fewer operand bytes per MFMA from L2) can be measured against the default.
-// Static resources (tools/isa_report.py): 201-212 registers, no scratch, 108 KB LDS -> one 8-wave block per CU.
+// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4|5; NOT the default): the same staging / MFMA scheme as
+// conv_split_kernel with a WM x WN wave grid and a selectable K-slice width, so that two hypotheses can be measured:
+//   4: 256x128 block tile (4 x 2 waves, 64x64 per wave: 0.67 LDS reads per MFMA instead of 1.0, 25 % fewer operand
+//      bytes per MFMA from L2); 201-212 registers, no scratch, 108 KB LDS -> one 8-wave block per CU;
+//   5: 128x128 tile with 64-wide K slices: every matrix row contributes 256 contiguous bytes per request round instead
+//      of one 128-byte line (the round-1 operand stream is scattered single lines), half the barriers;
+//      169 registers, no scratch, 136 KB LDS -> one block per CU.
 // Dropped on paper: 256x256 (two f32 accumulator sets = 256 VGPRs, spills) and an "A-deep" pipeline with activation
 // loads two K slices ahead (needs > 128 registers at 4 waves/SIMD: 420 B of scratch; at 2 waves/SIMD it is the
 // measured-slower variant 1).
-template <int BM, int BN, int WM, int WN, bool PW, int MINB>
+template <int BM, int BN, int WM, int WN, bool PW, int MINB, int RB = 128>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;
-  constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
-  constexpr int BKE = 32;
+  // RB = bytes of K per LDS row and slice: 128 (32 f32 k, two 16-k blocks) or 256 (64 k: twice the contiguous bytes per
+  // matrix row and memory request round, half the barriers; 136 KB of LDS -> one block per CU)
+  constexpr int ROWB = RB + 16, VPR = RB / 16, RPP = NW * 64 / VPR;
+  constexpr int BKE = RB / 4, KB16 = RB / 64;
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
   constexpr int STAGE = (BM + BN) * ROWB;
@@ -878,7 +883,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
   auto compute = [&](int stage) {
     const unsigned char* st = lds + stage * STAGE;
 #pragma unroll
-    for (int j16 = 0; j16 < 2; ++j16) {
+    for (int j16 = 0; j16 < KB16; ++j16) {
       f16x8 ah[TM], al[TM], bh[TN], bl[TN];
 #pragma unroll
       for (int i = 0; i < TM; ++i) {
@@ -958,7 +963,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MINB>
+template <int BM, int BN, int WM, int WN, int MINB, int RB = 128>
 void launch_split2(ConvArgs& a, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
@@ -966,8 +971,8 @@ void launch_split2(ConvArgs& a, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
   const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
-  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB>), grid, dim3(WM * WN * 64), 0, s, a);
-  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB>), grid, dim3(WM * WN * 64), 0, s, a);
+  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB, RB>), grid, dim3(WM * WN * 64), 0, s, a);
+  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB, RB>), grid, dim3(WM * WN * 64), 0, s, a);
   if (a.splits > 1) {
     long long total = (long long)a.M * a.Cout;
     hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
@@ -1039,10 +1044,19 @@ void launch_split(ConvArgs& a, hipStream_t s) {
     if (bm == 128 && !strcmp(e, "128x64")) bn = 64;
     if (bm == 128 && !strcmp(e, "128x128") && a.Cout > 64) bn = 128;
   }
-  // opt-in experiment variant 4 (conv_split2_kernel, 256x128 tile); default stays variant 2
+  // opt-in experiment variants (conv_split2_kernel); default stays variant 2
+  //   4 = 256x128 tile, 8 waves 4x2        5 = 128x128 tile, 8 waves 2x4, 64-wide K slices (256 contiguous bytes per row)
   if (const char* e = getenv("OMNI_SPLIT_VARIANT")) {
-    if (atoi(e) == 4 && bm == 128 && bn == 128 && a.splits == 1 && blocks(256, 128) >= 256) {
+    const int v = atoi(e);
+    if (v == 4 && bm == 128 && bn == 128 && a.splits == 1 && blocks(256, 128) >= 256) {
       launch_split2<256, 128, 4, 2, 2>(a, s);
+      return;
+    }
+    if (v == 5 && bm == 128 && bn == 128 && a.splits == 1 && a.Cin % 64 == 0) {
+      a.cin_tiles = a.Cin / 64;
+      a.ktiles = a.K / 64;
+      a.kt_per_split = a.ktiles;
+      launch_split2<128, 128, 2, 4, 2, 256>(a, s);
       return;
     }
   }
