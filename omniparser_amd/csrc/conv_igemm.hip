@@ -758,17 +758,19 @@ __global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
 }
 
 // ---------------------------------------------------------------------------------------------------------
-// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4|5; NOT the default): the same staging / MFMA scheme as
+// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4|5|6; NOT the default): the same staging / MFMA scheme as
 // conv_split_kernel with a WM x WN wave grid and a selectable K-slice width, so that two hypotheses can be measured:
 //   4: 256x128 block tile (4 x 2 waves, 64x64 per wave: 0.67 LDS reads per MFMA instead of 1.0, 25 % fewer operand
 //      bytes per MFMA from L2); 201-212 registers, no scratch, 108 KB LDS -> one 8-wave block per CU;
 //   5: 128x128 tile with 64-wide K slices: every matrix row contributes 256 contiguous bytes per request round instead
 //      of one 128-byte line (the round-1 operand stream is scattered single lines), half the barriers;
-//      169 registers, no scratch, 136 KB LDS -> one block per CU.
+//      169 registers, no scratch, 136 KB LDS -> one block per CU;
+//   6: the default tile with the weight slices staged by LDS-DMA (no staging registers, no ds_write_b128): 112-120
+//      registers, 68 KB LDS, still two blocks per CU (layout checked symbolically: tests/test_split_kernel_layout_cpu.py).
 // Dropped on paper: 256x256 (two f32 accumulator sets = 256 VGPRs, spills) and an "A-deep" pipeline with activation
 // loads two K slices ahead (needs > 128 registers at 4 waves/SIMD: 420 B of scratch; at 2 waves/SIMD it is the
 // measured-slower variant 1).
-template <int BM, int BN, int WM, int WN, bool PW, int MINB, int RB = 128>
+template <int BM, int BN, int WM, int WN, bool PW, int MINB, int RB = 128, bool BDMA = false>
 __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArgs a) {
   constexpr int NW = WM * WN;
   // RB = bytes of K per LDS row and slice: 128 (32 f32 k, two 16-k blocks) or 256 (64 k: twice the contiguous bytes per
@@ -777,7 +779,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
   constexpr int BKE = RB / 4, KB16 = RB / 64;
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-  constexpr int STAGE = (BM + BN) * ROWB;
+  // BDMA: the (pre-split) weight slice goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers
+  // and no ds_write.  A DMA instruction writes wave-uniform base + lane*16, so the weight rows are UNPADDED (RB bytes)
+  // and bank conflicts are avoided by an XOR swizzle instead: LDS slot s of row r holds source chunk s ^ ((r >> 1) & 7)
+  // (applied to the per-lane SOURCE address here and to the fragment read address below — same involution).
+  constexpr int ROWB_B = BDMA ? RB : ROWB;
+  constexpr int STAGE = BM * ROWB + BN * ROWB_B;
+  static_assert(!BDMA || RB == 128, "the swizzle below is written for 8 chunks per row");
   static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile / wave grid mismatch");
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
 
@@ -817,7 +825,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
   for (int it = 0; it < B_IT; ++it) {
     int n = n0 + r0 + it * RPP;
     b_ok[it] = n < a.Cout;
-    b_ptr[it] = Wb + (long long)(b_ok[it] ? n : 0) * a.K * 4 + vec * 16;
+    b_ptr[it] = Wb + (long long)(b_ok[it] ? n : 0) * a.K * 4 + (BDMA ? ((vec ^ ((r0 >> 1) & 7)) * 16) : vec * 16);
   }
   int w_r = 0, w_s = 0, w_c = 0;
   if (!PW) {
@@ -847,18 +855,29 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
       }
     }
   };
-  auto load_b = [&](int kt) {
+  auto load_b = [&](int kt, int stage) {
+    if constexpr (BDMA) {
+      // rows r0 = wave*8 + lane/8, slot vec = lane%8: the wave's 64 lanes fill 8 consecutive 128-byte rows = 1 KiB
+      unsigned char* dstw = lds + stage * STAGE + BM * ROWB + (wave * 8) * RB;
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + (long long)kt * RB) : zero4;
+      for (int it = 0; it < B_IT; ++it)
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + (long long)kt * RB),
+                                         (__attribute__((address_space(3))) void*)(dstw + it * RPP * RB), 16, 0, 0);
+    } else {
+#pragma unroll
+      for (int it = 0; it < B_IT; ++it)
+        rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + (long long)kt * RB) : zero4;
+    }
   };
   const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
   auto store_tile = [&](int stage, const u32x4* ra) {
     unsigned char* sA = lds + stage * STAGE;
     unsigned char* sB = sA + BM * ROWB;
+    if constexpr (!BDMA) {
 #pragma unroll
-    for (int it = 0; it < B_IT; ++it)
-      *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
+      for (int it = 0; it < B_IT; ++it)
+        *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
+    }
 #pragma unroll
     for (int it = 0; it < A_IT; ++it) {
       uint2 hi, lo;
@@ -878,7 +897,8 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
       for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
 
   const int a_rd = (wm * (BM / WM) + (lane & 31)) * ROWB + (lane >> 5) * 16;
-  const int b_rd = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB + (lane >> 5) * 16;
+  const int b_rd = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB_B + (BDMA ? 0 : (lane >> 5) * 16);
+  const int b_swz = (lane >> 1) & 7;             // (row >> 1) & 7 of this lane's weight rows (row = 32*j + lane%32 + const*32)
 
   auto compute = [&](int stage) {
     const unsigned char* st = lds + stage * STAGE;
@@ -892,8 +912,13 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
       }
 #pragma unroll
       for (int j = 0; j < TN; ++j) {
-        bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64);
-        bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64 + 32);
+        if constexpr (BDMA) {
+          bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB_B + (((j16 * 4 + (lane >> 5)) ^ b_swz) * 16));
+          bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB_B + (((j16 * 4 + 2 + (lane >> 5)) ^ b_swz) * 16));
+        } else {
+          bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64);
+          bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64 + 32);
+        }
       }
 #pragma unroll
       for (int i = 0; i < TM; ++i)
@@ -906,12 +931,12 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
     }
   };
 
-  if (kt0 < kt1) { load_b(kt0); load_a(kt0, ra0); store_tile(0, ra0); }
+  if (kt0 < kt1) { load_b(kt0, 0); load_a(kt0, ra0); store_tile(0, ra0); }
   __syncthreads();
   int cur = 0;
   for (int kt = kt0; kt < kt1; ++kt) {
     const bool more = kt + 1 < kt1;
-    if (more) { load_b(kt + 1); load_a(kt + 1, ra0); }
+    if (more) { load_b(kt + 1, cur ^ 1); load_a(kt + 1, ra0); }
     compute(cur);
     if (more) store_tile(cur ^ 1, ra0);
     __syncthreads();
@@ -963,7 +988,7 @@ __global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArg
   }
 }
 
-template <int BM, int BN, int WM, int WN, int MINB, int RB = 128>
+template <int BM, int BN, int WM, int WN, int MINB, int RB = 128, bool BDMA = false>
 void launch_split2(ConvArgs& a, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = (a.Cout + BN - 1) / BN;
@@ -971,8 +996,8 @@ void launch_split2(ConvArgs& a, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
   const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
-  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB, RB>), grid, dim3(WM * WN * 64), 0, s, a);
-  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB, RB>), grid, dim3(WM * WN * 64), 0, s, a);
+  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB, RB, BDMA>), grid, dim3(WM * WN * 64), 0, s, a);
+  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB, RB, BDMA>), grid, dim3(WM * WN * 64), 0, s, a);
   if (a.splits > 1) {
     long long total = (long long)a.M * a.Cout;
     hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
@@ -1046,6 +1071,7 @@ void launch_split(ConvArgs& a, hipStream_t s) {
   }
   // opt-in experiment variants (conv_split2_kernel); default stays variant 2
   //   4 = 256x128 tile, 8 waves 4x2        5 = 128x128 tile, 8 waves 2x4, 64-wide K slices (256 contiguous bytes per row)
+  //   6 = 128x128 tile, 8 waves 2x4, weight slices by LDS-DMA (global_load_lds) into an XOR-swizzled unpadded layout
   if (const char* e = getenv("OMNI_SPLIT_VARIANT")) {
     const int v = atoi(e);
     if (v == 4 && bm == 128 && bn == 128 && a.splits == 1 && blocks(256, 128) >= 256) {
@@ -1057,6 +1083,10 @@ void launch_split(ConvArgs& a, hipStream_t s) {
       a.ktiles = a.K / 64;
       a.kt_per_split = a.ktiles;
       launch_split2<128, 128, 2, 4, 2, 256>(a, s);
+      return;
+    }
+    if (v == 6 && bm == 128 && bn == 128 && a.splits == 1) {        // default tile, weights by LDS-DMA + XOR swizzle
+      launch_split2<128, 128, 2, 4, 4, 128, true>(a, s);
       return;
     }
   }

@@ -89,3 +89,41 @@ def test_epilogue_covers_the_tile_once_and_reads_are_bank_conflict_free(BM, BN, 
             addr = (lane & 31) * ROWB + (lane >> 5) * 16
             banks += [((addr // 4) + d) % 64 for d in range(4)]
         assert len(set(banks)) == 64, (RB, sorted(banks))
+
+
+def test_lds_dma_weight_layout_variant6():
+    """conv_split2_kernel<..., BDMA = true> (OMNI_SPLIT_VARIANT=6): weight slices arrive by global_load_lds_dwordx4,
+    whose LDS destination is wave-uniform base + lane*16 — rows are unpadded (128 B) and an XOR swizzle on the per-lane
+    SOURCE chunk, undone by the same XOR on the fragment read address, keeps ds_read_b128 conflict-free."""
+    BM, BN, WM, WN, RB = 128, 128, 2, 4, 128
+    NW, VPR = WM * WN, 8
+    RPP, B_IT = NW * 8, BN // (NW * 8)
+    lds = np.full((BN * RB // 2, 3), -1, dtype=np.int64)              # weight region only: (row, k, part) per f16 slot
+    for wave, lane, it in itertools.product(range(NW), range(64), range(B_IT)):
+        tid = wave * 64 + lane
+        vec, r0 = tid % VPR, tid // VPR
+        row = r0 + it * RPP                                            # global weight row of this lane
+        chunk = vec ^ ((r0 >> 1) & 7)                                  # source chunk (16 B) of the 128-byte slice
+        dst = (it * RPP + wave * 8) * RB + lane * 16                   # hardware: M0 base + lane * 16
+        for h in range(8):
+            byte = chunk * 16 + h * 2                                  # within [16 hi | 16 lo] x 2 blocks
+            blk, inb = byte // 64, byte % 64
+            lds[dst // 2 + h] = (row, blk * 16 + (inb % 32) // 2, inb // 32)
+    assert (lds[:, 0] >= 0).all()                                      # the 16 DMA instructions fill the region exactly
+    TN = BN // (32 * WN)
+    for wave, lane in itertools.product(range(NW), range(64)):
+        wn = wave % WN
+        swz = (lane >> 1) & 7
+        for j, j16, part in itertools.product(range(TN), range(2), range(2)):
+            R = wn * (BN // WN) + j * 32 + (lane & 31)
+            addr = R * RB + (((j16 * 4 + part * 2 + (lane >> 5)) ^ swz) * 16)
+            got = lds[addr // 2:][:8].tolist()
+            assert got == [[R, j16 * 16 + (lane >> 5) * 8 + h, part] for h in range(8)], (wave, lane, j16, part)
+    groups = [[0, 1, 2, 3, 12, 13, 14, 15, 20, 21, 22, 23, 24, 25, 26, 27], [4, 5, 6, 7, 8, 9, 10, 11, 16, 17, 18, 19, 28, 29, 30, 31]]
+    groups += [[l + 32 for l in g] for g in groups]
+    for g, c in itertools.product(groups, range(4)):                    # c = j16*2 + part: the chunk pair a read touches
+        banks = []
+        for lane in g:
+            addr = (lane & 31) * RB + (((c // 2 * 4 + c % 2 * 2 + (lane >> 5)) ^ ((lane >> 1) & 7)) * 16)
+            banks += [((addr // 4) + d) % 64 for d in range(4)]
+        assert len(set(banks)) == 64, sorted(banks)

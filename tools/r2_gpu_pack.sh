@@ -15,7 +15,7 @@ step() { echo "=== $1" | tee -a "$OUT/log.txt"; shift; ( "$@" ) >>"$OUT/log.txt"
 step "pytest gpu kernels+caption (new tile order)" timeout 600 python -m pytest tests -m gpu -x -q
 
 # 2. GEMM micro-benchmark A/B: tile order, residency budget, 256x128 tile
-step "gemm_bench A/B" env VARIANTS="split:128x128:2+OMNI_XCD_NSPLIT=0,split:128x128:2,split:128x128:2+OMNI_XCD_L2_BUDGET_KB=1280,split:128x128:4,split:128x128:4+OMNI_XCD_NSPLIT=0,split:128x128:5" \
+step "gemm_bench A/B" env VARIANTS="split:128x128:2+OMNI_XCD_NSPLIT=0,split:128x128:2,split:128x128:2+OMNI_XCD_L2_BUDGET_KB=1280,split:128x128:4,split:128x128:4+OMNI_XCD_NSPLIT=0,split:128x128:5,split:128x128:6" \
   timeout 300 python tools/gemm_bench.py
 
 # 3. headline A/B (same process settings except the knob)
