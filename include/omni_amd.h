@@ -67,7 +67,12 @@ enum {
    *  i12 Cout i13 ldo i14 out_coff i15 act i16 ldr i17 res_coff
    *  p5 optional split-K workspace (f32), i19 its size in KiB   f0 output scale (0 => 1)
    *  i20 = 1: split-f16 mode (f32 activations; w = [Cout][K/16][16 hi | 16 lo] f16 halves with w = hi + lo*2^-11;
-   *           three f16 MFMAs per block give f32-class accuracy at the f16 matrix rate; needs Cin % 32 == 0) */
+   *           three f16 MFMAs per block give f32-class accuracy at the f16 matrix rate; needs Cin % 32 == 0)
+   *  i20 = 2: pre-split LDS-DMA GEMM (csrc/gemm_dma.hip; pointwise layers only, K % 32 == 0, Cout % 128 == 0):
+   *           BOTH operands are "format B" f16 pairs — a 16-channel group is 64 bytes, 16 hi halves then 16 lo halves,
+   *           value = hi + lo (4 bytes per element, same strides as f32) — x written that way by its producer
+   *           (OMNI_OP_LAYERNORM i6, this op's i21, OMNI_OP_SPLIT_CONVERT), w = split(W * 2^k) with f1 = 2^-k;
+   *           i21 = 1: write y in format B as well (bias + activation applied first; no residual) */
   OMNI_OP_CONV = 1,
   /* avg_pool2d(k=2,s=1,p=0) (ADown, ref blob T1).  p0 x, p4 y.
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */
@@ -104,7 +109,8 @@ enum {
    *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p4 y; i0 B i1 H i2 W i3 C */
   OMNI_OP_DWCONV3 = 8,
   /* nn.LayerNorm over C (<= 1024) of x (+ add[row % period]) (hf florence2 :154-574, bart :272-341).
-   *  p0 x [rows,C] p1 add [period,C] or NULL p2 gamma f32 p3 beta f32 p4 y; i0*i1 rows i3 C i5 period; f0 eps */
+   *  p0 x [rows,C] p1 add [period,C] or NULL p2 gamma f32 p3 beta f32 p4 y; i0*i1 rows i3 C i5 period; f0 eps
+   *  i6 output mode (f32 plans, C % 16 == 0): 0 = f32 y, 1 = y in format B (see OMNI_OP_CONV i20 = 2), 2 = f32 y AND format B p5 */
   OMNI_OP_LAYERNORM = 9,
   /* softmax(q k^T * scale) v, one query row per thread; mode 0 plain MHA (bart :143-257), mode 1 DaViT
    * 12x12 window attention incl. the unmasked zero-padded window tokens (florence2 :338-398).
@@ -143,6 +149,9 @@ enum {
    *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p3 h [B,H,W,C] p4 x1 [B,H,W,C] p5 gamma f32 p6 beta f32
    *  i0 B i1 H i2 W i3 C (<= 1024); f0 eps */
   OMNI_OP_DWCONV3_LN = 18,
+  /* f32 channel slice of a token matrix -> format B (OMNI_OP_CONV i20 = 2), in place when p0 == p4 and the slices coincide.
+   *  p0 x [rows, ldi] p4 y [rows, ldo]; i0*i1 rows i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (all multiples of 16) */
+  OMNI_OP_SPLIT_CONVERT = 19,
   OMNI_OP__COUNT
 };
 

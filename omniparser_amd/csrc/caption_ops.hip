@@ -177,7 +177,7 @@ inline DwStripGrid dwconv3_strip_grid(const DwArgs& a, int V) {
 }
 
 // ------------------------------------------------------------------------------------ layernorm
-struct LnArgs { const void* x; const void* add; const float* g; const float* b; void* y; long long rows; int C, period; float eps; };
+struct LnArgs { const void* x; const void* add; const float* g; const float* b; void* y; void* y2; long long rows; int C, period, omode; float eps; };
 
 template <typename T, int NIT>
 __global__ __launch_bounds__(256) void layernorm_kernel(LnArgs a) {
@@ -222,6 +222,89 @@ void launch_layernorm_typed(const LnArgs& a, unsigned blocks, hipStream_t s) {
   else if (nit <= 8) hipLaunchKernelGGL((layernorm_kernel<T, 8>), dim3(blocks), dim3(256), 0, s, a);
   else if (nit <= 12) hipLaunchKernelGGL((layernorm_kernel<T, 12>), dim3(blocks), dim3(256), 0, s, a);
   else hipLaunchKernelGGL((layernorm_kernel<T, 16>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+
+// f32 rows with C % 4 == 0 (every LayerNorm of the captioner): 16-byte vectors per lane, LPR lanes per row (a wave
+// covers two C = 128 rows at once), same two-pass statistics.  OMODE 0: f32 output; 1: "format B" split output (the
+// consumer is a gemm_dma GEMM: hi/lo f16 pairs, omni_internal.h); 2: both (BART post-LN rows are also the residual).
+template <int LPR>
+__device__ __forceinline__ float group_sum(float v) {
+#pragma unroll
+  for (int o = LPR / 2; o > 0; o >>= 1) v += __shfl_xor(v, o);
+  return v;
+}
+
+template <int NIT, int LPR, int OMODE>
+__global__ __launch_bounds__(256) void layernorm_f32v4_kernel(LnArgs a) {
+  constexpr int RPW = 64 / LPR;
+  const int lane = threadIdx.x & 63, lr = lane % LPR, sub = lane / LPR;
+  long long row = ((long long)blockIdx.x * 4 + (threadIdx.x >> 6)) * RPW + sub;
+  const bool live = row < a.rows;
+  if (!live) row = a.rows - 1;                    // the lane stays for the shuffles and stores nothing
+  const float* __restrict__ x = (const float*)a.x + row * a.C;
+  const float* __restrict__ ad = a.add ? (const float*)a.add + (row % a.period) * a.C : nullptr;
+  f32x4 v[NIT];
+  float s = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = (lr + i * LPR) * 4;
+    f32x4 t = {0.f, 0.f, 0.f, 0.f};
+    if (c < a.C) {
+      t = *reinterpret_cast<const f32x4*>(x + c);
+      if (ad) t += *reinterpret_cast<const f32x4*>(ad + c);
+    }
+    v[i] = t;
+    s += (t[0] + t[1]) + (t[2] + t[3]);
+  }
+  const float mean = group_sum<LPR>(s) / (float)a.C;
+  float q = 0.0f;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = (lr + i * LPR) * 4;
+    if (c < a.C) {
+      f32x4 d = v[i] - mean;
+      q += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+  }
+  const float rstd = 1.0f / sqrtf(group_sum<LPR>(q) / (float)a.C + a.eps);
+  if (!live) return;
+#pragma unroll
+  for (int i = 0; i < NIT; ++i) {
+    const int c = (lr + i * LPR) * 4;
+    if (c < a.C) {
+      const f32x4 g = *reinterpret_cast<const f32x4*>(a.g + c), b = *reinterpret_cast<const f32x4*>(a.b + c);
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (v[i][e] - mean) * rstd * g[e] + b[e];
+      if constexpr (OMODE != 1) *reinterpret_cast<f32x4*>((float*)a.y + row * a.C + c) = f32x4{o[0], o[1], o[2], o[3]};
+      if constexpr (OMODE != 0) {
+        uint2 hi, lo;
+        omni_split4(o, hi, lo);
+        unsigned char* p = (unsigned char*)(OMODE == 1 ? a.y : a.y2) + row * a.C * 4 + omni_split_off(c);
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + 32) = lo;
+      }
+    }
+  }
+}
+
+template <int NIT, int LPR>
+void launch_ln_v4_mode(const LnArgs& a, hipStream_t s) {
+  const unsigned blocks = (unsigned)((a.rows + 4 * (64 / LPR) - 1) / (4 * (64 / LPR)));
+  if (a.omode == 0) hipLaunchKernelGGL((layernorm_f32v4_kernel<NIT, LPR, 0>), dim3(blocks), dim3(256), 0, s, a);
+  else if (a.omode == 1) hipLaunchKernelGGL((layernorm_f32v4_kernel<NIT, LPR, 1>), dim3(blocks), dim3(256), 0, s, a);
+  else hipLaunchKernelGGL((layernorm_f32v4_kernel<NIT, LPR, 2>), dim3(blocks), dim3(256), 0, s, a);
+}
+
+inline bool launch_layernorm_v4(const LnArgs& a, hipStream_t s) {
+  if (a.C % 4) return false;
+  if (a.C <= 128) launch_ln_v4_mode<1, 32>(a, s);
+  else if (a.C <= 256) launch_ln_v4_mode<1, 64>(a, s);
+  else if (a.C <= 512) launch_ln_v4_mode<2, 64>(a, s);
+  else if (a.C <= 768) launch_ln_v4_mode<3, 64>(a, s);
+  else launch_ln_v4_mode<4, 64>(a, s);
+  return true;
 }
 
 // ------------------------------------------------------------------------------------ dwconv3 + layernorm fused
@@ -1135,7 +1218,14 @@ int omni_launch_layernorm(const omni_op_t* op, hipStream_t s) {
   a.x = op->p[0]; a.add = op->p[1]; a.g = (const float*)op->p[2]; a.b = (const float*)op->p[3]; a.y = op->p[4];
   a.rows = ((long long)op->i[0]) * (op->i[1] > 0 ? op->i[1] : 1); a.C = op->i[3]; a.period = op->i[5] > 0 ? op->i[5] : 1;
   a.eps = op->f[0];
+  a.omode = op->i[6]; a.y2 = op->p[5];
   OMNI_REQUIRE(a.x && a.g && a.b && a.y && a.rows > 0 && a.C > 0 && a.C <= 1024, "layernorm: bad arguments (C <= 1024)");
+  OMNI_REQUIRE(a.omode >= 0 && a.omode <= 2 && (a.omode != 2 || a.y2), "layernorm: bad output mode %d", a.omode);
+  OMNI_REQUIRE(a.omode == 0 || (op->dtype == OMNI_F32 && a.C % 16 == 0), "layernorm: split output needs an f32 plan and C %% 16 == 0");
+  if (op->dtype == OMNI_F32 && launch_layernorm_v4(a, s)) {
+    OMNI_HIP_CHECK(hipGetLastError());
+    return OMNI_OK;
+  }
   unsigned blocks = (unsigned)((a.rows + 3) / 4);
   int rc = by_dtype(op->dtype, "layernorm",
       [&] { launch_layernorm_typed<float>(a, blocks, s); },

@@ -25,8 +25,10 @@
 //     bias/act/residual) fills the 256 CUs when M*Cout is small (P4/P5 layers at batch 1).
 //   * concat / chunk are zero-copy: in_coff/ldi and out_coff/ldo address channel slices.
 #include "omni_internal.h"
+#include "gemm_common.h"
 #include <stdlib.h>
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -40,60 +42,33 @@ struct ConvArgs {
   float scale;
 };
 
-// Block -> output tile.  MI355X dispatches consecutive workgroups round-robin over its 8 XCDs (bid & 7), each with
-// a private 4 MiB L2.  With xcd_order the grid is laid out per XCD:
-//   * xcd_n == 1: XCD x owns row blocks mt = x (mod 8) and walks all N tiles of one row block back to back, so the
-//     activation tile is fetched once per row block and re-used from L2 by its N-tile neighbours;
-//   * xcd_n  > 1: the N tiles are additionally partitioned over xcd_n XCD groups (XCD x serves N partition x % xcd_n
-//     and row blocks = x / xcd_n (mod 8 / xcd_n)).  Each XCD then touches only ntiles/xcd_n weight panels — chosen so
-//     that slab (<= 2 MiB) stays resident in its L2 while activations stream through — instead of the whole weight
-//     matrix being re-fetched from Infinity Cache / HBM by every row block (measured in round 1: weight re-fetch was
-//     ~65 % of this kernel's L2-miss traffic, profiles/r1_gemm_traffic_model.md).
-// Pure index permutation: every (mt, nt) is produced exactly once for bid in [0, omni_tile_grid), results are
-// bit-identical for any xcd_n.  Host mirror + exhaustive bijection test: omni_debug_tile_map / tests/test_host_cpu.py.
-__host__ __device__ __forceinline__ bool tile_of_block(int bid, int mtiles, int ntiles, int xcd_order, int xcd_n, int& mt, int& nt) {
-  if (xcd_order) {
-    const int x = bid & 7, s = bid >> 3;
-    const int gn = ntiles / xcd_n;               // N tiles per XCD group (xcd_n divides ntiles)
-    const int ml = s / gn;
-    mt = ml * (8 / xcd_n) + x / xcd_n;
-    nt = (x % xcd_n) * gn + (s - ml * gn);
-    return mt < mtiles;
+
+// Epilogue shared by the register-staged kernels below.  C/D layout of a 32x32 MFMA tile: col = lane & 31 (output channel),
+// row = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5) (output pixel).  Per tile: all 16 residual loads are issued first (one
+// wait instead of sixteen), the activation is a compile-time choice (no per-element switch) and addresses advance by row
+// strides instead of being rebuilt per element.
+template <typename T, int ACT, typename GetAcc>
+__device__ __forceinline__ void epilogue_tile(const ConvArgs& a, int mb, int n, bool nok, float bias, GetAcc get) {
+  if (!nok) return;
+  T* __restrict__ Yb = reinterpret_cast<T*>(a.y) + (long long)mb * a.ldo + a.out_coff + n;
+  const T* __restrict__ Rb = a.res ? reinterpret_cast<const T*>(a.res) + (long long)mb * a.ldr + a.res_coff + n : nullptr;
+  float r[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int dm = (e & 3) + 8 * (e >> 2);
+    r[e] = (Rb && mb + dm < a.M) ? ElemTraits<T>::to_f32(Rb[dm * a.ldr]) : 0.0f;
   }
-  mt = bid % mtiles;                             // few M tiles: plain order keeps all 8 XCDs busy
-  nt = bid / mtiles;
-  return true;
-}
-
-__host__ inline unsigned tile_grid(int mtiles, int ntiles, int xcd_order, int xcd_n) {
-  if (!xcd_order) return (unsigned)(mtiles * ntiles);
-  const int mper = 8 / xcd_n;
-  return (unsigned)(((mtiles + mper - 1) / mper) * (ntiles / xcd_n) * 8);
-}
-
-// N-partition choice: smallest xcd_n in {2, 4, 8} dividing ntiles whose per-XCD weight slab fits the L2 budget;
-// 1 (row-block mapping) when the whole matrix already fits or no divisor achieves residency.
-__host__ inline int choose_xcd_n(int ntiles, long long weight_bytes) {
-  // read per launch (like the other tuning knobs) so one process can A/B the orders; captured graphs keep theirs
-  const char* e = getenv("OMNI_XCD_NSPLIT");
-  const bool enabled = !(e && atoi(e) == 0);
-  long long budget = 2ll << 20;                  // half of the 4 MiB L2 (tools/l2_sim.py; OMNI_XCD_L2_BUDGET_KB overrides)
-  if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
-  if (!enabled || weight_bytes <= budget) return 1;
-  for (int xn = 2; xn <= 8; xn *= 2)
-    if (ntiles % xn == 0 && weight_bytes / xn <= budget) return xn;
-  return 1;
-}
-
-__device__ __forceinline__ float act_apply(float v, int act) {
-  if (act == OMNI_ACT_SILU) {
-    // torch CPU: x / (1 + exp(-x))
-    return v / (1.0f + expf(-v));
-  } else if (act == OMNI_ACT_GELU) {
-    // exact erf GELU (hf ACT2FN["gelu"]): 0.5 * x * (1 + erf(x / sqrt(2)))
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+  const float scale = a.scale;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int dm = (e & 3) + 8 * (e >> 2);
+    float v = get(e) + bias;
+    if (scale != 0.0f) v *= scale;
+    if constexpr (ACT == OMNI_ACT_SILU) v = v / (1.0f + expf(-v));                                   // torch CPU: x / (1 + exp(-x))
+    else if constexpr (ACT == OMNI_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact erf GELU
+    v += r[e];
+    if (mb + dm < a.M) Yb[dm * a.ldo] = ElemTraits<T>::from_f32(v);
   }
-  return v;
 }
 
 template <typename T, int BM, int BN, int RB, bool ALIGNED, bool PW>
@@ -315,30 +290,21 @@ __global__ __launch_bounds__(256) void conv_igemm_kernel(ConvArgs a) {
     }
     return;
   }
-  T* __restrict__ Y = reinterpret_cast<T*>(a.y);
-  const T* __restrict__ R = reinterpret_cast<const T*>(a.res);
-  const float scale = a.scale;
+  auto run = [&](auto tag) {
+    constexpr int ACT = decltype(tag)::value;
 #pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
-    bool nok = n < a.Cout;
-    float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
+    for (int j = 0; j < TN; ++j) {
+      const int n = n0 + wn * (BN / 2) + j * 32 + (lane & 31);
+      const bool nok = n < a.Cout;
+      const float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
 #pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = mb + (e & 3) + 8 * (e >> 2);
-        if (nok && m < a.M) {
-          float v = acc[i][j][e] + bias;
-          if (scale != 0.0f) v *= scale;
-          v = act_apply(v, a.act);
-          if (R) v += ElemTraits<T>::to_f32(R[(long long)m * a.ldr + a.res_coff + n]);
-          Y[(long long)m * a.ldo + a.out_coff + n] = ElemTraits<T>::from_f32(v);
-        }
-      }
+      for (int i = 0; i < TM; ++i)
+        epilogue_tile<T, ACT>(a, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n, nok, bias, [&](int e) { return acc[i][j][e]; });
     }
-  }
+  };
+  if (a.act == OMNI_ACT_SILU) run(std::integral_constant<int, OMNI_ACT_SILU>{});
+  else if (a.act == OMNI_ACT_GELU) run(std::integral_constant<int, OMNI_ACT_GELU>{});
+  else run(std::integral_constant<int, OMNI_ACT_NONE>{});
 }
 
 // split-K second pass: y = act(sum_z partial[z] + bias) (+ residual); fixed summation order.
@@ -385,9 +351,9 @@ __device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& 
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
-template <int BM, int BN, int NW, bool DEEP, bool PW>
+template <int BM, int BN, int NW, bool PW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
-  // NW waves as 2 (M) x NW/2 (N); DEEP: global loads run two K slices ahead (second register stage)
+  // NW waves as 2 (M) x NW/2 (N)
   constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
   constexpr int BKE = 32;                  // f32 elements of K per slice
   constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
@@ -442,7 +408,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
     w_s = tap - w_r * a.KW;
   }
 
-  u32x4 ra0[A_IT], rb0[B_IT], ra1[A_IT], rb1[B_IT];     // two register stages: loads run two K slices ahead
+  u32x4 ra0[A_IT], rb0[B_IT];
   const u32x4 zero4 = {0u, 0u, 0u, 0u};
   auto load_tile = [&](int kt, u32x4* ra, u32x4* rb) {
     if (PW) {
@@ -519,34 +485,16 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
     }
   };
 
-  if constexpr (DEEP) {
-    // software pipeline: global loads run TWO K slices ahead (registers), LDS writes ONE slice ahead
-    if (kt0 < kt1) { load_tile(kt0, ra0, rb0); store_tile(0, ra0, rb0); }
-    if (kt0 + 1 < kt1) load_tile(kt0 + 1, ra1, rb1);
+  if (kt0 < kt1) { load_tile(kt0, ra0, rb0); store_tile(0, ra0, rb0); }
+  __syncthreads();
+  int cur = 0;
+  for (int kt = kt0; kt < kt1; ++kt) {
+    const bool more = kt + 1 < kt1;
+    if (more) load_tile(kt + 1, ra0, rb0);
+    compute(cur);
+    if (more) store_tile(cur ^ 1, ra0, rb0);
     __syncthreads();
-    for (int kt = kt0; kt < kt1; kt += 2) {
-      if (kt + 2 < kt1) load_tile(kt + 2, ra0, rb0);
-      compute(0);
-      if (kt + 1 < kt1) store_tile(1, ra1, rb1);
-      __syncthreads();
-      if (kt + 1 >= kt1) break;
-      if (kt + 3 < kt1) load_tile(kt + 3, ra1, rb1);
-      compute(1);
-      if (kt + 2 < kt1) store_tile(0, ra0, rb0);
-      __syncthreads();
-    }
-  } else {
-    if (kt0 < kt1) { load_tile(kt0, ra0, rb0); store_tile(0, ra0, rb0); }
-    __syncthreads();
-    int cur = 0;
-    for (int kt = kt0; kt < kt1; ++kt) {
-      const bool more = kt + 1 < kt1;
-      if (more) load_tile(kt + 1, ra0, rb0);
-      compute(cur);
-      if (more) store_tile(cur ^ 1, ra0, rb0);
-      __syncthreads();
-      cur ^= 1;
-    }
+    cur ^= 1;
   }
 
   const float inv = 1.0f / 2048.0f;
@@ -568,440 +516,22 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
     }
     return;
   }
-  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
-  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
-  const float scale = a.scale;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    bool nok = n < a.Cout;
-    float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = mb + (e & 3) + 8 * (e >> 2);
-        if (nok && m < a.M) {
-          float v = (accM[i][j][e] + accC[i][j][e] * inv) + bias;
-          if (scale != 0.0f) v *= scale;
-          v = act_apply(v, a.act);
-          if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
-          Y[(long long)m * a.ldo + a.out_coff + n] = v;
-        }
-      }
-    }
-  }
-}
-
-// 128x128 tile, 8 waves (2 x 4, 64x32 per wave), weights NOT staged through LDS: every wave reads its B fragments
-// (32 output channels x 16 k, hi|lo) straight from the packed weight matrix into registers, one K slice ahead.  The
-// weight matrix is small and L2/MALL-resident; skipping its LDS round trip removes ~40 % of the LDS traffic that
-// co-limits conv_split_kernel (LDS then carries only the split activation tile).
-template <bool PW>
-__global__ __launch_bounds__(512, 2) void conv_split_breg_kernel(ConvArgs a) {
-  constexpr int BM = 128, BN = 128, RB = 128, ROWB = RB + 16, VPR = 8, RPP = 64, BKE = 32;
-  constexpr int A_IT = BM / RPP, TM = 2;
-  constexpr int STAGE = BM * ROWB;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave >> 2, wn = wave & 3;
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int vec = tid % VPR, r0 = tid / VPR;
-  const int kt0 = blockIdx.z * a.kt_per_split;
-  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
-  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
-  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(a.w);
-
-  long long a_base[A_IT];
-  int a_hi0[A_IT], a_wi0[A_IT];
-  bool a_ok[A_IT];
-  const float* a_row[A_IT];
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    int m = m0 + r0 + it * RPP;
-    a_ok[it] = m < a.M;
-    int mm = a_ok[it] ? m : 0;
-    int wo = mm % a.Wo;
-    int t = mm / a.Wo;
-    int ho = t % a.Ho;
-    int b = t / a.Ho;
-    a_hi0[it] = ho * a.stride - a.pad;
-    a_wi0[it] = wo * a.stride - a.pad;
-    a_base[it] = (long long)b * a.H * a.W * a.ldi + a.in_coff;
-    a_row[it] = X + (long long)mm * a.ldi + a.in_coff + vec * 4;
-  }
-  // this lane's weight row (output channel) and its 16-byte column inside each [16 hi | 16 lo] block
-  const int bn = n0 + wn * 32 + (lane & 31);
-  const bool bn_ok = bn < a.Cout;
-  const unsigned char* b_row = Wb + (long long)(bn_ok ? bn : 0) * a.K * 4 + (lane >> 5) * 16;
-  int w_r = 0, w_s = 0, w_c = 0;
-  if (!PW) {
-    int tap = kt0 / a.cin_tiles;
-    w_c = (kt0 - tap * a.cin_tiles) * BKE;
-    w_r = tap / a.KW;
-    w_s = tap - w_r * a.KW;
-  }
-  u32x4 ra[A_IT];
-  u32x4 nbh[2], nbl[2];                         // next slice's B fragments (two 16-wide k blocks)
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  auto load_tile = [&](int kt) {
-    if (PW) {
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it)
-        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
-    } else {
-      int r = w_r, s = w_s, c = w_c + vec * 4;
-      w_c += BKE;
-      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it) {
-        int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
-        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
-      }
-    }
-#pragma unroll
-    for (int j = 0; j < 2; ++j) {
-      const unsigned char* p = b_row + ((long long)kt * 2 + j) * 64;
-      nbh[j] = bn_ok ? *reinterpret_cast<const u32x4*>(p) : zero4;
-      nbl[j] = bn_ok ? *reinterpret_cast<const u32x4*>(p + 32) : zero4;
-    }
-  };
-  const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
-  auto store_tile = [&](int stage) {
-    unsigned char* sA = lds + stage * STAGE;
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      uint2 hi, lo;
-      split_f16x4(ra[it], hi, lo);
-      unsigned char* p = sA + (r0 + it * RPP) * ROWB + a_wr;
-      *reinterpret_cast<uint2*>(p) = hi;
-      *reinterpret_cast<uint2*>(p + 32) = lo;
-    }
-  };
-  f32x16 accM[TM], accC[TM];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int e = 0; e < 16; ++e) { accM[i][e] = 0.0f; accC[i][e] = 0.0f; }
-  const int a_rd = (wm * 64 + (lane & 31)) * ROWB + (lane >> 5) * 16;
-  u32x4 cbh[2], cbl[2];
-  if (kt0 < kt1) { load_tile(kt0); store_tile(0); }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) { cbh[j] = nbh[j]; cbl[j] = nbl[j]; }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) load_tile(kt + 1);
-    const unsigned char* st = lds + cur * STAGE;
-#pragma unroll
-    for (int j16 = 0; j16 < 2; ++j16) {
-      f16x8 bh = __builtin_bit_cast(f16x8, cbh[j16]), bl = __builtin_bit_cast(f16x8, cbl[j16]);
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        f16x8 ah = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64);
-        f16x8 al = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64 + 32);
-        accM[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bh, accM[i], 0, 0, 0);
-        accC[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah, bl, accC[i], 0, 0, 0);
-        accC[i] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al, bh, accC[i], 0, 0, 0);
-      }
-    }
-    if (more) {
-      store_tile(cur ^ 1);
-#pragma unroll
-      for (int j = 0; j < 2; ++j) { cbh[j] = nbh[j]; cbl[j] = nbl[j]; }
-    }
-    __syncthreads();
-    cur ^= 1;
-  }
-  const float inv = 1.0f / 2048.0f;
-  const int n = n0 + wn * 32 + (lane & 31);
-  const bool nok = n < a.Cout;
-  if (a.splits > 1) {
-    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
-    if (nok) {
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          int m = mb + (e & 3) + 8 * (e >> 2);
-          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][e] + accC[i][e] * inv;
-        }
-      }
-    }
-    return;
-  }
-  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
-  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
-  const float scale = a.scale;
-  const float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
-#pragma unroll
-  for (int i = 0; i < TM; ++i) {
-    int mb = m0 + wm * 64 + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-    for (int e = 0; e < 16; ++e) {
-      int m = mb + (e & 3) + 8 * (e >> 2);
-      if (nok && m < a.M) {
-        float v = (accM[i][e] + accC[i][e] * inv) + bias;
-        if (scale != 0.0f) v *= scale;
-        v = act_apply(v, a.act);
-        if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
-        Y[(long long)m * a.ldo + a.out_coff + n] = v;
-      }
-    }
-  }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Generalised split-f16 kernel (opt-in, OMNI_SPLIT_VARIANT=4|5|6; NOT the default): the same staging / MFMA scheme as
-// conv_split_kernel with a WM x WN wave grid and a selectable K-slice width, so that two hypotheses can be measured:
-//   4: 256x128 block tile (4 x 2 waves, 64x64 per wave: 0.67 LDS reads per MFMA instead of 1.0, 25 % fewer operand
-//      bytes per MFMA from L2); 201-212 registers, no scratch, 108 KB LDS -> one 8-wave block per CU;
-//   5: 128x128 tile with 64-wide K slices: every matrix row contributes 256 contiguous bytes per request round instead
-//      of one 128-byte line (the round-1 operand stream is scattered single lines), half the barriers;
-//      169 registers, no scratch, 136 KB LDS -> one block per CU;
-//   6: the default tile with the weight slices staged by LDS-DMA (no staging registers, no ds_write_b128): 112-120
-//      registers, 68 KB LDS, still two blocks per CU (layout checked symbolically: tests/test_split_kernel_layout_cpu.py).
-// Dropped on paper: 256x256 (two f32 accumulator sets = 256 VGPRs, spills) and an "A-deep" pipeline with activation
-// loads two K slices ahead (needs > 128 registers at 4 waves/SIMD: 420 B of scratch; at 2 waves/SIMD it is the
-// measured-slower variant 1).
-template <int BM, int BN, int WM, int WN, bool PW, int MINB, int RB = 128, bool BDMA = false>
-__global__ __launch_bounds__(WM * WN * 64, MINB) void conv_split2_kernel(ConvArgs a) {
-  constexpr int NW = WM * WN;
-  // RB = bytes of K per LDS row and slice: 128 (32 f32 k, two 16-k blocks) or 256 (64 k: twice the contiguous bytes per
-  // matrix row and memory request round, half the barriers; 136 KB of LDS -> one block per CU)
-  constexpr int ROWB = RB + 16, VPR = RB / 16, RPP = NW * 64 / VPR;
-  constexpr int BKE = RB / 4, KB16 = RB / 64;
-  constexpr int A_IT = BM / RPP, B_IT = BN / RPP;
-  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);
-  // BDMA: the (pre-split) weight slice goes global -> LDS by LDS-DMA (global_load_lds_dwordx4), no staging registers
-  // and no ds_write.  A DMA instruction writes wave-uniform base + lane*16, so the weight rows are UNPADDED (RB bytes)
-  // and bank conflicts are avoided by an XOR swizzle instead: LDS slot s of row r holds source chunk s ^ ((r >> 1) & 7)
-  // (applied to the per-lane SOURCE address here and to the fragment read address below — same involution).
-  constexpr int ROWB_B = BDMA ? RB : ROWB;
-  constexpr int STAGE = BM * ROWB + BN * ROWB_B;
-  static_assert(!BDMA || RB == 128, "the swizzle below is written for 8 chunks per row");
-  static_assert(BM % RPP == 0 && BN % RPP == 0 && TM >= 1 && TN >= 1, "tile / wave grid mismatch");
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
-
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const int wm = wave / WN, wn = wave % WN;
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
-  const int m0 = mt * BM, n0 = nt * BN;
-  const int vec = tid % VPR, r0 = tid / VPR;
-  const int kt0 = blockIdx.z * a.kt_per_split;
-  const int kt1 = min(kt0 + a.kt_per_split, a.ktiles);
-
-  const float* __restrict__ X = reinterpret_cast<const float*>(a.x);
-  const unsigned char* __restrict__ Wb = reinterpret_cast<const unsigned char*>(a.w);
-
-  long long a_base[A_IT];
-  int a_hi0[A_IT], a_wi0[A_IT];
-  bool a_ok[A_IT];
-  const float* a_row[A_IT];
-#pragma unroll
-  for (int it = 0; it < A_IT; ++it) {
-    int m = m0 + r0 + it * RPP;
-    a_ok[it] = m < a.M;
-    int mm = a_ok[it] ? m : 0;
-    int wo = mm % a.Wo;
-    int t = mm / a.Wo;
-    int ho = t % a.Ho;
-    int b = t / a.Ho;
-    a_hi0[it] = ho * a.stride - a.pad;
-    a_wi0[it] = wo * a.stride - a.pad;
-    a_base[it] = (long long)b * a.H * a.W * a.ldi + a.in_coff;
-    a_row[it] = X + (long long)mm * a.ldi + a.in_coff + vec * 4;
-  }
-  const unsigned char* b_ptr[B_IT];
-  bool b_ok[B_IT];
-#pragma unroll
-  for (int it = 0; it < B_IT; ++it) {
-    int n = n0 + r0 + it * RPP;
-    b_ok[it] = n < a.Cout;
-    b_ptr[it] = Wb + (long long)(b_ok[it] ? n : 0) * a.K * 4 + (BDMA ? ((vec ^ ((r0 >> 1) & 7)) * 16) : vec * 16);
-  }
-  int w_r = 0, w_s = 0, w_c = 0;
-  if (!PW) {
-    int tap = kt0 / a.cin_tiles;
-    w_c = (kt0 - tap * a.cin_tiles) * BKE;
-    w_r = tap / a.KW;
-    w_s = tap - w_r * a.KW;
-  }
-
-  u32x4 ra0[A_IT], rb[B_IT];
-  const u32x4 zero4 = {0u, 0u, 0u, 0u};
-  // load_a MUST be called once per K slice in increasing order (it advances the (r, s, c) walker)
-  auto load_a = [&](int kt, u32x4* ra) {
-    if (PW) {
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it)
-        ra[it] = a_ok[it] ? *reinterpret_cast<const u32x4*>(a_row[it] + kt * BKE) : zero4;
-    } else {
-      int r = w_r, s = w_s, c = w_c + vec * 4;
-      w_c += BKE;
-      if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
-#pragma unroll
-      for (int it = 0; it < A_IT; ++it) {
-        int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
-        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
-        ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
-      }
-    }
-  };
-  auto load_b = [&](int kt, int stage) {
-    if constexpr (BDMA) {
-      // rows r0 = wave*8 + lane/8, slot vec = lane%8: the wave's 64 lanes fill 8 consecutive 128-byte rows = 1 KiB
-      unsigned char* dstw = lds + stage * STAGE + BM * ROWB + (wave * 8) * RB;
-#pragma unroll
-      for (int it = 0; it < B_IT; ++it)
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)(b_ptr[it] + (long long)kt * RB),
-                                         (__attribute__((address_space(3))) void*)(dstw + it * RPP * RB), 16, 0, 0);
-    } else {
-#pragma unroll
-      for (int it = 0; it < B_IT; ++it)
-        rb[it] = b_ok[it] ? *reinterpret_cast<const u32x4*>(b_ptr[it] + (long long)kt * RB) : zero4;
-    }
-  };
-  const int a_wr = (vec >> 2) * 64 + (vec & 3) * 8;
-  auto store_tile = [&](int stage, const u32x4* ra) {
-    unsigned char* sA = lds + stage * STAGE;
-    unsigned char* sB = sA + BM * ROWB;
-    if constexpr (!BDMA) {
-#pragma unroll
-      for (int it = 0; it < B_IT; ++it)
-        *reinterpret_cast<u32x4*>(sB + (r0 + it * RPP) * ROWB + vec * 16) = rb[it];
-    }
-#pragma unroll
-    for (int it = 0; it < A_IT; ++it) {
-      uint2 hi, lo;
-      split_f16x4(ra[it], hi, lo);
-      unsigned char* p = sA + (r0 + it * RPP) * ROWB + a_wr;
-      *reinterpret_cast<uint2*>(p) = hi;
-      *reinterpret_cast<uint2*>(p + 32) = lo;
-    }
-  };
-
-  f32x16 accM[TM][TN], accC[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) { accM[i][j][e] = 0.0f; accC[i][j][e] = 0.0f; }
-
-  const int a_rd = (wm * (BM / WM) + (lane & 31)) * ROWB + (lane >> 5) * 16;
-  const int b_rd = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB_B + (BDMA ? 0 : (lane >> 5) * 16);
-  const int b_swz = (lane >> 1) & 7;             // (row >> 1) & 7 of this lane's weight rows (row = 32*j + lane%32 + const*32)
-
-  auto compute = [&](int stage) {
-    const unsigned char* st = lds + stage * STAGE;
-#pragma unroll
-    for (int j16 = 0; j16 < KB16; ++j16) {
-      f16x8 ah[TM], al[TM], bh[TN], bl[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        ah[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64);
-        al[i] = *reinterpret_cast<const f16x8*>(st + a_rd + i * 32 * ROWB + j16 * 64 + 32);
-      }
-#pragma unroll
-      for (int j = 0; j < TN; ++j) {
-        if constexpr (BDMA) {
-          bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB_B + (((j16 * 4 + (lane >> 5)) ^ b_swz) * 16));
-          bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB_B + (((j16 * 4 + 2 + (lane >> 5)) ^ b_swz) * 16));
-        } else {
-          bh[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64);
-          bl[j] = *reinterpret_cast<const f16x8*>(st + b_rd + j * 32 * ROWB + j16 * 64 + 32);
-        }
-      }
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) {
-          accM[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bh[j], accM[i][j], 0, 0, 0);
-          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(ah[i], bl[j], accC[i][j], 0, 0, 0);
-          accC[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(al[i], bh[j], accC[i][j], 0, 0, 0);
-        }
-    }
-  };
-
-  if (kt0 < kt1) { load_b(kt0, 0); load_a(kt0, ra0); store_tile(0, ra0); }
-  __syncthreads();
-  int cur = 0;
-  for (int kt = kt0; kt < kt1; ++kt) {
-    const bool more = kt + 1 < kt1;
-    if (more) { load_b(kt + 1, cur ^ 1); load_a(kt + 1, ra0); }
-    compute(cur);
-    if (more) store_tile(cur ^ 1, ra0);
-    __syncthreads();
-    cur ^= 1;
-  }
-
-  const float inv = 1.0f / 2048.0f;
-  if (a.splits > 1) {
-    float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+  auto run = [&](auto tag) {
+    constexpr int ACT = decltype(tag)::value;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
-      int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-      if (n >= a.Cout) continue;
+      const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+      const bool nok = n < a.Cout;
+      const float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
 #pragma unroll
-      for (int i = 0; i < TM; ++i) {
-        int mb = m0 + wm * (BM / WM) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-        for (int e = 0; e < 16; ++e) {
-          int m = mb + (e & 3) + 8 * (e >> 2);
-          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][j][e] + accC[i][j][e] * inv;
-        }
-      }
+      for (int i = 0; i < TM; ++i)
+        epilogue_tile<float, ACT>(a, m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5), n, nok, bias,
+                                  [&](int e) { return accM[i][j][e] + accC[i][j][e] * inv; });
     }
-    return;
-  }
-  float* __restrict__ Y = reinterpret_cast<float*>(a.y);
-  const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
-  const float scale = a.scale;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
-    bool nok = n < a.Cout;
-    float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-      int mb = m0 + wm * (BM / WM) + i * 32 + 4 * (lane >> 5);
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = mb + (e & 3) + 8 * (e >> 2);
-        if (nok && m < a.M) {
-          float v = (accM[i][j][e] + accC[i][j][e] * inv) + bias;
-          if (scale != 0.0f) v *= scale;
-          v = act_apply(v, a.act);
-          if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
-          Y[(long long)m * a.ldo + a.out_coff + n] = v;
-        }
-      }
-    }
-  }
-}
-
-template <int BM, int BN, int WM, int WN, int MINB, int RB = 128, bool BDMA = false>
-void launch_split2(ConvArgs& a, hipStream_t s) {
-  a.mtiles = (a.M + BM - 1) / BM;
-  a.ntiles = (a.Cout + BN - 1) / BN;
-  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
-  a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
-  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
-  const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
-  if (pw) hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, true, MINB, RB, BDMA>), grid, dim3(WM * WN * 64), 0, s, a);
-  else hipLaunchKernelGGL((conv_split2_kernel<BM, BN, WM, WN, false, MINB, RB, BDMA>), grid, dim3(WM * WN * 64), 0, s, a);
-  if (a.splits > 1) {
-    long long total = (long long)a.M * a.Cout;
-    hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
-  }
+  };
+  if (a.act == OMNI_ACT_SILU) run(std::integral_constant<int, OMNI_ACT_SILU>{});
+  else if (a.act == OMNI_ACT_GELU) run(std::integral_constant<int, OMNI_ACT_GELU>{});
+  else run(std::integral_constant<int, OMNI_ACT_NONE>{});
 }
 
 template <int BM, int BN>
@@ -1012,30 +542,15 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.Cout * a.K) : 1;      // 4 bytes per (n, k): hi | lo halves
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n), 1, a.splits);
   const bool pw = a.KH == 1 && a.KW == 1 && a.stride == 1 && a.pad == 0 && a.H == a.Ho && a.W == a.Wo;
-  // 128x128 tile variants (measured on MI355X, TF/s effective on the stage-2 GEMMs):
-  //   0 = 4 waves, 64x64 per wave, 2 waves/SIMD: 172-209   1 = 8 waves + two-slice-ahead loads, 1 block/CU: 142-177
-  //   2 = 8 waves, 64x32 per wave, 4 waves/SIMD: 191-229  (default)
-  int variant = 2;
-  if (const char* e = getenv("OMNI_SPLIT_VARIANT")) variant = atoi(e);
-  bool done = false;
+  // 128x128: 8 waves (64x32 per wave, 4 waves/SIMD; measured 191-229 TF/s vs 172-209 for 4 waves of 64x64); smaller
+  // tiles: 4 waves.  Round-1 variants that lost (two-slice register prefetch, weights straight to registers, 256x128,
+  // 64-wide K slices, weight-only LDS-DMA) are recorded in DESIGN.md and profiles/r2_gemm_diag.md, not kept here.
   if constexpr (BM == 128 && BN == 128) {
-    if (variant == 3) {
-      if (pw) hipLaunchKernelGGL((conv_split_breg_kernel<true>), grid, dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((conv_split_breg_kernel<false>), grid, dim3(512), 0, s, a);
-      done = true;
-    } else if (variant == 1) {
-      if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, true>), grid, dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true, false>), grid, dim3(512), 0, s, a);
-      done = true;
-    } else if (variant == 2) {
-      if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false, true>), grid, dim3(512), 0, s, a);
-      else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false, false>), grid, dim3(512), 0, s, a);
-      done = true;
-    }
-  }
-  if (!done) {
-    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false, true>), grid, dim3(256), 0, s, a);
-    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false, false>), grid, dim3(256), 0, s, a);
+    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true>), grid, dim3(512), 0, s, a);
+    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false>), grid, dim3(512), 0, s, a);
+  } else {
+    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, true>), grid, dim3(256), 0, s, a);
+    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false>), grid, dim3(256), 0, s, a);
   }
   if (a.splits > 1) {
     long long total = (long long)a.M * a.Cout;
@@ -1068,27 +583,6 @@ void launch_split(ConvArgs& a, hipStream_t s) {
   if (const char* e = getenv("OMNI_SPLIT_TILE")) {        // tuning knob
     if (bm == 128 && !strcmp(e, "128x64")) bn = 64;
     if (bm == 128 && !strcmp(e, "128x128") && a.Cout > 64) bn = 128;
-  }
-  // opt-in experiment variants (conv_split2_kernel); default stays variant 2
-  //   4 = 256x128 tile, 8 waves 4x2        5 = 128x128 tile, 8 waves 2x4, 64-wide K slices (256 contiguous bytes per row)
-  //   6 = 128x128 tile, 8 waves 2x4, weight slices by LDS-DMA (global_load_lds) into an XOR-swizzled unpadded layout
-  if (const char* e = getenv("OMNI_SPLIT_VARIANT")) {
-    const int v = atoi(e);
-    if (v == 4 && bm == 128 && bn == 128 && a.splits == 1 && blocks(256, 128) >= 256) {
-      launch_split2<256, 128, 4, 2, 2>(a, s);
-      return;
-    }
-    if (v == 5 && bm == 128 && bn == 128 && a.splits == 1 && a.Cin % 64 == 0) {
-      a.cin_tiles = a.Cin / 64;
-      a.ktiles = a.K / 64;
-      a.kt_per_split = a.ktiles;
-      launch_split2<128, 128, 2, 4, 2, 256>(a, s);
-      return;
-    }
-    if (v == 6 && bm == 128 && bn == 128 && a.splits == 1) {        // default tile, weights by LDS-DMA + XOR swizzle
-      launch_split2<128, 128, 2, 4, 4, 128, true>(a, s);
-      return;
-    }
   }
   if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
   else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);

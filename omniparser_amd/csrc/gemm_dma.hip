@@ -1,0 +1,343 @@
+// Pre-split LDS-DMA GEMM for gfx950: the captioner's linear layers (hf:models/florence2/modeling_florence2.py
+// nn.Linear in DaViT blocks / projector, hf:models/bart/modeling_bart.py:143-308 attention + FFN projections).
+//
+//   Y[m, n] = act( 2^-k * sum_c A[m, c] * W'[n, c] + bias[n] ) (+ residual[m, n])         W' = W * 2^k
+//
+// Both operands arrive PRE-SPLIT in HBM as f16 pairs (4 bytes per element, the f32 footprint):
+//   row = [K/16 groups][16 hi halves | 16 lo halves],   x = hi + lo,   hi = f16(x) (rtz),  lo = f16(x - hi)
+// ("format B": lo is NOT rescaled, so ONE f32 accumulator takes all three products hi*hi + hi*lo + lo*hi; the weights
+// are pre-multiplied by a power of two so that their lo parts stay normal f16 numbers, activations are O(1) and keep
+// ~22 bits down to |x| = 2^-3 and an absolute 2^-25 floor below).  Producers (LayerNorm, the previous GEMM's epilogue,
+// split_convert_kernel) write that format, so the K loop holds no conversion, no VGPR staging and no ds_write:
+//   * global -> LDS by LDS-DMA (buffer_load_dwordx4 ... lds, 1 KiB = 8 rows x 128 B per wave instruction), SRD + SGPR
+//     K offset + one VGPR row offset per instruction: zero VALU address work inside the loop;
+//   * LDS rows are unpadded 128 B (one 32-wide K slice); bank conflicts are avoided by an XOR swizzle of the 16-byte
+//     chunk index with (row >> 1) & 7, applied to the DMA SOURCE address and to the fragment READ address (same
+//     involution; symbolic check in tests/test_split_kernel_layout_cpu.py);
+//   * NSTAGE-deep LDS ring, one raw s_barrier per K slice, counted s_waitcnt vmcnt so later slices stay in flight;
+//   * MFMA fragments are double-buffered in registers (next unit's ds_read_b128 issue under the current 12 MFMAs);
+//   * D^T = W * A^T: the MFMA's row operand is the weight fragment, so every lane owns ONE token and 4 consecutive
+//     output channels per accumulator quad -> 16-byte residual loads / stores, split output as two 8-byte stores;
+//   * epilogue is compiled per (activation, output format, residual) — no per-element branches.
+// Ablations that led here (profiles/r2_gemm_diag.md): the round-1 kernel was bound by its compute side
+// (ds_read -> lgkmcnt(0) -> MFMA without prefetch, 10.8 VALU per MFMA, a per-element epilogue), not by memory.
+#include "omni_internal.h"
+#include "gemm_common.h"
+#include <string.h>
+
+namespace {
+
+typedef __attribute__((address_space(3))) void lds_void;
+
+struct GemmArgs {
+  const unsigned char* x; const unsigned char* w; const float* bias; const float* res; unsigned char* y;
+  int M, N, K, nk;
+  int ldi, in_coff, ldo, out_coff, ldr, res_coff;
+  int mtiles, ntiles, xcd_order, xcd_n;
+  float oscale;                       // 2^-k of the weight pre-scale
+};
+
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES>
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
+  constexpr int NW = WM * WN;
+  constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);     // 32x32 MFMA tiles per wave (tokens x channels)
+  constexpr int A_DMA = BM / (8 * NW), B_DMA = BN / (8 * NW);  // 8-row DMA pieces per wave and K slice
+  constexpr int DPS = A_DMA + B_DMA;
+  constexpr int STAGE = (BM + BN) * 128;
+  constexpr int NP = TM / 2;                                   // token-tile pairs per wave
+  constexpr int NU = 2 * NP;                                   // MFMA units per K slice: (16-wide K group, tile pair)
+  static_assert(TM % 2 == 0 && TN >= 1 && A_DMA >= 1 && B_DMA >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile / wave grid mismatch");
+  static_assert(BM * 128 + (TN - 1) * 4096 < 65536 && (TM - 1) * 4096 < 65536, "ds_read immediate offsets");
+  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave / WN, wn = wave % WN;
+  int mt, nt;
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
+  const int m0 = mt * BM, n0 = nt * BN;
+
+  // ---- LDS-DMA descriptors.  Piece p (8 rows x 128 B) of an operand tile lands at LDS piece slot p; lane l of the
+  // issuing wave supplies row 8p + l/8, 16-byte slot l%8, whose SOURCE chunk is slot ^ ((row >> 1) & 7).
+  const int rsub = lane >> 3, slot = lane & 7;
+  unsigned voffA[A_DMA], voffB[B_DMA];
+#pragma unroll
+  for (int i = 0; i < A_DMA; ++i) {
+    const int rl = (wave * A_DMA + i) * 8 + rsub;
+    const int rr = min(rl, a.M - 1 - m0);                  // M tail: re-read the last row (its results are never stored)
+    voffA[i] = (unsigned)rr * (unsigned)(a.ldi * 4) + (unsigned)((slot ^ ((rl >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < B_DMA; ++i) {
+    const int rl = (wave * B_DMA + i) * 8 + rsub;
+    const int rr = min(rl, a.N - 1 - n0);
+    voffB[i] = (unsigned)rr * (unsigned)(a.K * 4) + (unsigned)((slot ^ ((rl >> 1) & 7)) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rsrcA =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long long)m0 * a.ldi + a.in_coff) * 4), 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrcB =
+      __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)n0 * a.K * 4), 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int kt, int stage) {
+    unsigned char* sA = lds + stage * STAGE + (wave * A_DMA) * 1024;
+    unsigned char* sB = lds + stage * STAGE + BM * 128 + (wave * B_DMA) * 1024;
+    const int so = kt * 128;
+#pragma unroll
+    for (int i = 0; i < A_DMA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sA + i * 1024), 16, voffA[i], so, 0, 0);
+#pragma unroll
+    for (int i = 0; i < B_DMA; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sB + i * 1024), 16, voffB[i], so, 0, 0);
+  };
+
+  // ---- fragment read offsets: lane -> (row lane & 31, k half lane >> 5); chunk of (K group g, part p) = 4g + 2p + half
+  const int swz = (lane >> 1) & 7, hsel = lane >> 5;
+  int offA[4], offW[4];
+#pragma unroll
+  for (int gp = 0; gp < 4; ++gp) {
+    const int c = ((((gp >> 1) * 4 + (gp & 1) * 2 + hsel) ^ swz)) * 16;
+    offA[gp] = (wm * (BM / WM) + (lane & 31)) * 128 + c;
+    offW[gp] = BM * 128 + (wn * (BN / WN) + (lane & 31)) * 128 + c;
+  }
+  struct AF { f16x8 h[2], l[2]; };
+  struct WF { f16x8 h[TN], l[TN]; };
+  auto loadA = [&](const unsigned char* st, int g, int ip, AF& f) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f.h[t] = *reinterpret_cast<const f16x8*>(st + offA[g * 2 + 0] + (ip * 2 + t) * 4096);
+      f.l[t] = *reinterpret_cast<const f16x8*>(st + offA[g * 2 + 1] + (ip * 2 + t) * 4096);
+    }
+  };
+  auto loadW = [&](const unsigned char* st, int g, WF& f) {
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      f.h[j] = *reinterpret_cast<const f16x8*>(st + offW[g * 2 + 0] + j * 4096);
+      f.l[j] = *reinterpret_cast<const f16x8*>(st + offW[g * 2 + 1] + j * 4096);
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
+
+  // three products per accumulator, issued product-major so that the same accumulator recurs every 2*TN MFMAs
+  auto mma = [&](const AF& af, const WF& wf, int ip) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.l[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.l[t], acc[ip * 2 + t][j], 0, 0, 0);
+  };
+
+  const int nk = a.nk;
+#pragma unroll
+  for (int s = 0; s < NSTAGE - 1; ++s)
+    if (s < nk) issue(s, s);
+  int stage = 0, nstage = NSTAGE - 1;          // ring positions of slice kt and of slice kt + NSTAGE - 1
+  for (int kt = 0; kt < nk; ++kt) {
+    // slice kt landed (this wave's pieces), later slices may stay in flight; then everybody's pieces landed and everybody is
+    // done reading the stage that the next DMA overwrites (it was read in iteration kt - 1)
+    if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    const unsigned char* st = lds + stage * STAGE;
+    AF af[2];
+    WF wf[2];
+    loadW(st, 0, wf[0]);
+    loadA(st, 0, 0, af[0]);
+    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, nstage);
+#pragma unroll
+    for (int u = 0; u < NU; ++u) {
+      const int g = u / NP, ip = u % NP;
+      if (u + 1 < NU) {
+        const int g2 = (u + 1) / NP, ip2 = (u + 1) % NP;
+        if (g2 != g) loadW(st, g2, wf[g2 & 1]);
+        loadA(st, g2, ip2, af[(u + 1) & 1]);
+      }
+      // pin "next unit's ds_reads, then this unit's 12 MFMAs": left alone, hipcc sinks the reads to just before their
+      // first use (fewer live registers) and every unit then starts with an exposed LDS round trip
+      __builtin_amdgcn_sched_barrier(0);
+      mma(af[u & 1], wf[g & 1], ip);
+      __builtin_amdgcn_sched_barrier(0);
+    }
+    stage = stage + 1 == NSTAGE ? 0 : stage + 1;
+    nstage = nstage + 1 == NSTAGE ? 0 : nstage + 1;
+  }
+
+  // ---- epilogue.  D^T layout: lane -> token (lane & 31) of each token tile; accumulator quad q of channel tile j holds
+  // channels j*32 + 8q + 4*(lane >> 5) + 0..3.
+  const int mrow = m0 + wm * (BM / WM) + (lane & 31);
+  const int nb = n0 + wn * (BN / WN) + 4 * hsel;
+  f32x4 bq[TN][4];
+#pragma unroll
+  for (int j = 0; j < TN; ++j)
+#pragma unroll
+    for (int q = 0; q < 4; ++q)
+      bq[j][q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + j * 32 + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+  const float osc = a.oscale;
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    const int m = mrow + i * 32;
+    const bool ok = m < a.M;
+    f32x4 rq[TN][4];
+    if constexpr (RES) {
+      const float* __restrict__ Rr = a.res + (long long)(ok ? m : 0) * a.ldr + a.res_coff + nb;
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+#pragma unroll
+        for (int q = 0; q < 4; ++q) rq[j][q] = *reinterpret_cast<const f32x4*>(Rr + j * 32 + q * 8);
+    }
+    unsigned char* __restrict__ Yr = a.y + ((long long)(ok ? m : 0) * a.ldo + a.out_coff) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        float v[4];
+#pragma unroll
+        for (int c = 0; c < 4; ++c) {
+          float t = acc[i][j][q * 4 + c] * osc + bq[j][q][c];
+          if constexpr (ACT == OMNI_ACT_GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
+          else if constexpr (ACT == OMNI_ACT_SILU) t = t / (1.0f + expf(-t));
+          if constexpr (RES) t += rq[j][q][c];
+          v[c] = t;
+        }
+        const int n = nb + j * 32 + q * 8;
+        if (ok) {
+          if constexpr (OSPLIT) {
+            uint2 hi, lo;
+            omni_split4(v, hi, lo);
+            unsigned char* p = Yr + omni_split_off(n);
+            *reinterpret_cast<uint2*>(p) = hi;
+            *reinterpret_cast<uint2*>(p + 32) = lo;
+          } else {
+            *reinterpret_cast<f32x4*>(Yr + n * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          }
+        }
+      }
+  }
+#endif
+}
+
+// f32 -> format B, elementwise over a channel slice of a token matrix (in place when x == y): used where a producer does
+// not emit the split format itself (attention outputs, projector input).  One thread per 16-channel group.
+__global__ __launch_bounds__(256) void split_convert_kernel(const float* __restrict__ x, unsigned char* __restrict__ y, long long rows,
+                                                            int C, int ldi, int in_coff, int ldo, int out_coff) {
+  const int gpr = C / 16;
+  const long long idx = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  if (idx >= rows * gpr) return;
+  const long long r = idx / gpr;
+  const int g = (int)(idx - r * gpr);
+  const float* src = x + r * ldi + in_coff + g * 16;
+  f32x4 v[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) v[q] = *reinterpret_cast<const f32x4*>(src + q * 4);
+  uint2 hi[4], lo[4];
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    float t[4] = {v[q][0], v[q][1], v[q][2], v[q][3]};
+    omni_split4(t, hi[q], lo[q]);
+  }
+  unsigned char* dst = y + (r * ldo + out_coff + g * 16) * 4;
+  *reinterpret_cast<u32x4*>(dst) = u32x4{hi[0].x, hi[0].y, hi[1].x, hi[1].y};
+  *reinterpret_cast<u32x4*>(dst + 16) = u32x4{hi[2].x, hi[2].y, hi[3].x, hi[3].y};
+  *reinterpret_cast<u32x4*>(dst + 32) = u32x4{lo[0].x, lo[0].y, lo[1].x, lo[1].y};
+  *reinterpret_cast<u32x4*>(dst + 48) = u32x4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
+}
+
+template <int BM, int BN, int WM, int WN, int NSTAGE>
+int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
+  a.mtiles = (a.M + BM - 1) / BM;
+  a.ntiles = a.N / BN;
+  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
+  a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
+  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
+  const bool res = a.res != nullptr;
+  if (act == OMNI_ACT_NONE && !osplit && !res)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false>), grid, block, 0, s, a);
+  else if (act == OMNI_ACT_NONE && !osplit && res)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, true>), grid, block, 0, s, a);
+  else if (act == OMNI_ACT_NONE && osplit && !res)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, true, false>), grid, block, 0, s, a);
+  else if (act == OMNI_ACT_GELU && osplit && !res)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_GELU, true, false>), grid, block, 0, s, a);
+  else if (act == OMNI_ACT_GELU && !osplit && !res)
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_GELU, false, false>), grid, block, 0, s, a);
+  else {
+    omni_set_error("gemm_dma: unsupported epilogue (act %d, split out %d, residual %d)", act, osplit, (int)res);
+    return OMNI_E_ARG;
+  }
+  return OMNI_OK;
+}
+
+}  // namespace
+
+// OMNI_OP_CONV with i20 == 2 (see include/omni_amd.h): pointwise, pre-split operands.
+int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s) {
+  GemmArgs a;
+  a.x = (const unsigned char*)op->p[0]; a.w = (const unsigned char*)op->p[1]; a.bias = (const float*)op->p[2];
+  a.res = (const float*)op->p[3]; a.y = (unsigned char*)op->p[4];
+  const int B = op->i[0], H = op->i[1], W = op->i[2];
+  a.K = op->i[3]; a.ldi = op->i[4]; a.in_coff = op->i[5];
+  a.N = op->i[12]; a.ldo = op->i[13]; a.out_coff = op->i[14];
+  const int act = op->i[15];
+  a.ldr = op->i[16]; a.res_coff = op->i[17];
+  const int osplit = op->i[21];
+  a.oscale = op->f[1] != 0.0f ? op->f[1] : 1.0f;
+  OMNI_REQUIRE(op->dtype == OMNI_F32, "gemm_dma: f32 plans only");
+  OMNI_REQUIRE(a.x && a.w && a.y, "gemm_dma: null pointer");
+  OMNI_REQUIRE(op->i[6] == 1 && op->i[7] == 1 && op->i[8] == 1 && op->i[9] == 0 && op->i[10] == H && op->i[11] == W,
+               "gemm_dma: pointwise layers only");
+  OMNI_REQUIRE(op->f[0] == 0.0f, "gemm_dma: output scale is not supported");
+  const long long M = (long long)B * H * W;
+  OMNI_REQUIRE(M > 0 && M < (1ll << 31), "gemm_dma: bad M");
+  a.M = (int)M;
+  OMNI_REQUIRE(a.K >= 32 && a.K % 32 == 0 && a.N % 128 == 0, "gemm_dma: needs K %% 32 == 0 and N %% 128 == 0 (K %d, N %d)", a.K, a.N);
+  OMNI_REQUIRE(a.ldi % 16 == 0 && a.in_coff % 16 == 0, "gemm_dma: split input needs 16-channel aligned ld / offset (%d, %d)", a.ldi, a.in_coff);
+  OMNI_REQUIRE(a.ldo % 4 == 0 && a.out_coff % 4 == 0 && (!osplit || (a.ldo % 16 == 0 && a.out_coff % 16 == 0)), "gemm_dma: output alignment");
+  OMNI_REQUIRE(!a.res || (a.ldr % 4 == 0 && a.res_coff % 4 == 0), "gemm_dma: residual alignment");
+  OMNI_REQUIRE((long long)a.ldi * 4 * 256 < (1ll << 31) && (long long)a.K * 4 * 256 < (1ll << 31), "gemm_dma: row stride too large");
+  a.nk = a.K / 32;
+  // tile choice: 256x256 (one 8-wave block per CU, 128x64 per wave) when N allows; 256x128 otherwise.  OMNI_GEMM_TILE
+  // (256x256 | 256x128 | 128x128) is the A/B knob of tools/gemm_bench.py.
+  int tile = (a.N % 256 == 0) ? 0 : 1;
+  if (const char* e = getenv("OMNI_GEMM_TILE")) {
+    if (!strcmp(e, "256x128")) tile = 1;
+    else if (!strcmp(e, "128x128")) tile = 2;
+    else if (!strcmp(e, "256x256") && a.N % 256 == 0) tile = 0;
+  }
+  int rc;
+  if (tile == 0) rc = launch_tile<256, 256, 2, 4, 2>(a, act, osplit, s);
+  else if (tile == 1) rc = launch_tile<256, 128, 4, 2, 3>(a, act, osplit, s);
+  else rc = launch_tile<128, 128, 2, 2, 2>(a, act, osplit, s);
+  if (rc) return rc;
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+// OMNI_OP_SPLIT_CONVERT: f32 channel slice -> format B (in place allowed).
+int omni_launch_split_convert(const omni_op_t* op, hipStream_t s) {
+  const long long rows = (long long)op->i[0] * (op->i[1] > 0 ? op->i[1] : 1);
+  const int C = op->i[3], ldi = op->i[4], in_coff = op->i[5], ldo = op->i[13], out_coff = op->i[14];
+  OMNI_REQUIRE(op->dtype == OMNI_F32 && op->p[0] && op->p[4], "split_convert: f32 plans, non-null pointers");
+  OMNI_REQUIRE(rows > 0 && C > 0 && C % 16 == 0 && ldi % 16 == 0 && in_coff % 16 == 0 && ldo % 16 == 0 && out_coff % 16 == 0,
+               "split_convert: 16-channel alignment (C %d, ld %d/%d, off %d/%d)", C, ldi, ldo, in_coff, out_coff);
+  const long long total = rows * (C / 16);
+  hipLaunchKernelGGL(split_convert_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, (const float*)op->p[0],
+                     (unsigned char*)op->p[4], rows, C, ldi, in_coff, ldo, out_coff);
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}

@@ -45,8 +45,27 @@ template <> struct ElemTraits<half_t> {
   static __host__ __device__ __forceinline__ half_t from_f32(float v) { return (half_t)v; }
 };
 
+// "Format B" split of 4 consecutive channels: x = hi + lo, hi = f16(x) (rtz), lo = f16(x - hi), |x| clamped to the f16 range.
+// A 16-channel group occupies 64 bytes: 16 hi halves then 16 lo halves (gemm_dma.hip consumes it by LDS-DMA).
+__device__ __forceinline__ void omni_split4(const float* v, uint2& hi, uint2& lo) {
+  typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+  float c[4];
+#pragma unroll
+  for (int e = 0; e < 4; ++e) c[e] = __builtin_fminf(__builtin_fmaxf(v[e], -65504.0f), 65504.0f);
+  hv2 h01 = __builtin_amdgcn_cvt_pkrtz(c[0], c[1]);
+  hv2 h23 = __builtin_amdgcn_cvt_pkrtz(c[2], c[3]);
+  hv2 l01 = __builtin_amdgcn_cvt_pkrtz(c[0] - (float)h01[0], c[1] - (float)h01[1]);
+  hv2 l23 = __builtin_amdgcn_cvt_pkrtz(c[2] - (float)h23[0], c[3] - (float)h23[1]);
+  hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
+  lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
+}
+// byte offset of channel c (c % 4 == 0) inside a split row: hi halves; the lo halves sit 32 bytes further
+__device__ __forceinline__ int omni_split_off(int c) { return (c >> 4) * 64 + (c & 15) * 2; }
+
 // per-kind launchers (each lives in its own .hip file)
 int omni_launch_conv(const omni_op_t* op, hipStream_t s);
+int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s);
+int omni_launch_split_convert(const omni_op_t* op, hipStream_t s);
 int omni_launch_avgpool2(const omni_op_t* op, hipStream_t s);
 int omni_launch_maxpool(const omni_op_t* op, hipStream_t s);
 int omni_launch_resize_nearest(const omni_op_t* op, hipStream_t s);

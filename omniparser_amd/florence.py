@@ -107,11 +107,16 @@ class _CaptionPlans:
         V = pb.V
         wc = cap._wcache
 
-        def packed(key, make):
-            ck = (key, dt)
+        # f32 plans run the encode-side linear layers on the pre-split LDS-DMA GEMM (csrc/gemm_dma.hip): weights in format B,
+        # inputs written pre-split by their producers.  OMNI_GEMM_DMA=0 keeps every layer on the register-staged kernels.
+        use_dma = dt == L.F32 and pb.split and os.environ.get("OMNI_GEMM_DMA", "1") != "0"
+        self.use_dma = use_dma
+
+        def packed(key, make, dma=False):
+            ck = (key, dt, "dma") if dma else (key, dt)
             if ck not in wc:
                 wt, b = make()
-                wc[ck] = (pb.pack_weight(wt if wt.dim() == 4 else wt[:, :, None, None]),
+                wc[ck] = (pb.pack_weight_dma(wt) if dma else pb.pack_weight(wt if wt.dim() == 4 else wt[:, :, None, None]),
                           pb.upload(b.float()) if b is not None else None)
             return wc[ck]
 
@@ -122,22 +127,40 @@ class _CaptionPlans:
             return wc[ck]
 
         def tokens(v: View) -> View:
-            return View(v.t.view(v.B, v.H * v.W, 1, v.ld), v.coff, v.C)
+            return View(v.t.view(v.B, v.H * v.W, 1, v.ld), v.coff, v.C, v.fmt)
 
-        def linear(key, x: View, out: View, act=L.ACT_NONE, res=None, bias=True, keys=None):
+        def linear(key, x: View, out: View, act=L.ACT_NONE, res=None, bias=True, keys=None, out_split=False):
+            """nn.Linear.  With the LDS-DMA GEMM an f32 input is converted to format B IN PLACE first (callers only pass
+            tensors whose f32 content nobody else reads); out_split: the epilogue writes format B for the next GEMM."""
             keys = keys or [key]
             def make():
                 wt = torch.cat([sd[k + ".weight"] for k in keys], 0)
                 b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
                 return wt, b
-            wp, bp = packed("|".join(keys), make)
-            return pb.conv(tokens(x), wp, bp, tokens(out), 1, act=act, res=tokens(res) if res is not None else None)
+            n_out, k_in = out.C, x.C
+            dma = use_dma and n_out % 128 == 0 and k_in % 32 == 0 and x.ld % 16 == 0 and x.coff % 16 == 0
+            wp, bp = packed("|".join(keys), make, dma=dma)
+            if dma and x.fmt != "split":
+                pb.split_convert(x)
+            xt, ot = tokens(x), tokens(out)
+            pb.conv(xt, wp, bp, ot, 1, act=act, res=tokens(res) if res is not None else None, out_split=dma and out_split)
+            out.fmt = ot.fmt
+            return out
 
-        def layernorm(key, x: View, out: View, add=None, period=0, eps=1e-5):
+        def layernorm(key, x: View, out: View, add=None, period=0, eps=1e-5, split=None):
+            """split=None: f32 output; split=out: write format B instead (the only consumer is an LDS-DMA GEMM);
+            split=<other View>: f32 into `out` AND format B into that view (post-LN rows that are also a residual)."""
             rows = x.B * x.H * x.W
+            omode, y2 = 0, None
+            if use_dma and split is not None and x.C % 16 == 0:
+                omode, y2 = (1, None) if split is out else (2, split)
             pb.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[x.ptr, add.data_ptr() if add is not None else None,
-                                                      f32(key + ".weight").data_ptr(), f32(key + ".bias").data_ptr(), out.ptr],
-                                i={0: rows, 1: 1, 3: x.C, 5: period}, f={0: eps}))
+                                                      f32(key + ".weight").data_ptr(), f32(key + ".bias").data_ptr(), out.ptr,
+                                                      y2.ptr if y2 is not None else None],
+                                i={0: rows, 1: 1, 3: x.C, 5: period, 6: omode}, f={0: eps}))
+            out.fmt = "split" if omode == 1 else "f32"
+            if y2 is not None:
+                y2.fmt = "split"
             return out
 
         def dwconv(key, x: View, out: View):
@@ -157,7 +180,7 @@ class _CaptionPlans:
             """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
             if not fuse_dwln:
                 dwconv(conv_key, x, y1)
-                return layernorm(norm_key, y1, hout)
+                return layernorm(norm_key, y1, hout, split=hout)      # hbuf only feeds qkv / fc1
             ck = (conv_key, dt)
             if ck not in wc:
                 wt = sd[conv_key + ".weight"]
@@ -168,6 +191,7 @@ class _CaptionPlans:
                                 p=[x.ptr, wp.data_ptr(), bp.data_ptr(), hout.ptr, y1.ptr,
                                    f32(norm_key + ".weight").data_ptr(), f32(norm_key + ".bias").data_ptr()],
                                 i={0: x.B, 1: x.H, 2: x.W, 3: x.C}, f={0: 1e-5}))
+            hout.fmt = "f32"
             return hout
 
         # ---------------- input + vision tower
@@ -219,14 +243,16 @@ class _CaptionPlans:
                             i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
                                11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s]},
                             f={0: (C // w.heads[s]) ** -0.5}))
+                        att.fmt = "f32"
                         linear(pre + "window_attn.proj", att, B_, res=B_)
                     else:
                         linear(pre + "channel_attn.qkv", hbuf, qkv)
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
                                             i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens}))
+                        att.fmt = "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
-                    linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU)
+                    linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU, out_split=True)
                     linear(pre + "ffn.fc2", ffn, A_, res=A_)
             x = A_
         self.vision_out = x
@@ -272,7 +298,9 @@ class _CaptionPlans:
         encpos = wc[ck]
         pb.keep.append(encpos)
         xa = pb.alloc(B, S, 1, D)
-        layernorm(lm + "encoder.layernorm_embedding", enc, xa, add=encpos, period=S)
+        xs = pb.alloc(B, S, 1, D) if use_dma else None       # format-B twin of xa (xa itself stays f32: it is the residual)
+        layernorm(lm + "encoder.layernorm_embedding", enc, xa, add=encpos, period=S, split=xs)
+        xin = xs if use_dma else xa
         qkv = pb.alloc(B, S, 1, 3 * D)
         att = pb.alloc(B, S, 1, D)
         tmp = pb.alloc(B, S, 1, D)
@@ -280,22 +308,23 @@ class _CaptionPlans:
         nh = w.n_heads
         for l in range(w.enc_layers):
             pre = f"{lm}encoder.layers.{l}."
-            linear(None, xa, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
+            linear(None, xin, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
             pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
                                 i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
                                    12: 0, 15: 64}, f={0: 64 ** -0.5}))
+            att.fmt = "f32"
             linear(pre + "self_attn.out_proj", att, tmp, res=xa)
-            layernorm(pre + "self_attn_layer_norm", tmp, xa)
-            linear(pre + "fc1", xa, ffn, act=L.ACT_GELU)
+            layernorm(pre + "self_attn_layer_norm", tmp, xa, split=xs)
+            linear(pre + "fc1", xin, ffn, act=L.ACT_GELU, out_split=True)
             linear(pre + "fc2", ffn, tmp, res=xa)
-            layernorm(pre + "final_layer_norm", tmp, xa)
+            layernorm(pre + "final_layer_norm", tmp, xa, split=xs)
         self.enc_out = xa
         # ---------------- cross-attention K/V of every decoder layer (computed once per batch)
         self.cross_kv = []
         for l in range(w.dec_layers):
             pre = f"{lm}decoder.layers.{l}.encoder_attn."
             kv = pb.alloc(B, S, 1, 2 * D)
-            linear(None, xa, kv, keys=[pre + "k_proj", pre + "v_proj"])
+            linear(None, xin, kv, keys=[pre + "k_proj", pre + "v_proj"])
             self.cross_kv.append(kv)
         self.n_encode_ops = len(pb.ops)
         self.encode_flops = pb.flops

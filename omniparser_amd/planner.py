@@ -3,6 +3,7 @@
 Tensors are NHWC.  A `View` is a channel slice [coff, coff+C) of a buffer with `ld` channels per
 pixel, so chunk/concat/split never copy: producers write into slices, consumers read slices.
 """
+import math
 import os
 from dataclasses import dataclass
 from typing import Optional
@@ -25,6 +26,8 @@ class View:
     t: torch.Tensor          # [B, H, W, ld]
     coff: int
     C: int
+    fmt: str = "f32"         # "f32" | "split": what the bytes hold right now (f32 plans only; set by the producing op).
+                             # "split" = format B of csrc/gemm_dma.hip: per 16 channels 16 hi halves then 16 lo halves.
 
     @property
     def B(self): return self.t.shape[0]
@@ -39,7 +42,7 @@ class View:
 
     def slice(self, off, c):
         assert 0 <= off and off + c <= self.C, (off, c, self.C)
-        return View(self.t, self.coff + off, c)
+        return View(self.t, self.coff + off, c, self.fmt)
 
     def torch(self):
         """Materialise as a torch NCHW float tensor (tests / debugging)."""
@@ -56,7 +59,6 @@ class PlanBuilder:
         # f32 plans run their long-K GEMMs on the split-f16 MFMA path (f32-class accuracy at the f16 matrix rate;
         # measured error vs f64 <= the exact-f32 MFMA path).  OMNI_CONV_SPLIT=0 selects v_mfma_f32_32x32x2_f32 everywhere.
         self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
-        self.split_weights = set()
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
         self.flops = 0           # 2*MAC of all conv ops (algorithmic work, for the roofline)
@@ -90,6 +92,30 @@ class PlanBuilder:
         lo = ((w2d - hi.float()) * 2048.0).to(torch.float16)
         return torch.cat([hi.view(cout, K // 16, 16), lo.view(cout, K // 16, 16)], -1).contiguous()
 
+    @staticmethod
+    def split_f16_b(w2d: torch.Tensor):
+        """[Cout, K] f32 -> (f16 [Cout, K/16, 32], 2^-k): "format B" of csrc/gemm_dma.hip.  W' = W * 2^k with the largest
+        |W'| in [2^12, 2^13) so that the lo parts of all but vanishing weights are normal f16 numbers; per 16-wide K block
+        16 hi halves then 16 lo halves with W' = hi + lo (lo NOT rescaled: one accumulator takes all three products)."""
+        cout, K = w2d.shape
+        assert K % 16 == 0
+        w2d = w2d.double()
+        amax = float(w2d.abs().max())
+        k = 0 if amax == 0.0 else 12 - math.floor(math.log2(amax))
+        k = max(-24, min(24, k))
+        ws = (w2d * (2.0 ** k)).float()
+        hi = ws.to(torch.float16)
+        lo = (ws - hi.float()).to(torch.float16)
+        return torch.cat([hi.view(cout, K // 16, 16), lo.view(cout, K // 16, 16)], -1).contiguous(), 2.0 ** -k
+
+    def pack_weight_dma(self, w: torch.Tensor) -> torch.Tensor:
+        """[Cout, Cin] or [Cout, Cin, 1, 1] f32 -> device format-B weight for the pre-split LDS-DMA GEMM (f32 plans)."""
+        w2d = w.detach().float().reshape(w.shape[0], -1)
+        t, oscale = self.split_f16_b(w2d)
+        t = self.upload(t)
+        t.omni_fmt, t.omni_oscale = 2, oscale
+        return t
+
     def pack_weight(self, w: torch.Tensor, cin_pad: Optional[int] = None) -> torch.Tensor:
         """[Cout, Cin, kh, kw] f32 -> device [Cout, kh*kw*Cin'] in plan dtype (k = (r*kw+s)*Cin'+c)."""
         w = w.detach().float()
@@ -100,25 +126,33 @@ class PlanBuilder:
         cin_eff = max(cin, cin_pad or 0)
         if self.split and self.dtype == L.F32 and cin_eff % 32 == 0 and cin_eff * kh * kw >= 128:
             t = self.upload(self.split_f16(w))
-            self.split_weights.add(t.data_ptr())
+            t.omni_fmt = 1
             return t
         return self.upload(w.to(torch_dtype(self.dtype)))
 
     # ---- ops
     def conv(self, x: View, w_packed: torch.Tensor, bias: Optional[torch.Tensor], out: View, k: int, s: int = 1,
-             p: Optional[int] = None, act: int = L.ACT_NONE, res: Optional[View] = None, scale: float = 0.0):
+             p: Optional[int] = None, act: int = L.ACT_NONE, res: Optional[View] = None, scale: float = 0.0,
+             out_split: bool = False):
         p = k // 2 if p is None else p
         Ho = (x.H + 2 * p - k) // s + 1
         Wo = (x.W + 2 * p - k) // s + 1
         assert (out.B, out.H, out.W) == (x.B, Ho, Wo), ((out.B, out.H, out.W), (x.B, Ho, Wo))
         cout = out.C
-        is_split = w_packed.dtype == torch.float16 and self.dtype == L.F32
-        if is_split:
-            assert w_packed.numel() == 2 * cout * k * k * x.C and x.C % 32 == 0, (tuple(w_packed.shape), cout, k, x.C)
+        wfmt = getattr(w_packed, "omni_fmt", 0) if self.dtype == L.F32 else 0     # 0 plain, 1 split (in-loop), 2 format B (LDS-DMA GEMM)
+        if wfmt:
+            assert w_packed.dtype == torch.float16 and w_packed.numel() == 2 * cout * k * k * x.C and x.C % 32 == 0, \
+                (tuple(w_packed.shape), cout, k, x.C)
         else:
             assert tuple(w_packed.shape) == (cout, k * k * x.C), (tuple(w_packed.shape), cout, k, x.C)
+        if wfmt == 2:
+            assert k == 1 and s == 1 and p == 0 and scale == 0.0 and cout % 128 == 0, "format-B weights: pointwise layers, Cout % 128 == 0"
+            assert x.fmt == "split", "the LDS-DMA GEMM reads a pre-split input: its producer must emit format B (or insert split_convert)"
+            assert x.ld % 16 == 0 and x.coff % 16 == 0 and not (out_split and (res is not None or out.ld % 16 or out.coff % 16))
+        else:
+            assert x.fmt == "f32" and not out_split, "register-staged conv kernels read and write f32"
         if res is not None:
-            assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C)
+            assert (res.B, res.H, res.W, res.C) == (out.B, out.H, out.W, out.C) and res.fmt == "f32"
         b = None
         if bias is not None:
             b = bias if bias.device == self.device and bias.dtype == torch.float32 else self.upload(bias.detach().float())
@@ -133,14 +167,25 @@ class PlanBuilder:
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
-               19: self.ws_kib if self.ws is not None else 0, 20: 1 if is_split else 0},
-            f={0: scale})
+               19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0},
+            f={0: scale, 1: getattr(w_packed, "omni_oscale", 0.0) if wfmt == 2 else 0.0})
         self.ops.append(op)
         self.keep.append(w_packed)
+        out.fmt = "split" if out_split else "f32"
         M = x.B * Ho * Wo
         esz = 4 if self.dtype == L.F32 else 2
         self.flops += 2 * M * cout * k * k * x.C
-        self.bytes += esz * (x.B * x.H * x.W * x.C + w_packed.numel() + M * cout * (2 if res is not None else 1))
+        self.bytes += esz * (x.B * x.H * x.W * x.C + w_packed.numel() // (2 if wfmt else 1) + M * cout * (2 if res is not None else 1))
+        return out
+
+    def split_convert(self, x: View, out: Optional[View] = None) -> View:
+        """f32 channel slice -> format B (in place by default): for GEMM inputs whose producer does not emit the split format."""
+        out = out or x
+        assert self.dtype == L.F32 and x.fmt == "f32" and x.C % 16 == 0 and (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, x.C)
+        self.ops.append(L.make_op(L.OP_SPLIT_CONVERT, self.dtype, p=[x.ptr, None, None, None, out.ptr],
+                                  i={0: x.B * x.H * x.W, 1: 1, 3: x.C, 4: x.ld, 5: x.coff, 13: out.ld, 14: out.coff}))
+        self.bytes += 8 * x.B * x.H * x.W * x.C
+        out.fmt = "split"
         return out
 
     def _pool(self, kind, x: View, out: View, k=0, s=1, p=0, accumulate=0):

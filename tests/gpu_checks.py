@@ -107,6 +107,96 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
     return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), e) for c, e in details]}
 
 
+
+# ------------------------------------------------------------------------------------------ pre-split LDS-DMA GEMM
+GEMM_DMA_CASES = [
+    # M, K, N, in_ld, in_off, out_ld, out_off, res, act, out_split
+    (300, 128, 128, 128, 0, 128, 0, False, L.ACT_NONE, False),        # ragged M inside one tile, 256x128 tile
+    (1000, 512, 384, 512, 0, 384, 0, True, L.ACT_NONE, False),        # N = 3 x 128
+    (777, 512, 2048, 512, 0, 2048, 0, False, L.ACT_GELU, True),       # fc1: GELU, format-B output, 256x256 tile
+    (2304, 2048, 512, 2048, 0, 512, 0, True, L.ACT_NONE, False),      # fc2: long K + residual
+    (513, 32, 256, 64, 32, 512, 256, False, L.ACT_NONE, False),       # single K slice, channel-slice in/out
+    (20000, 768, 768, 768, 0, 768, 0, True, L.ACT_NONE, False),       # >= 64 row tiles: XCD-aware order, 3 N tiles
+    (70000, 256, 1024, 256, 0, 1024, 0, False, L.ACT_GELU, True),     # many tiles, split out
+    (5, 1024, 768, 1024, 0, 768, 0, False, L.ACT_NONE, False),        # tiny M (captioner tests at B = 2)
+]
+
+
+def check_gemm_dma(seed=0, cases=None, tiles=(None, "256x128", "128x128")):
+    """csrc/gemm_dma.hip through OMNI_OP_CONV i20 = 2 vs an f64 matmul of the SAME (decoded) operands, every tile
+    configuration; format-B outputs are decoded with the test interpreter's reader.  Also checks the producers:
+    split_convert (in place) and LayerNorm's split / dual outputs against the interpreter's encoder (bitwise)."""
+    import os
+    from plan_interp import split_decode, split_encode
+    g = torch.Generator().manual_seed(seed)
+    worst = 0.0
+    details = []
+    for case in (cases or GEMM_DMA_CASES):
+        M, K, N, ild, ioff, old, ooff, use_res, act, osplit = case
+        x = torch.randn(M, K, generator=g) * (1.0 if case[0] % 2 else 3.0)
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g) if use_res else None
+        xbuf = torch.randn(M, ild)
+        xbuf[:, ioff:ioff + K] = x
+        for tile in tiles:
+            pb = PlanBuilder(DEV, L.F32)
+            xv = View(xbuf.clone().view(1, M, 1, ild).to(DEV), ioff, K)
+            pb.split_convert(xv)                                              # in place, only the slice
+            ov = View(torch.full((1, M, 1, old), 7.0, device=DEV), ooff, N)
+            rv = View(torch.cat([torch.randn(M, 16), res], 1).view(1, M, 1, N + 16).to(DEV), 16, N) if use_res else None
+            wp = pb.pack_weight_dma(w)
+            pb.conv(xv, wp, b, ov, 1, act=act, res=rv, out_split=osplit)
+            if tile:
+                os.environ["OMNI_GEMM_TILE"] = tile
+            try:
+                for op in pb.ops:
+                    L.launch(op)
+                _sync()
+            finally:
+                os.environ.pop("OMNI_GEMM_TILE", None)
+            # operands exactly as the kernel sees them
+            xs = xv.t.view(M, ild).cpu()
+            assert torch.equal(xs[:, :ioff], xbuf[:, :ioff]) and torch.equal(xs[:, ioff + K:], xbuf[:, ioff + K:]), "split_convert left its slice"
+            assert torch.equal(xs[:, ioff:ioff + K].contiguous().view(torch.uint8), split_encode(x).view(torch.uint8)), f"split_convert bits: {case}"
+            xd = split_decode(xs[:, ioff:ioff + K].contiguous()).double()
+            wd = split_decode(wp.cpu().view(torch.float32).view(N, K)).double() * wp.omni_oscale
+            assert (wd - w.double()).abs().max() <= 2.0 ** -21 * w.abs().max()
+            ref = xd @ wd.t() + b.double()
+            if act == L.ACT_GELU:
+                ref = F.gelu(ref)
+            if use_res:
+                ref = ref + res.double()
+            full = ov.t.view(M, old).cpu()
+            got = full[:, ooff:ooff + N].contiguous()
+            got = split_decode(got).double() if osplit else got.double()
+            e = rel_err(got, ref)
+            mask = torch.ones(old, dtype=torch.bool); mask[ooff:ooff + N] = False
+            assert (full[:, mask] == 7.0).all(), f"gemm_dma wrote outside its channel slice: {case}"
+            tol = 2e-6
+            details.append((case, tile, e))
+            assert e < tol, f"gemm_dma case {case} tile {tile}: rel err {e:.3e} >= {tol}"
+            worst = max(worst, e)
+    # LayerNorm producers: split-only and dual outputs are the format-B encoding of the f32 output, bit for bit
+    for rows, C in ((1000, 128), (513, 256), (300, 512), (77, 768), (64, 1024)):
+        x = torch.randn(rows, C, generator=g) * 2 + 0.3
+        gm, bt = torch.randn(C, generator=g), torch.randn(C, generator=g)
+        outs = {}
+        for omode in (0, 1, 2):
+            xd = x.to(DEV); y = torch.zeros(rows, C, device=DEV); y2 = torch.zeros(rows, C, device=DEV)
+            gd, bd = gm.to(DEV), bt.to(DEV)
+            L.launch(L.make_op(L.OP_LAYERNORM, L.F32, p=[xd.data_ptr(), None, gd.data_ptr(), bd.data_ptr(), y.data_ptr(), y2.data_ptr()],
+                               i={0: rows, 1: 1, 3: C, 5: 0, 6: omode}, f={0: 1e-5}))
+            _sync()
+            outs[omode] = (y.cpu(), y2.cpu())
+        ref = F.layer_norm(x.double(), (C,), gm.double(), bt.double(), 1e-5)
+        assert rel_err(outs[0][0].double(), ref) < 4e-6
+        enc = split_encode(outs[0][0]).view(torch.uint8)
+        assert torch.equal(outs[1][0].view(torch.uint8), enc), f"LayerNorm split output ({rows}x{C})"
+        assert torch.equal(outs[2][0], outs[0][0]) and torch.equal(outs[2][1].view(torch.uint8), enc), f"LayerNorm dual output ({rows}x{C})"
+    return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), t, e) for c, t, e in details]}
+
+
 def check_mfma_layout():
     """A = I-like probe with asymmetric W: catches transposed / permuted MFMA fragment maps."""
     out = {}

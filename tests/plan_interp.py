@@ -39,6 +39,34 @@ class Mem:
         return flat[: n * torch.empty((), dtype=dt).element_size()].view(dt)
 
 
+
+# ---- "format B" (csrc/gemm_dma.hip): per 16 channels 64 bytes = 16 hi halves then 16 lo halves, value = hi + lo
+def _rtz_f16(x: torch.Tensor) -> torch.Tensor:
+    """f32 -> f16 rounding toward zero (v_cvt_pkrtz_f16_f32), input already clamped to the f16 range."""
+    h = x.to(torch.float16)
+    bits = h.view(torch.int16).clone()
+    over = h.float().abs() > x.abs()
+    bits[over] -= 1                      # one ulp toward zero (sign-magnitude encoding)
+    return bits.view(torch.float16)
+
+
+def split_encode(x: torch.Tensor) -> torch.Tensor:
+    """[rows, C] f32 (C % 16 == 0) -> [rows, C] f32-typed buffer holding format B."""
+    rows, C = x.shape
+    x = x.float().clamp(-65504.0, 65504.0)
+    hi = _rtz_f16(x)
+    lo = _rtz_f16(x - hi.float())
+    out = torch.cat([hi.view(rows, C // 16, 16), lo.view(rows, C // 16, 16)], -1).contiguous()
+    return out.view(rows, 2 * C).view(torch.float32)
+
+
+def split_decode(buf: torch.Tensor) -> torch.Tensor:
+    """inverse view: [rows, C] f32-typed buffer in format B -> f32 values."""
+    rows, C = buf.shape
+    hl = buf.contiguous().view(torch.float16).view(rows, C // 16, 2, 16).float()
+    return (hl[:, :, 0] + hl[:, :, 1]).reshape(rows, C)
+
+
 def _tdt(op):
     return torch.float32 if op.dtype == L.F32 else torch.float16
 
@@ -53,7 +81,29 @@ def run_op(op, m):
     i, p, f = op.i, op.p, op.f
     dt = _tdt(op)
     k = op.kind
-    if k == L.OP_CONV:
+    if k == L.OP_CONV and i[20] == 2:
+        # pre-split LDS-DMA GEMM: x and w in format B, optional format-B output
+        B, H, W, Cin, ldi, icoff = [i[j] for j in range(6)]
+        Cout, ldo, ocoff, act, ldr, rcoff = [i[j] for j in range(12, 18)]
+        M = B * H * W
+        x = split_decode(m.at(p[0], torch.float32)[: M * ldi].view(M, ldi)[:, icoff:icoff + Cin])
+        w = split_decode(m.at(p[1], torch.float16)[: 2 * Cout * Cin].view(torch.float32).view(Cout, Cin)) * f[1]
+        y = x @ w.t()
+        if p[2]:
+            y = y + m.at(p[2], torch.float32)[:Cout]
+        if act == L.ACT_GELU:
+            y = F.gelu(y)
+        elif act == L.ACT_SILU:
+            y = F.silu(y)
+        if p[3]:
+            y = y + m.at(p[3], torch.float32)[: M * ldr].view(M, ldr)[:, rcoff:rcoff + Cout]
+        out = m.at(p[4], torch.float32)[: M * ldo].view(M, ldo)
+        out[:, ocoff:ocoff + Cout] = split_encode(y) if i[21] else y
+    elif k == L.OP_SPLIT_CONVERT:
+        rows, C, ldi, icoff, ldo, ocoff = i[0] * max(i[1], 1), i[3], i[4], i[5], i[13], i[14]
+        x = m.at(p[0], torch.float32)[: rows * ldi].view(rows, ldi)[:, icoff:icoff + C].clone()
+        m.at(p[4], torch.float32)[: rows * ldo].view(rows, ldo)[:, ocoff:ocoff + C] = split_encode(x)
+    elif k == L.OP_CONV:
         B, H, W, Cin, ldi, icoff, KH, KW, s, pad, Ho, Wo, Cout, ldo, ocoff, act, ldr, rcoff = [i[j] for j in range(18)]
         x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi)[..., icoff:icoff + Cin].permute(0, 3, 1, 2).float()
         if i[20]:
@@ -110,7 +160,12 @@ def run_op(op, m):
             add = m.at(p[1], dt)[: period * C].view(period, C).float()
             x = x + add.repeat(rows // period, 1)
         y = F.layer_norm(x, (C,), m.at(p[2], torch.float32)[:C], m.at(p[3], torch.float32)[:C], f[0])
-        m.at(p[4], dt)[: rows * C].view(rows, C).copy_(y.to(dt))
+        if i[6] == 1:
+            m.at(p[4], dt)[: rows * C].view(rows, C).copy_(split_encode(y))
+        else:
+            m.at(p[4], dt)[: rows * C].view(rows, C).copy_(y.to(dt))
+            if i[6] == 2:
+                m.at(p[5], dt)[: rows * C].view(rows, C).copy_(split_encode(y))
     elif k == L.OP_ATTN_ROWS:
         ldq, ldk, ldv, ldo, qoff, koff, voff, ooff, heads, nq, nk, groups, mode, H, W, D = [i[j] for j in range(16)]
         scale = f[0]

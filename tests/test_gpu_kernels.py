@@ -27,6 +27,13 @@ def test_conv_igemm_exact_f32_path(monkeypatch):
     assert r["cases"] >= 6 and r["worst_rel_err"] < 2e-5
 
 
+def test_gemm_dma_presplit():
+    """pre-split LDS-DMA GEMM (every tile configuration), split_convert and LayerNorm's format-B outputs."""
+    import gpu_checks as G
+    r = G.check_gemm_dma()
+    assert r["cases"] >= 20 and r["worst_rel_err"] < 2e-6
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])
 def test_pool_and_resize(dtype):
     import gpu_checks as G

@@ -1,7 +1,8 @@
 """Micro-benchmark of conv_igemm on the captioner's dominant GEMM shapes (HIP events, per variant).
 
-VARIANTS="f32,split:128x128:2,split:128x128:2+OMNI_XCD_NSPLIT=0,split:128x128:4" — kind[:tile[:split variant]] and
-optional +ENV=value pairs applied for that variant only.  Accuracy is checked on 2048 rows sampled over the whole
+VARIANTS="f32,split:128x128,dma,dma:256x128,dma:128x128+OMNI_XCD_NSPLIT=0" — kind[:tile] and optional +ENV=value pairs
+applied for that variant only.  kind: f32 (exact f32 MFMA), split (register-staged split-f16), dma (pre-split LDS-DMA GEMM,
+csrc/gemm_dma.hip: input converted to format B before the timed region, as its producer would have written it).  Accuracy is checked on 2048 rows sampled over the whole
 M range (a wrong block -> tile permutation would leave rows unwritten or doubly written)."""
 import os
 import sys
@@ -24,34 +25,48 @@ def main():
     dtype = L.F32 if os.environ.get("OMNI_PRECISION", "f32") == "f32" else L.F16
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     stream = torch.cuda.Stream()
-    for variant in os.environ.get("VARIANTS", "f32,split:128x64,split:128x128").split(","):
-        os.environ["OMNI_CONV_SPLIT"] = "1" if variant.startswith("split") else "0"
+    for variant in os.environ.get("VARIANTS", "split:128x128,dma,dma:256x128,dma:128x128").split(","):
+        os.environ["OMNI_CONV_SPLIT"] = "0" if variant.startswith("f32") else "1"
         variant, *envs = variant.split("+")
-        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB"):
+        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE"):
             os.environ.pop(k, None)
         for kv in envs:
             k, v = kv.split("=")
             os.environ[k] = v
         parts = variant.split(":")
+        dma = parts[0] == "dma"
         if len(parts) > 1:
-            os.environ["OMNI_SPLIT_TILE"] = parts[1]
-        os.environ["OMNI_SPLIT_VARIANT"] = parts[2] if len(parts) > 2 else "0"
+            os.environ["OMNI_GEMM_TILE" if dma else "OMNI_SPLIT_TILE"] = parts[1]
         print(f"--- variant {variant} {' '.join(envs)}")
+        only = [t for t in os.environ.get("SHAPES", "").split(",") if t]
         for name, M, N, K, act, res in SHAPES:
+            if (only and name not in only) or (dma and act == 1):
+                continue
+            torch.cuda.synchronize()
             pb = PlanBuilder("cuda", dtype)
             x = View(torch.randn(1, M, 1, K, device="cuda").to(tdt), 0, K)
+            xref = x.t.clone() if dma else x.t
             wcpu = torch.randn(N, K) * 0.05
-            w = pb.pack_weight(wcpu[:, :, None, None])
             y = pb.alloc(1, M, 1, N)
             r = View(torch.randn(1, M, 1, N, device="cuda").to(tdt), 0, N) if res else None
             bias = torch.randn(N)
-            pb.conv(x, w, bias, y, 1, act=act, res=r)
+            torch.cuda.synchronize()
+            if dma:
+                pre = PlanBuilder("cuda", dtype)
+                pre.split_convert(x)
+                pre.build().run(stream); stream.synchronize()
+                x.fmt = "split"
+                w = pb.pack_weight_dma(wcpu)
+                pb.conv(x, w, bias, y, 1, act=act, res=r, out_split=(act == 2))
+            else:
+                w = pb.pack_weight(wcpu[:, :, None, None])
+                pb.conv(x, w, bias, y, 1, act=act, res=r)
             plan = pb.build()
             plan.run(stream); stream.synchronize()
             ms = plan.time(5, stream)
             # accuracy vs f64 on rows sampled over the whole M range (incl. the first and last tiles)
             rows = torch.cat([torch.arange(128), torch.arange(M - 128, M), torch.randint(0, M, (1792,))]).cuda()
-            xs = x.t[0, rows, 0, :].double().cpu()
+            xs = xref[0, rows, 0, :].double().cpu()
             ref = xs @ wcpu.double().t()
             got = y.t[0, rows, 0, :].double().cpu()
             if act == 0 and not res:
