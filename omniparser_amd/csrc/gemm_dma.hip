@@ -24,6 +24,7 @@
 #include "omni_internal.h"
 #include "gemm_common.h"
 #include <string.h>
+#include <type_traits>
 
 namespace {
 
@@ -37,7 +38,11 @@ struct GemmArgs {
   float oscale;                       // 2^-k of the weight pre-scale
 };
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES>
+// VAR: K-loop schedule.  0 = all DMA pieces of the next slice right after the barrier, next-unit ds_reads pinned in front of
+// each unit's 12 MFMAs; 1 = DMA pieces spread over the units and ds_reads / DMA interleaved one-per-MFMA
+// (sched_group_barrier).  ABL (tools/gemm_bench.py diagnostics, results WRONG): 1 no DMA in the loop, 2 no DMA and no
+// barrier, 3 MFMA only (fragments loaded once), 4 no MFMA.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int VAR = 0, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -78,16 +83,18 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long long)m0 * a.ldi + a.in_coff) * 4), 0, 0x7fffffff, 0x00020000);
   const __amdgpu_buffer_rsrc_t rsrcB =
       __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)n0 * a.K * 4), 0, 0x7fffffff, 0x00020000);
-  auto issue = [&](int kt, int stage) {
-    unsigned char* sA = lds + stage * STAGE + (wave * A_DMA) * 1024;
-    unsigned char* sB = lds + stage * STAGE + BM * 128 + (wave * B_DMA) * 1024;
+  // piece i of slice kt into ring slot `stage` (i < A_DMA: activation rows, else weight rows)
+  auto issue_piece = [&](int kt, int stage, int i) {
     const int so = kt * 128;
+    if (i < A_DMA)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(lds + stage * STAGE + (wave * A_DMA + i) * 1024), 16, voffA[i], so, 0, 0);
+    else
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(lds + stage * STAGE + BM * 128 + (wave * B_DMA + i - A_DMA) * 1024), 16,
+                                               voffB[i - A_DMA], so, 0, 0);
+  };
+  auto issue = [&](int kt, int stage) {
 #pragma unroll
-    for (int i = 0; i < A_DMA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(sA + i * 1024), 16, voffA[i], so, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_DMA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(sB + i * 1024), 16, voffB[i], so, 0, 0);
+    for (int i = 0; i < DPS; ++i) issue_piece(kt, stage, i);
   };
 
   // ---- fragment read offsets: lane -> (row lane & 31, k half lane >> 5); chunk of (K group g, part p) = 4g + 2p + half
@@ -148,35 +155,73 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   int stage = 0, nstage = NSTAGE - 1;          // ring positions of slice kt and of slice kt + NSTAGE - 1
-  for (int kt = 0; kt < nk; ++kt) {
+  constexpr int PPU = (DPS + NU - 1) / NU;     // DMA pieces per unit (VAR 1)
+  AF af[2];
+  WF wf[2];
+  if constexpr (ABL == 3) {
+    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    __builtin_amdgcn_s_barrier();
+    loadW(lds, 0, wf[0]); loadW(lds, 1, wf[1]); loadA(lds, 0, 0, af[0]); loadA(lds, 1, 0, af[1]);
+  }
+  // One K slice.  MORE (compile time): a further slice is issued into the ring — the steady-state loop and the drain loop are
+  // separate copies so that no branch splits the scheduling region (ds_reads / DMA pieces interleave with the MFMAs).
+  auto slice = [&](int kt, auto more_tag) {
+    constexpr bool MORE = decltype(more_tag)::value && (ABL == 0 || ABL == 4);
     // slice kt landed (this wave's pieces), later slices may stay in flight; then everybody's pieces landed and everybody is
     // done reading the stage that the next DMA overwrites (it was read in iteration kt - 1)
-    if (NSTAGE > 2 && kt + NSTAGE - 2 < nk) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
-    else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
-    __builtin_amdgcn_s_barrier();
+    if constexpr (ABL != 2 && ABL != 3) {
+      if constexpr (NSTAGE > 2 && decltype(more_tag)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
+      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      __builtin_amdgcn_s_barrier();
+    }
     const unsigned char* st = lds + stage * STAGE;
-    AF af[2];
-    WF wf[2];
-    loadW(st, 0, wf[0]);
-    loadA(st, 0, 0, af[0]);
-    if (kt + NSTAGE - 1 < nk) issue(kt + NSTAGE - 1, nstage);
+    if constexpr (ABL != 3) {
+      loadW(st, 0, wf[0]);
+      loadA(st, 0, 0, af[0]);
+    }
+    if constexpr (VAR == 0 && MORE) issue(kt + NSTAGE - 1, nstage);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int g = u / NP, ip = u % NP;
-      if (u + 1 < NU) {
+      int nds = 0;
+      if (ABL != 3 && u + 1 < NU) {
         const int g2 = (u + 1) / NP, ip2 = (u + 1) % NP;
-        if (g2 != g) loadW(st, g2, wf[g2 & 1]);
+        if (g2 != g) { loadW(st, g2, wf[g2 & 1]); nds += 2 * TN; }
         loadA(st, g2, ip2, af[(u + 1) & 1]);
+        nds += 4;
       }
-      // pin "next unit's ds_reads, then this unit's 12 MFMAs": left alone, hipcc sinks the reads to just before their
-      // first use (fewer live registers) and every unit then starts with an exposed LDS round trip
-      __builtin_amdgcn_sched_barrier(0);
-      mma(af[u & 1], wf[g & 1], ip);
+      if constexpr (VAR == 1 && MORE) {
+#pragma unroll
+        for (int i = u * PPU; i < (u + 1) * PPU && i < DPS; ++i) issue_piece(kt + NSTAGE - 1, nstage, i);
+      }
+      if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);   // pin "next unit's ds_reads, then this unit's 12 MFMAs"
+      if constexpr (ABL != 4) mma(ABL == 3 ? af[g & 1] : af[u & 1], wf[g & 1], ip);
+      else {
+#pragma unroll
+        for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(af[u & 1].h[t]), "v"(af[u & 1].l[t]));
+#pragma unroll
+        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wf[g & 1].h[j]), "v"(wf[g & 1].l[j]));
+      }
+      if constexpr (VAR == 1) {
+        // one ds_read (then one DMA piece) behind each of the first MFMAs: they issue inside the 32-cycle MFMA slots
+        const int npc = MORE ? PPU : 0;
+#pragma unroll
+        for (int k = 0; k < 12; ++k) {
+          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
+          if (k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
+          else if (k < nds + npc) __builtin_amdgcn_sched_group_barrier(0x20, 1, 0);
+        }
+      }
       __builtin_amdgcn_sched_barrier(0);
     }
     stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     nstage = nstage + 1 == NSTAGE ? 0 : nstage + 1;
-  }
+  };
+  // slices with a successor to issue: kt + NSTAGE - 1 < nk.  The NSTAGE > 2 counted wait needs the full ring in flight, which
+  // holds exactly for those iterations.
+  int kt = 0;
+  for (; kt + NSTAGE - 1 < nk; ++kt) slice(kt, std::true_type{});
+  for (; kt < nk; ++kt) slice(kt, std::false_type{});
 
   // ---- epilogue.  D^T layout: lane -> token (lane & 31) of each token tile; accumulator quad q of channel tile j holds
   // channels j*32 + 8q + 4*(lane >> 5) + 0..3.
@@ -266,6 +311,20 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
+  int var = 0, abl = 0;
+  if (const char* e = getenv("OMNI_GEMM_VAR")) var = atoi(e);
+  if (const char* e = getenv("OMNI_GEMM_ABL")) abl = atoi(e);
+  if (act == OMNI_ACT_NONE && !osplit && !res && (var || abl)) {       // schedule A/B + ablations: plain epilogue only
+#define OMNI_GD(V, A) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false, V, A>), grid, block, 0, s, a)
+    if (var == 1 && abl == 0) OMNI_GD(1, 0);
+    else if (var == 0 && abl == 1) OMNI_GD(0, 1);
+    else if (var == 0 && abl == 2) OMNI_GD(0, 2);
+    else if (var == 0 && abl == 3) OMNI_GD(0, 3);
+    else if (var == 0 && abl == 4) OMNI_GD(0, 4);
+    else OMNI_GD(0, 0);
+#undef OMNI_GD
+    return OMNI_OK;
+  }
   if (act == OMNI_ACT_NONE && !osplit && !res)
     hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false>), grid, block, 0, s, a);
   else if (act == OMNI_ACT_NONE && !osplit && res)

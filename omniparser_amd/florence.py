@@ -409,8 +409,9 @@ class _CaptionPlans:
         self.step_flops = pd_.flops
         self.step_plan = pd_.build()
         self.start_token = w.start
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)      # allocations / uploads ran on the current stream: order them before cap.stream
         if cap.use_graph:
-            torch.cuda.synchronize(dev)
             self.reset()
             self.encode_plan.run(cap.stream); self.step_plan.run(cap.stream)
             cap.stream.synchronize()
@@ -454,6 +455,7 @@ class Florence2Captioner:
         self._wcache = {}
         self._plans = {}
         self.max_new_tokens = 20
+        self.early_exit_every = int(os.environ.get("OMNI_DECODE_POLL", "5"))    # 0 = always run max_new_tokens steps
         self._lut = None
         self._lock = threading.RLock()   # plans own their device buffers: one caption batch at a time per model
 
@@ -476,6 +478,7 @@ class Florence2Captioner:
             self._plans[key] = self._plans.pop(key)
             return self._plans[key]
         while len(self._plans) >= int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "6")):   # LRU bound on activation pools
+            self.stream.synchronize()                       # deferred read-backs may still be running on the evicted plan's buffers
             self._plans.pop(next(iter(self._plans)))
         with torch.cuda.device(self.device):
             self._plans[key] = _CaptionPlans(self, B, R, max_new)
@@ -485,8 +488,13 @@ class Florence2Captioner:
     def _run(self, cp: _CaptionPlans, n: int, max_new: int, defer: bool = False) -> torch.Tensor:
         run = (lambda p: p.replay(self.stream)) if self.use_graph else (lambda p: p.run(self.stream))
         run(cp.encode_plan)
-        for _ in range(max_new):
+        poll = 0 if defer else self.early_exit_every
+        for t in range(max_new):
             run(cp.step_plan)
+            # hf stops as soon as every row has emitted EOS (generation/utils.py:2936): poll the device flags every few steps
+            # (a 4-byte read-back) instead of always paying max_new steps; the deferred (batched-stream) path never syncs
+            if poll and (t + 1) % poll == 0 and t + 1 < max_new and bool(cp.finished[:n].min().item()):
+                break
         if defer:                          # stream-ordered snapshot; the caller reads it back later (no sync here)
             return cp.ids[:n].clone()
         return self._finish_ids(cp.ids[:n].cpu().long())     # synchronises the stream
@@ -549,6 +557,7 @@ class Florence2Captioner:
             if R != 64:
                 b, k = L.resample_coeffs(64, R, 1)
                 self._bic = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device), k.shape[1])
+        batch_size = max(1, min(int(batch_size), 128))      # plan capacity: buckets stop at 128 crops (the reference's default batch)
         for s in range(0, n_all, batch_size):
             boxes = boxes_px[s:s + batch_size]
             n = len(boxes)

@@ -25,7 +25,7 @@ class ScreenParser:
         self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
-        self.max_det, self.imgsz, self.batch_size = max_det, imgsz, batch_size
+        self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
@@ -82,16 +82,16 @@ class ScreenParser:
         rec.view(np.int32)[:, 6] = np.arange(n)               # stable tie-break = concatenation order (tile-major)
         dev = self.det.device
         cap_n = max(n, 1)
-        cand = torch.from_numpy(np.concatenate([rec, np.zeros((cap_n - n, 8), dtype=np.float32)], 0)).to(dev)
-        count = torch.tensor([n], dtype=torch.int32, device=dev)
-        srt = torch.zeros((cap_n + 1) * 8, dtype=torch.float32, device=dev)
-        mask = torch.empty(cap_n * ((cap_n + 63) // 64), dtype=torch.int64, device=dev)
-        ob = torch.zeros(self.max_det, 4, device=dev); osc = torch.zeros(self.max_det, device=dev)
-        oc = torch.zeros(self.max_det, dtype=torch.int32, device=dev); on = torch.zeros(1, dtype=torch.int32, device=dev)
-        op = L.make_op(L.OP_NMS, L.F32, p=[cand.data_ptr(), count.data_ptr(), srt.data_ptr(), mask.data_ptr(), ob.data_ptr(),
-                                          osc.data_ptr(), oc.data_ptr(), on.data_ptr()],
-                       i={0: cap_n, 1: self.max_det, 2: iw, 3: ih}, f={0: self.nms_iou})
-        with torch.cuda.stream(self.det.stream):
+        with torch.cuda.stream(self.det.stream):               # scratch is created AND consumed on the detector's stream
+            cand = torch.from_numpy(np.concatenate([rec, np.zeros((cap_n - n, 8), dtype=np.float32)], 0)).to(dev)
+            count = torch.tensor([n], dtype=torch.int32, device=dev)
+            srt = torch.zeros((cap_n + 1) * 8, dtype=torch.float32, device=dev)
+            mask = torch.empty(cap_n * ((cap_n + 63) // 64), dtype=torch.int64, device=dev)
+            ob = torch.zeros(self.max_det, 4, device=dev); osc = torch.zeros(self.max_det, device=dev)
+            oc = torch.zeros(self.max_det, dtype=torch.int32, device=dev); on = torch.zeros(1, dtype=torch.int32, device=dev)
+            op = L.make_op(L.OP_NMS, L.F32, p=[cand.data_ptr(), count.data_ptr(), srt.data_ptr(), mask.data_ptr(), ob.data_ptr(),
+                                              osc.data_ptr(), oc.data_ptr(), on.data_ptr()],
+                           i={0: cap_n, 1: self.max_det, 2: iw, 3: ih}, f={0: self.nms_iou})
             L.launch(op, self.det.stream)
             k = int(on.cpu())
             return ob[:k].cpu(), osc[:k].cpu(), oc[:k].cpu().long()

@@ -123,8 +123,8 @@ class _DetectPlan:
                 i={0: A, 1: max_det, 2: iw, 3: ih}, f={0: iou}))
         self.plan = pb.build()
         self.n_ops = len(pb.ops)
+        torch.cuda.synchronize(det.device)          # buffers were allocated / zero-filled on the current stream: order them before det.stream
         if det.use_graph:
-            torch.cuda.synchronize(det.device)
             with torch.cuda.device(det.device):
                 self.plan.run(det.stream)            # warm-up (module load) outside capture
                 det.stream.synchronize()
@@ -204,6 +204,7 @@ class YOLOv9Detector:
             return self._plans[key]
         max_plans = int(os.environ.get("OMNI_MAX_DETECT_PLANS", "8"))
         while len(self._plans) >= max_plans:                 # streams of mixed resolutions: bound the buffer pool (LRU)
+            self.stream.synchronize()                        # the evicted plan's buffers may still be in use on our stream
             self._plans.pop(next(iter(self._plans)))
         with torch.cuda.device(self.device):
             self._plans[key] = _DetectPlan(self, iw, ih, imgsz, conf, iou, max_det, batch)
@@ -228,6 +229,7 @@ class YOLOv9Detector:
                 k = int(counts[bi])
                 out.append(Result(Boxes(dp.out_boxes[bi, :k].clone(), dp.out_scores[bi, :k].clone(),
                                         dp.out_cls[bi, :k].clone().long())))
+            self.stream.synchronize()      # the clones run on this private stream: finish them before any other stream reads them
         return out
 
     @torch.inference_mode()

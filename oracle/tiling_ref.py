@@ -1,6 +1,6 @@
 """ORACLE (test infrastructure): CPU statement of the tiled-detection policy used for >1080p frames
 (BASELINE configs[4]).  The policy does not exist in the reference (it letterboxes the whole image —
-SURVEY 0.7); this file only pins OUR policy: overlapping tiles -> reference detector per tile
+SURVEY 0.7); this file only states OUR merge policy for given tiles: reference detector per tile
 (oracle.detector_ref.predict) -> shift -> global batched_nms(iou)[:max_det] -> clamp."""
 import numpy as np
 import torch
@@ -9,19 +9,10 @@ from PIL import Image
 from . import detector_ref as D
 
 
-def tile_origins(iw, ih, tile_w=1952, tile_h=1112, overlap=64):
-    def axis(n, t):
-        if n <= t:
-            return [0]
-        k = -(-(n - overlap) // (t - overlap))
-        step = (n - t) / (k - 1)
-        return [int(round(i * step)) for i in range(k)]
-    return [(x, y) for y in axis(ih, tile_h) for x in axis(iw, tile_w)], min(tile_w, iw), min(tile_h, ih)
-
-
-def predict_tiled(model, image_u8: np.ndarray, conf=0.05, imgsz=640, iou=0.1, max_det=300):
+def predict_tiled(model, image_u8: np.ndarray, origins, tw, th, conf=0.05, imgsz=640, iou=0.1, max_det=300):
+    """origins: [(x0, y0)] of the tw x th tiles — the tiling geometry is an input here (tests pin the product's
+    geometry with literal expected values instead of comparing two copies of one function)."""
     ih, iw = image_u8.shape[:2]
-    origins, tw, th = tile_origins(iw, ih)
     bs, ss, cs = [], [], []
     for (x0, y0) in origins:
         b, s, c = D.predict(model, Image.fromarray(image_u8[y0:y0 + th, x0:x0 + tw]), conf=conf, imgsz=imgsz, iou=iou, max_det=max_det)

@@ -9,10 +9,10 @@ logits and dist=[B,4,H/s,W/s] LTRB distances in stride units (DFL reduced inside
 
 PARITY UNPINNED for the network itself: the reference ships no weights, golden outputs or
 tests for it.  Parameter/FLOP counts match the published 57.3 M / 189 GFLOP.
-Weights are seeded-random with BatchNorm statistics calibrated so activations stay O(1).
-NOTE: a random BN net is chaotic — fp32 rounding noise is amplified ~1e3-1e4x through its ~100
-layers (CPU fp32 vs CPU fp64 logits differ by ~5e-3) — so network-level parity tests bound the
-GPU-vs-oracle error by the oracle's own fp32-vs-fp64 error instead of by a fixed epsilon.
+Weights are seeded-random and deliberately WELL CONDITIONED (build_random_detector): small BatchNorm gains keep the
+net from amplifying rounding noise (CPU fp32 vs CPU fp64 logits differ by ~3e-5 of the logit spread; the round-1
+stand-in was chaotic, 5e-3), and the score threshold is centred in a gap of the parity frames' anchor logits, so the
+network-level parity tests assert fixed epsilons and identical boxes on EVERY frame.
 """
 import math
 
@@ -241,25 +241,38 @@ class YOLOv9E(nn.Module):
         return self.head([p3, n4, n5])
 
 
-def _calibration_input(seeds=(0, 1, 2)):
-    """640x640 letterboxes (PIL, as ref:util/yolov9.py:73-87) of synthetic screenshots."""
-    import numpy as np
+def letterbox_tensor(img_u8, imgsz):
+    """PIL LANCZOS letterbox exactly as ref:util/yolov9.py:73-87 -> [1,3,H,W] float32."""
     from PIL import Image
+    from . import detector_ref as D
+    x, _, _, _ = D.preprocess(Image.fromarray(img_u8), imgsz)
+    return x
+
+
+def _calibration_input(seeds=(0, 1, 2, 3)):
+    """640x640 letterboxes of synthetic screenshots."""
     from omniparser_amd.synth import synthetic_screenshot
-    xs = []
-    for sd in seeds:
-        img = Image.fromarray(synthetic_screenshot(sd))
-        r = img.resize((640, 360), Image.Resampling.LANCZOS)
-        canvas = Image.new("RGB", (640, 640), (114, 114, 114))
-        canvas.paste(r, (0, 140))
-        xs.append(torch.from_numpy(np.asarray(canvas, dtype=np.float32).transpose(2, 0, 1) / 255.0))
-    return torch.stack(xs)
+    return torch.cat([letterbox_tensor(synthetic_screenshot(sd), 640) for sd in seeds])
 
 
-def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05):
-    """Seeded random YOLOv9-E whose BN statistics are calibrated on a synthetic screenshot so that
-    activations stay O(1) through depth, and whose class-head bias is set so that roughly
-    `pass_rate` of the anchors exceed `conf`."""
+def max_class_logits(model, x):
+    with torch.no_grad():
+        out = model(x)
+    return torch.cat([out[i].flatten(2) for i in (0, 2, 4)], 2).max(1).values.flatten()
+
+
+def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05, margin_frames=()):
+    """Seeded random YOLOv9-E that is WELL CONDITIONED, so that box-for-box parity can be asserted on every frame:
+
+      * BatchNorm gains are small (gamma ~ 0.25) and shifts sizeable (beta ~ 0.5 randn): every Conv+BN+SiLU then works
+        around the near-linear part of SiLU and the net stops amplifying rounding noise (the round-1 stand-in, gamma ~ 1,
+        amplified f32 noise 1e3-1e4x: its own f32 and f64 evaluations disagreed by 5e-3 in the logits).  Measured here:
+        f32-vs-f64 head difference ~3e-5 of the logit spread (tools/make_weights.py --report);
+      * running statistics are calibrated on synthetic screenshots; the class head is rescaled to a logit spread of ~1.5
+        and biased so that ~`pass_rate` of the anchors exceed `conf` (SURVEY 8d config 2);
+      * `margin_frames` ([1,3,H,W] letterboxed inputs the parity tests run on): the threshold logit is moved (by < 0.1)
+        into the widest gap between neighbouring anchor logits of those frames, so no candidate sits within rounding
+        distance of `conf` — the tests can then demand identical candidate sets unconditionally."""
     g = torch.Generator().manual_seed(seed)
     model = YOLOv9E(nc=nc, width=width)
     with torch.no_grad():
@@ -270,30 +283,43 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05):
                 if m.bias is not None:
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.copy_(1.0 + 0.1 * torch.randn(m.weight.shape, generator=g))
-                m.bias.copy_(0.1 * torch.randn(m.bias.shape, generator=g))
-        # calibration pass: running stats <- batch stats of a structured noise image
+                m.weight.copy_(0.25 * (1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)))
+                m.bias.copy_(0.5 * torch.randn(m.bias.shape, generator=g))
         for m in model.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.momentum = 1.0
         model.train()
         for seq in model.head.cv2:   # icon-sized boxes: DFL mass centred near 1.5 strides per side
-            seq[-1].weight.mul_(0.3)
             bins = torch.arange(16, dtype=torch.float32)
             seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
         x = _calibration_input()
-        model(x)
+        model(x)                      # running stats <- batch stats of the calibration frames
         model.eval()
         for m in model.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.momentum = 0.03
-        # class bias: put the `pass_rate` quantile of the max-class logit at logit(conf)
-        out = model(x)
-        logits = torch.cat([out[i].flatten(2) for i in (0, 2, 4)], 2).max(1).values.flatten()
-        q = torch.quantile(logits, 1.0 - pass_rate)
-        shift = math.log(conf / (1 - conf)) - q.item()
+        # class head: logit spread 1.5, `pass_rate` quantile at logit(conf)
+        logits = max_class_logits(model, x)
+        gain = 1.5 / float(logits.std().clamp_min(1e-6))
+        for seq in model.head.cv3:
+            seq[-1].weight.mul_(gain)
+            seq[-1].bias.mul_(gain)
+        logits = max_class_logits(model, x)
+        thr = math.log(conf / (1 - conf))
+        shift = thr - torch.quantile(logits, 1.0 - pass_rate).item()
         for seq in model.head.cv3:
             seq[-1].bias.add_(shift)
+        # margin: centre the threshold in the widest gap of the parity frames' anchor logits within +-0.1
+        if len(margin_frames):
+            lg = torch.cat([max_class_logits(model, f) for f in margin_frames])
+            near = torch.sort(lg[(lg > thr - 0.1) & (lg < thr + 0.1)]).values
+            if near.numel() >= 2:
+                gaps = near[1:] - near[:-1]
+                i = int(torch.argmax(gaps))
+                centre = 0.5 * float(near[i] + near[i + 1])
+                for seq in model.head.cv3:
+                    seq[-1].bias.add_(thr - centre)
+                model.margin = 0.5 * float(gaps[i])
     return model.eval()
 
 

@@ -1,51 +1,51 @@
-"""`-m gpu`: the whole detector stage behind the reference API vs the oracle (tier D of SURVEY 7.5)."""
+"""`-m gpu`: the whole detector stage behind the reference API vs the oracle (tier D of SURVEY 7.5).  Every assert is
+unconditional: fixed epsilons, identical candidate sets and boxes on every frame."""
 import pytest
 
 pytestmark = pytest.mark.gpu
-
-
-def _assert_network_within_oracle_noise(rec, factor=10.0):
-    """GPU-vs-CPU(f32) head error must be of the order of the CPU's own f32-vs-f64 rounding noise
-    (the seeded random BN net is chaotic — see oracle/yolov9e_ref.py)."""
-    for (e_cls, e_dist), (n_cls, n_dist, _) in zip(rec["head_err(cls,dist)"], rec["oracle_noise(cls,dist,gpu_vs_f64)"]):
-        assert e_cls <= factor * n_cls + 1e-4, rec
-        assert e_dist <= factor * n_dist + 1e-4, rec
 
 
 def test_detector_half_width_640():
     import gpu_checks as G
     out, det = G.check_detector(width=0.5, image_seeds=(0, 1, 2), imgsz=640)
     for rec in out["images"]:
-        assert rec["input_mismatch"] == 0          # letterboxed pixels byte-exact vs PIL
-        _assert_network_within_oracle_noise(rec)
+        G.assert_detector_frame(rec)
 
 
 def test_detector_native_resolution_path():
     """scale_img=True path: 1080x1920 -> 1088x1920 network input, no resample (Pillow same-size copy)."""
     import gpu_checks as G
-    out, det = G.check_detector(width=0.25, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
-    rec = out["images"][0]
-    assert rec["input_mismatch"] == 0
-    _assert_network_within_oracle_noise(rec)
+    out, det = G.check_detector(width=0.25, image_seeds=(0,), imgsz=(1080, 1920))
+    G.assert_detector_frame(out["images"][0])
 
 
-def test_detector_full_width_boxes():
-    """Full YOLOv9-E: network within the oracle's own rounding noise on every frame; box-for-box parity
-    (same count, identical class ids, IoU >= 0.999) on every frame where the ORACLE is self-consistent,
-    i.e. its f32 and f64 evaluations keep the same boxes (the seeded random BN net is chaotic, so a
-    candidate sitting within 1e-3 of the score threshold can flip in either implementation)."""
+def test_detector_full_width_boxes_640():
+    """Full YOLOv9-E at the reference's default 640x640 network input: EVERY frame must match the CPU oracle box for
+    box — same candidates, same count, identical class ids, IoU >= 0.999, head tensors within 1e-4 absolute."""
     import gpu_checks as G
-    out, det = G.check_detector(width=1.0, image_seeds=(0, 1, 2), imgsz=640)
-    consistent = 0
+    out, det = G.check_detector(width=1.0, image_seeds=(0, 1, 2, 3), imgsz=640)
     for rec in out["images"]:
-        assert rec["input_mismatch"] == 0
-        _assert_network_within_oracle_noise(rec)
-        if rec["oracle_self_consistent"]:
-            consistent += 1
-            assert rec["n_ref"] == rec["n_gpu"] and rec["cls_equal"], rec
-            assert rec["matched_min_iou"] >= 0.999, rec
-    assert consistent >= 1, out
+        G.assert_detector_frame(rec)
     print(out)
+
+
+def test_detector_full_width_boxes_native():
+    """Full YOLOv9-E at 1088x1920 (configs[1] native path), same unconditional bar."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=1.0, image_seeds=(0, 1), imgsz=(1080, 1920))
+    for rec in out["images"]:
+        G.assert_detector_frame(rec)
+    print(out)
+
+
+def test_oracle_is_well_conditioned():
+    """The stand-in's own f32-vs-f64 head difference stays far below the parity epsilon (it was 5e-3 in round 1)."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=0.5, image_seeds=(0,), imgsz=640, with_f64=True)
+    rec = out["images"][0]
+    for n_cls, n_dist, g_cls in rec["oracle_noise(cls,dist,gpu_vs_f64)"]:
+        assert n_cls <= 3e-5 and n_dist <= 3e-5 and g_cls <= G.HEAD_TOL, rec
+    assert rec["oracle_self_consistent"]
 
 
 def test_tiled_detection_4k_matches_oracle_policy():
@@ -66,7 +66,7 @@ def test_tiled_detection_4k_matches_oracle_policy():
     sp = ScreenParser(det, captioner=None, processor=object())
     img = synthetic_screenshot(4, 3840, 2160)
     origins, tw, th = sp.tile_origins(3840, 2160)
-    assert origins == TR.tile_origins(3840, 2160)[0] and len(origins) == 4 and (tw, th) == (1952, 1112)
+    assert origins == [(0, 0), (1888, 0), (0, 1048), (1888, 1048)] and (tw, th) == (1952, 1112)   # 64-px overlap policy, literal
     gb, gs, gc = sp.detect_tiled(torch.from_numpy(img).cuda())
     # exactness of the merge: feed the GPU's own per-tile boxes to the restated batched_nms
     dp = det.get_plan(tw, th, 640, 0.05, 0.1, 300, batch=4)
@@ -76,14 +76,8 @@ def test_tiled_detection_4k_matches_oracle_policy():
     keep = D.batched_nms(bs, ss, cs, 0.1)[:300]
     eb = bs[keep].clone(); eb[:, [0, 2]] = eb[:, [0, 2]].clamp(0, 3840); eb[:, [1, 3]] = eb[:, [1, 3]].clamp(0, 2160)
     assert len(gb) == len(eb) and torch.equal(gb, eb) and torch.equal(gs, ss[keep]) and torch.equal(gc, cs[keep])
-    # end to end vs the oracle policy (chaotic random net: compare counts loosely, boxes by best match)
+    # end to end vs the oracle policy: same boxes (the stand-in is well conditioned and its threshold margin covers these tiles)
     cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
-    rb, rs, rc = TR.predict_tiled(cpu_model, img)
-    assert abs(len(rb) - len(gb)) <= max(3, len(rb) // 20)
-    if len(rb) and len(gb):
-        x1 = torch.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = torch.maximum(rb[:, None, 1], gb[None, :, 1])
-        x2 = torch.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = torch.minimum(rb[:, None, 3], gb[None, :, 3])
-        inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
-        ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
-        best = (inter / (ar[:, None] + ag[None, :] - inter)).max(1).values
-        assert (best >= 0.999).float().mean() >= 0.9
+    rb, rs, rc = TR.predict_tiled(cpu_model, img, origins, tw, th)
+    assert len(rb) == len(gb) and len(rb) > 0 and torch.equal(rc, gc)
+    assert G.box_iou_pairs(gb, rb).min().item() >= 0.999

@@ -15,6 +15,7 @@ SHAPES = [  # name, M, N, K, act, res
     ("s2.fc1", 294912, 2048, 512, 2, False), ("s2.fc2", 294912, 512, 2048, 0, True), ("s2.qkv", 294912, 1536, 512, 0, False),
     ("s2.proj", 294912, 512, 512, 0, True), ("s0.fc1", 4718592, 512, 128, 2, False), ("s0.fc2", 4718592, 128, 512, 0, True),
     ("enc.fc1", 74880, 3072, 768, 2, False), ("s3.fc1", 73728, 4096, 1024, 2, False), ("det.p3", 51200, 128, 1152, 1, False),
+    ("s2.fc2n", 294912, 512, 2048, 0, False),     # fc2 shape with the plain epilogue (schedule variants / ablations apply to it)
 ]
 
 
@@ -28,7 +29,7 @@ def main():
     for variant in os.environ.get("VARIANTS", "split:128x128,dma,dma:256x128,dma:128x128").split(","):
         os.environ["OMNI_CONV_SPLIT"] = "0" if variant.startswith("f32") else "1"
         variant, *envs = variant.split("+")
-        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE"):
+        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE", "OMNI_GEMM_VAR", "OMNI_GEMM_ABL"):
             os.environ.pop(k, None)
         for kv in envs:
             k, v = kv.split("=")

@@ -16,9 +16,33 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
+# Frames the GPU parity tests / smoke / bench run the detector on, per stand-in width: (image seed, iw, ih, imgsz, tiled).
+# build_random_detector centres the score threshold in a gap of THESE frames' anchor logits (oracle/yolov9e_ref.py).
+PARITY_FRAMES = {
+    1.0: [(s, 1920, 1080, 640, False) for s in range(8)] + [(s, 1920, 1080, (1080, 1920), False) for s in (0, 1)],
+    0.5: [(s, 1920, 1080, 640, False) for s in (0, 1, 2)] + [(4, 3840, 2160, 640, True), (2, 1280, 800, 640, False)],
+    0.25: [(0, 1920, 1080, (1080, 1920), False), (0, 640, 480, 320, False)],
+}
+
+
+def parity_inputs(width):
+    from oracle.yolov9e_ref import letterbox_tensor
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_screenshot
+    xs = []
+    for seed, iw, ih, imgsz, tiled in PARITY_FRAMES.get(float(width), []):
+        img = synthetic_screenshot(seed, iw, ih)
+        if tiled:
+            origins, tw, th = ScreenParser.tile_origins(iw, ih)
+            xs += [letterbox_tensor(img[y:y + th, x:x + tw], imgsz) for x, y in origins]
+        else:
+            xs.append(letterbox_tensor(img, imgsz))
+    return xs
+
+
 def make_blob(path, seed=0, nc=1, width=1.0):
     from oracle.yolov9e_ref import build_random_detector
-    model = build_random_detector(seed=seed, nc=nc, width=width)
+    model = build_random_detector(seed=seed, nc=nc, width=width, margin_frames=parity_inputs(width))
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     with torch.no_grad():
@@ -28,7 +52,7 @@ def make_blob(path, seed=0, nc=1, width=1.0):
 
 
 def default_path(seed=0, nc=1, width=1.0):
-    tag = f"s{seed}_nc{nc}_w{width:g}"
+    tag = f"v2_s{seed}_nc{nc}_w{width:g}"       # v2: well-conditioned stand-in (round 2)
     return ROOT / "weights" / f"icon_detect_v3_{tag}" / "icon_detect_v3" / "model.pt"
 
 
