@@ -38,11 +38,11 @@ struct GemmArgs {
   float oscale;                       // 2^-k of the weight pre-scale
 };
 
-// VAR: K-loop schedule.  0 = all DMA pieces of the next slice right after the barrier, next-unit ds_reads pinned in front of
-// each unit's 12 MFMAs; 1 = DMA pieces spread over the units and ds_reads / DMA interleaved one-per-MFMA
-// (sched_group_barrier).  ABL (tools/gemm_bench.py diagnostics, results WRONG): 1 no DMA in the loop, 2 no DMA and no
+// VAR: K-loop schedule.  1 (default) = DMA pieces spread over the units, ds_reads / DMA pieces interleaved one per MFMA
+// (sched_group_barrier); 0 = all DMA pieces of the next slice right after the barrier, next-unit ds_reads pinned in front of
+// each unit's 12 MFMAs (measured 1-6 % slower, profiles/r2_gemm_diag.md).  ABL (tools/gemm_bench.py diagnostics, results WRONG): 1 no DMA in the loop, 2 no DMA and no
 // barrier, 3 MFMA only (fragments loaded once), 4 no MFMA.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int VAR = 0, int ABL = 0>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int VAR = 1, int ABL = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -311,16 +311,15 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  int var = 0, abl = 0;
+  int var = 1, abl = 0;
   if (const char* e = getenv("OMNI_GEMM_VAR")) var = atoi(e);
   if (const char* e = getenv("OMNI_GEMM_ABL")) abl = atoi(e);
-  if (act == OMNI_ACT_NONE && !osplit && !res && (var || abl)) {       // schedule A/B + ablations: plain epilogue only
+  if (act == OMNI_ACT_NONE && !osplit && !res && (var != 1 || abl)) {  // schedule A/B + ablations (tools/gemm_bench.py): plain epilogue only
 #define OMNI_GD(V, A) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false, V, A>), grid, block, 0, s, a)
-    if (var == 1 && abl == 0) OMNI_GD(1, 0);
-    else if (var == 0 && abl == 1) OMNI_GD(0, 1);
-    else if (var == 0 && abl == 2) OMNI_GD(0, 2);
-    else if (var == 0 && abl == 3) OMNI_GD(0, 3);
-    else if (var == 0 && abl == 4) OMNI_GD(0, 4);
+    if (abl == 1) OMNI_GD(0, 1);
+    else if (abl == 2) OMNI_GD(0, 2);
+    else if (abl == 3) OMNI_GD(0, 3);
+    else if (abl == 4) OMNI_GD(0, 4);
     else OMNI_GD(0, 0);
 #undef OMNI_GD
     return OMNI_OK;

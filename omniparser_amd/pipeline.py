@@ -200,4 +200,5 @@ class ScreenParser:
                     e["content"] = q.pop(0)[0]
             ids_out.append([r for _, r in cl])
         self.stats = {"crops": [len(c) for c in crops_all], "boxes": [len(b) for b in det_boxes]}
+        self.last_crops = crops_all            # integer crop boxes per frame, in caption order (parity tests read them)
         return (elems_all, ids_out) if return_ids else elems_all

@@ -18,6 +18,8 @@ def test_captioner_token_exact_r64():
     out, _ = G.check_captioner(R=64, n=5)
     assert out["ids_equal"], out
     assert out["feat_rel_err"] < 1e-4 and out["enc_rel_err"] < 1e-4
+    assert out["max_logit_err"] < out["min_top1_top2_margin"], out
+    print(out)
 
 
 def test_captioner_token_exact_r768():
@@ -26,6 +28,17 @@ def test_captioner_token_exact_r768():
     out, _ = G.check_captioner(R=768, n=2)
     assert out["ids_equal"], out
     assert out["feat_rel_err"] < 3e-4 and out["enc_rel_err"] < 3e-4
+    assert out["max_logit_err"] < out["min_top1_top2_margin"], out      # token-exactness is not a coin flip: error below the smallest arg-max margin
+    print(out)
+
+
+def test_bench_path_parity_batch8_full_width_r768():
+    """The composition bench.py times (configs[2]): parse_batch over 8 frames, full-width detector, 768x768 crops packed
+    across frames into 128-crop micro-batches — elements of every frame and caption ids across frame / micro-batch seams."""
+    import gpu_checks as G
+    out = G.check_bench_path(R=768, width=1.0, n_frames=8)
+    assert out["caption_crops_checked"] >= 16 and len(out["frames_touched"]) >= 4 and len(out["micro_batches_touched"]) >= 2, out
+    print(out)
 
 
 def test_end_to_end_get_som_labeled_img():
