@@ -20,6 +20,7 @@ from PIL import Image
 from .. import _lib as L
 from ..planner import PlanBuilder
 from ..yolo_graph import YoloV9EGraph
+from ..yolo_import import import_state_dict, verify_against_blob
 
 DEFAULT_REPO_ID = "microsoft/OmniParser-v2.0"
 DEFAULT_MODEL_FILE = "icon_detect_v3/model.pt"
@@ -163,10 +164,10 @@ class YOLOv9Detector:
             from huggingface_hub import hf_hub_download
             model_path = hf_hub_download(repo_id=repo_id, filename=DEFAULT_MODEL_FILE, revision=revision)
         self.model_path = Path(model_path)
-        # The blob is only a weight container here: its graph is never executed.
+        # The blob is a weight container: its tensors are assigned to their roles from its own graph (yolo_import.py), whatever
+        # its attribute names are, and the lowered network is proven against the blob once, at load time, on a probe input.
         blob = torch.jit.load(str(self.model_path), map_location="cpu").eval()
-        self.state_dict = {k: v.detach().float().cpu() for k, v in blob.state_dict().items()}
-        del blob
+        self.state_dict = import_state_dict(blob)
         self.dtype = _precision_from_env(precision)
         self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"
         self.stream = torch.cuda.Stream(device=self.device)
@@ -174,6 +175,25 @@ class YOLOv9Detector:
         self._plans = {}
         self._lock = threading.Lock()   # plans own their device buffers: one inference at a time per detector
         self.model = self   # callers touch `.model` only to move devices
+        self.import_error = None
+        if os.environ.get("OMNI_VERIFY_IMPORT", "1") != "0":
+            nc = self.state_dict["head.cv3.0.2.weight"].shape[0]
+            self.import_error = verify_against_blob(blob, self._probe_network, nc, tol=2e-3 if self.dtype == L.F32 else 0.25)
+        del blob
+
+    def _probe_network(self, x_nchw: torch.Tensor):
+        """network part of a plan (no letterbox / decode) on a given input: used once, by the load-time import check."""
+        size = x_nchw.shape[-1]
+        with torch.cuda.device(self.device):
+            pb = PlanBuilder(self.device, self.dtype)
+            x = pb.alloc(1, size, size, pb.V, zero=True)
+            x.t[0, :, :, :3] = x_nchw[0].permute(1, 2, 0).to(x.t.dtype)
+            heads = YoloV9EGraph(self.state_dict, pb, 1, size, size, wcache=self._wcache).build(x)
+            plan = pb.build()
+            torch.cuda.synchronize(self.device)
+            plan.run(self.stream)
+            self.stream.synchronize()
+            return [(c.torch().cpu(), b.torch().cpu()) for c, b in heads]
 
     def to(self, device):   # ref:eval/ss_pro_gpt4o_omniv2.py:30 calls som_model.to(device)
         return self

@@ -11,8 +11,8 @@ nearest-resize kernels (topology: SURVEY.md Appendix B):
     chain into a scratch tensor consumed as the residual operand of the producing conv's epilogue;
   * box logits stay 4x16 DFL bins — the expectation is fused into the decode kernel.
 
-State-dict naming follows oracle/yolov9e_ref.py (the real `icon_detect_v3/model.pt` is unavailable
-here; a key-mapping table is all a differently named blob needs — see `KEYMAP_HOOK`).
+The state dict arrives under canonical names from `yolo_import.import_state_dict`, which assigns the blob's tensors to
+their roles from the blob's own graph (program order + hyper-parameters), not from its attribute names.
 """
 from typing import Dict, List
 
@@ -21,14 +21,10 @@ import torch
 from . import _lib as L
 from .planner import PlanBuilder, View
 
-KEYMAP_HOOK = None   # optional callable(state_dict) -> state_dict with the naming used below
-
 
 class YoloV9EGraph:
     def __init__(self, state_dict: Dict[str, torch.Tensor], pb: PlanBuilder, B: int, TH: int, TW: int,
                  wcache: Dict = None):
-        if KEYMAP_HOOK is not None:
-            state_dict = KEYMAP_HOOK(state_dict)
         self.sd = state_dict
         self.pb = pb
         self.B, self.TH, self.TW = B, TH, TW
@@ -52,12 +48,20 @@ class YoloV9EGraph:
 
     # ------------------------------------------------------------ weight transforms
     def fold(self, prefix):
-        """Conv2d(bias=False)+BN(eps) -> (W, b)."""
+        """Conv2d(bias=False)+BN(eps) -> (W, b); a blob exported with BN already folded (conv with bias, no norm) passes through."""
         w = self.sd[prefix + ".conv.weight"]
+        if prefix + ".bn.weight" not in self.sd:
+            if prefix + ".conv.bias" not in self.sd:
+                raise KeyError(f"{prefix}: neither BatchNorm statistics nor a conv bias in the imported blob")
+            return w, self.sd[prefix + ".conv.bias"]
         g, b = self.sd[prefix + ".bn.weight"], self.sd[prefix + ".bn.bias"]
         mu, var = self.sd[prefix + ".bn.running_mean"], self.sd[prefix + ".bn.running_var"]
-        inv = g / torch.sqrt(var + 1e-3)
-        return w * inv.view(-1, 1, 1, 1), b - mu * inv
+        eps = float(self.sd[prefix + ".bn.eps"]) if prefix + ".bn.eps" in self.sd else 1e-3
+        inv = g / torch.sqrt(var + eps)
+        bias = b - mu * inv
+        if prefix + ".conv.bias" in self.sd:
+            bias = bias + self.sd[prefix + ".conv.bias"] * inv
+        return w * inv.view(-1, 1, 1, 1), bias
 
     def fold_rep(self, prefix):
         """RepConvN: conv1 (3x3, BN) + conv2 (1x1, BN) -> one 3x3."""

@@ -95,3 +95,27 @@ def test_product_constructors_fail_loudly_without_gpu(ckpt_dir):
         YOLOv9Detector(model_path="does-not-matter.pt", device="cuda")
     with pytest.raises(RuntimeError):
         YOLOv9Detector(model_path="does-not-matter.pt", device="cpu")
+
+
+def test_batch_decode_through_tokenizer_json(tmp_path):
+    """ref:util/utils.py:128: `processor.batch_decode(ids, skip_special_tokens=True)` -> text.  With a tokenizer.json next to the
+    checkpoint the product decodes through `tokenizers` (byte-level BPE, BART layout); pinned with the committed synthetic
+    tokenizer (tests/golden/gen_tokenizer.py) because the real Florence-2 tokenizer files are not on this box."""
+    import shutil
+    from pathlib import Path
+    from tokenizers import Tokenizer
+    from omniparser_amd.util.utils import FlorenceProcessor
+    src = Path(__file__).resolve().parent / "golden" / "tokenizer_synth" / "tokenizer.json"
+    shutil.copy(src, tmp_path / "tokenizer.json")
+    proc = FlorenceProcessor(tmp_path)
+    tok = Tokenizer.from_file(str(src))
+    texts = ["a blue settings icon with a gear", "close window", "volume slider"]
+    rows = []
+    for t in texts:
+        ids = tok.encode(t).ids                                   # <s> ... </s>
+        rows.append([2] + ids + [1] * (21 - 1 - len(ids)))       # decoder start token 2, then pad to the plan width
+    out = proc.batch_decode(torch.tensor(rows), skip_special_tokens=True)
+    assert [o.strip() for o in out] == texts
+    raw = proc.batch_decode(torch.tensor(rows[:1]), skip_special_tokens=False)[0]
+    assert "<s>" in raw and "</s>" in raw and "<pad>" in raw
+    assert FlorenceProcessor(None).batch_decode(torch.tensor(rows[1:2]))[0].startswith("tok")      # no tokenizer file: ids as text
