@@ -17,9 +17,10 @@ W untimed warm-up steps, exactly K timed steps between barrier+synchronize pairs
 prints ONE JSON line; `value` = screenshots of all ranks / that time.  Screenshots shard across ranks with
 no data-path collective; the only exchange is one all_gather of packed element records per job.
 
-Extra objects: `roofline` (dominant kernel family conv_igemm_kernel: algorithmic conv/linear FLOPs per
-step / HIP-event time of exactly those launches, vs the dense MFMA peak of the dtype) and `cpu_baseline`
-(the reference-equivalent CPU path from oracle/, timed on rank 0 at N=1 on a bounded sample).
+Extra objects: `roofline` (dominant kernel family = the GEMMs: algorithmic conv/linear FLOPs per step at the REAL
+crop count / HIP-event time of exactly those launches timed in sequence, vs the dense f16 MFMA peak), `extra`
+(N=1: BASELINE configs[1] detector-only at both network sizes, the 64x64 crop size, configs[4] tiled 4K) and
+`cpu_baseline` (the reference-equivalent CPU path from oracle/, timed on rank 0 at N=1 on a bounded sample).
 Weights are seeded-random (tools/make_weights.py); data is synthetic (omniparser_amd/synth.py).
 """
 import argparse
@@ -44,6 +45,7 @@ def parse_args():
     ap.add_argument("--caption-res", type=int, default=768, choices=[64, 768])
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -175,7 +177,8 @@ def main():
             "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
             "gemm_tile_order": ("xcd row blocks + N partition (L2-resident weight slabs)"
                                 if os.environ.get("OMNI_XCD_NSPLIT", "1") != "0" else "xcd row blocks (round-1 order)"),
-            "gemm_path": ("split-f16 x3 MFMA (f32-class accuracy)" if args.precision == "f32" and
+            "gemm_path": ("split-f16 x3 MFMA (f32-class accuracy): pre-split LDS-DMA GEMM for the captioner's linear layers, "
+                          "register-staged split kernel for convs / decoder steps" if args.precision == "f32" and
                           os.environ.get("OMNI_CONV_SPLIT", "1") == "1" else
                           ("exact f32 MFMA" if args.precision == "f32" else "f16 MFMA")),
         },
@@ -186,6 +189,8 @@ def main():
 
     if rank == 0:
         out["roofline"] = roofline(args, det, parser, locals().get("dp"), crop_counts, B)
+        if world == 1 and not args.no_extra:
+            out["extra"] = extras(args, det, parser, frames, ocr, dev)
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0))
         print(json.dumps(out), flush=True)
@@ -194,71 +199,168 @@ def main():
         dist.destroy_process_group()
 
 
+KIND_NAMES = {1: "gemm (conv / linear)", 2: "avgpool", 3: "maxpool", 4: "resize_nearest", 5: "letterbox", 6: "detect_decode", 7: "nms",
+              8: "dwconv3", 9: "layernorm", 10: "attention (window / mha)", 11: "channel_attention", 12: "proj_prep", 13: "assemble",
+              14: "embed_step", 15: "attn_decode", 16: "greedy_step", 17: "crop_resize", 18: "dwconv3+ln", 19: "split_convert"}
+
+
+def profile_plan(plan, stream, repeat=1):
+    """per-op-kind device ms of `repeat` eager replays (HIP events around every op, in sequence: omni_plan_profile)."""
+    by_kind, n_gemm = {}, 0
+    for _ in range(repeat):
+        ms = plan.profile(stream)
+        for op, t in zip(plan.ops, ms):
+            by_kind[op.kind] = by_kind.get(op.kind, 0.0) + t
+        n_gemm += sum(1 for op in plan.ops if op.kind == 1)
+    return by_kind, n_gemm
+
+
 def roofline(args, det, parser, dp, crop_counts, B):
-    """conv_igemm_kernel family: algorithmic FLOPs of every conv/linear launch in one step divided by the
-    HIP-event time of exactly those launches (timed per plan on the stream they run on)."""
+    """Dominant kernel family = the GEMMs (conv / linear).  `achieved` = ALGORITHMIC GEMM FLOPs of one step (real crop count,
+    not the bucket-padded one) / device time of exactly those launches, each timed in its real sequence by HIP events during
+    an instrumented eager replay of the step's plans right after the timed region (same inputs, same buffers; every other
+    kernel of the step runs in between, so caches are in the state the timed steps leave them).  The same replay yields the
+    per-kernel-family split of a step; `rocprofv3 --kernel-trace --stats` of this command is committed under profiles/."""
     from omniparser_amd import _lib as L
-    peak = 157.3 if args.precision == "f32" else 2500.0
-
-    def conv_time(plan, stream, iters):
-        ops = [op for op in plan.ops if op.kind == L.OP_CONV]
-        sub = L.Plan(ops)
-        sub.run(stream); stream.synchronize()
-        return sub.time(iters, stream), len(ops)
-
-    flops = ms = 0.0
+    fam, parts = {}, {}
+    gemm_ms = 0.0
     launches = 0
-    parts = {}
+
+    def add(by_kind, times=1.0):
+        for k, t in by_kind.items():
+            fam[k] = fam.get(k, 0.0) + t * times
+
     if args.mode == "detect":
-        t, n = conv_time(dp.plan, det.stream, 20)
-        flops, ms, launches = dp.net_flops, t, n
-        parts["detector"] = {"ms": round(t, 4), "gflop": round(dp.net_flops / 1e9, 2)}
+        bk, n = profile_plan(dp.plan, det.stream)
+        add(bk)
+        flops, gemm_ms, launches = dp.net_flops, bk.get(1, 0.0), n
+        parts["detector_batch%d" % B] = {"gemm_ms": round(gemm_ms, 4), "gflop": round(dp.net_flops / 1e9, 2)}
+        crops = 0
     else:
         cap = parser.cap
-        ddp = next(iter(det._plans.values()))
-        t, n = conv_time(ddp.plan, det.stream, 5)
-        flops, ms, launches = ddp.net_flops, t, n
-        parts["detector_batch%d" % B] = {"ms": round(t, 4), "gflop": round(ddp.net_flops / 1e9, 2)}
+        ddp = next(p for p in det._plans.values() if p.batch == B)
+        bk, n = profile_plan(ddp.plan, det.stream)
+        add(bk)
+        flops, gemm_ms, launches = float(ddp.net_flops), bk.get(1, 0.0), n
+        parts["detector_batch%d" % B] = {"gemm_ms": round(bk.get(1, 0.0), 4), "gflop": round(ddp.net_flops / 1e9, 2)}
         crops = int(round(sum(crop_counts) / max(len(crop_counts), 1)))
         mbs = [128] * (crops // 128) + ([cap.bucket(crops % 128)] if crops % 128 else [])
+        per_crop = 0.0
         for bucket in sorted(set(mbs)):
-            key = (bucket, cap.resolution, 20)
-            if key not in cap._plans:
+            cp = cap._plans.get((bucket, cap.resolution, 20))
+            if cp is None:
                 continue
-            cp = cap._plans[key]
-            te, ne = conv_time(cp.encode_plan, cap.stream, 2)
-            ts, ns = conv_time(cp.step_plan, cap.stream, 5)
             cnt = mbs.count(bucket)
-            flops += cnt * (cp.encode_flops + 20 * cp.step_flops)
-            ms += cnt * (te + 20 * ts)
-            launches += cnt * (ne + 20 * ns)
-            parts["caption_mb%d_x%d" % (bucket, cnt)] = {"encode_ms": round(te, 3), "step_ms": round(ts, 4),
-                                                         "encode_gflop": round(cp.encode_flops / 1e9, 1),
-                                                         "step_gflop": round(cp.step_flops / 1e9, 3)}
-    achieved = flops / (ms * 1e-3) / 1e12
+            with torch_stream(cap.stream):
+                cp.reset()
+            be, ne = profile_plan(cp.encode_plan, cap.stream)
+            bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20)
+            add(be, cnt); add(bs, cnt)
+            gemm_ms += cnt * (be.get(1, 0.0) + bs.get(1, 0.0))
+            launches += cnt * (ne + ns)
+            parts["caption_mb%d_x%d" % (bucket, cnt)] = {
+                "encode_gemm_ms": round(be.get(1, 0.0), 3), "decode20_gemm_ms": round(bs.get(1, 0.0), 3),
+                "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2), "step_gflop_per_crop": round(cp.step_flops / cp.B / 1e9, 4),
+                "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
+            per_crop = cp.encode_flops / cp.B + 20 * cp.step_flops / cp.B
+        flops += crops * per_crop          # ALGORITHMIC: real crops (bucket padding is wasted time, not work)
+    achieved = flops / (gemm_ms * 1e-3) / 1e12
     split = args.precision == "f32" and os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
-    if split:
-        # f32 plans run their GEMMs as split-f16 MFMA: the matrix pipe bounding the kernel is the dense f16 one
-        # (2.5 PF/s); every algorithmic MAC issues 3 MFMA products, so pipe utilisation = 3 * achieved / peak.
-        peak = 2500.0
-    out = {"bound": "mfma", "kernel": ("conv_split_kernel<BM,BN,PW> (split-f16 x3 MFMA, f32 accumulate)" if split else
-                                       "conv_igemm_kernel<T,BM,BN,RB,ALIGNED,PW>") + " + splitk_reduce_kernel",
+    peak = 2500.0 if (split or args.precision == "f16") else 157.3
+    total = sum(fam.values())
+    out = {"bound": "mfma",
+           "kernel": ("gemm_dma_kernel (pre-split LDS-DMA GEMM, split-f16 x3 MFMA, f32 accumulate) + conv_split_kernel (convs, decoder steps)"
+                      if split else "conv_igemm_kernel<T,BM,BN,RB,ALIGNED,PW>") + " + splitk_reduce_kernel",
            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
     if split:
-        out.update(mfma_products_per_mac=3, matrix_pipe_utilisation=round(3 * achieved / peak, 4),
-                   vs_f32_mfma_peak=round(achieved / 157.3, 3))
-    # HBM traffic of the dominant kernel: PMC pass of this same command (rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE in
-    # separate runs, FETCH_SIZE doubled per MI355X_MICROARCH.md's gfx950 note), summarised under profiles/
-    tfile = ROOT / "profiles" / "r1_pmc_traffic_conv_split.json"
+        # every algorithmic MAC issues 3 f16 MFMA products (hi*hi + hi*lo + lo*hi): the matrix pipe is busy 3 * achieved / peak
+        out.update(mfma_products_per_mac=3, matrix_pipe_utilisation=round(3 * achieved / peak, 4), vs_f32_mfma_peak=round(achieved / 157.3, 3))
+    tfile = ROOT / "profiles" / "r2_pmc_traffic.json"
     if split and args.mode == "e2e" and args.caption_res == 768 and tfile.exists():
-        t = json.loads(tfile.read_text())["conv_split_128x128"]
-        out["traffic"] = round((t["fetch_bytes_corrected"] + t["write_bytes"]) / t["launches"])
-        out["traffic_note"] = ("mean HBM bytes per conv_split_kernel<128,128> launch (PMC, profiles/r1_pmc_traffic_conv_split.json; "
-                               "collected with the round-1 tile order, i.e. OMNI_XCD_NSPLIT=0)")
+        t = json.loads(tfile.read_text())
+        out["traffic"] = t.get("gemm_bytes_per_launch")
+        out["traffic_detail"] = {k: t[k] for k in ("gemm_fetch_bytes_per_crop", "gemm_write_bytes_per_crop", "algorithmic_gemm_bytes_per_crop",
+                                                   "ratio", "source") if k in t}
     out.update({
-            "flops_per_step": flops, "launches_per_step": launches, "kernel_ms_per_step": round(ms, 3),
-            "avg_launch_us": round(1000 * ms / max(launches, 1), 3), "parts": parts})
+        "flops_per_step": flops, "crops_per_step": crops, "gemm_launches_per_step": launches, "gemm_ms_per_step": round(gemm_ms, 3),
+        "avg_gemm_launch_us": round(1000 * gemm_ms / max(launches, 1), 3), "profiled_step_ms": round(total, 3),
+        "non_gemm_share": round(1.0 - gemm_ms / max(total, 1e-9), 4),
+        "kernel_family_ms_per_step": {KIND_NAMES.get(k, str(k)): round(v, 3) for k, v in sorted(fam.items(), key=lambda kv: -kv[1])},
+        "parts": parts,
+        "method": "HIP events around every op of an eager replay of the step's plans (omni_plan_profile), after the timed region"})
     return out
+
+
+def torch_stream(stream):
+    import torch
+    return torch.cuda.stream(stream)
+
+
+def extras(args, det, parser, frames, ocr, dev):
+    """BASELINE configs[1], the 64x64 (reference cuda-branch) crop size, configs[4] — small runs beside the headline line.
+    `value` of the JSON line stays configs[2] at 768x768."""
+    import torch
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from tools.make_weights import caption_dir
+    ex = {}
+
+    def time_region(fn, iters, warm=1):
+        for _ in range(warm):
+            fn()
+        torch.cuda.synchronize(dev)
+        t0 = time.perf_counter()
+        for _ in range(iters):
+            fn()
+        torch.cuda.synchronize(dev)
+        return (time.perf_counter() - t0) / iters
+
+    # configs[1]: detector only (letterbox + network + decode + NMS, HBM-resident input), batch 1 / 8, both network sizes
+    for tag, imgsz, batch, iters in (("detector_b1_640", 640, 1, 100), ("detector_b8_640", 640, 8, 20), ("detector_b1_1088x1920", (IH, IW), 1, 30)):
+        dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=batch)
+        with torch.cuda.stream(det.stream):
+            for j in range(batch):
+                dp.img[j].copy_(frames[j % 8])
+        det.stream.synchronize()
+
+        def run(dp=dp):
+            dp.launch(det)
+            det.stream.synchronize()
+        sec = time_region(run, iters, warm=2)
+        bk, n = profile_plan(dp.plan, det.stream)
+        g = bk.get(1, 1e-9)
+        ex[tag] = {"value": round(batch / sec, 2), "unit": "screenshots/s", "ms_per_step": round(1000 * sec, 3),
+                   "workload": "BASELINE configs[1]: detector only, batch %d, network input %s" % (batch, "640x640" if imgsz == 640 else "1088x1920"),
+                   "roofline": {"bound": "mfma", "achieved": round(dp.net_flops / g / 1e9, 2), "peak": 2500.0, "unit": "TFLOP/s",
+                                "frac": round(dp.net_flops / g / 1e9 / 2500.0, 4), "gemm_ms": round(g, 3),
+                                "gflop": round(dp.net_flops / 1e9, 1), "non_gemm_ms": round(sum(bk.values()) - g, 3)}}
+    if args.mode != "e2e":
+        return ex
+    # the reference's cuda branch feeds 64x64 crops (ref:util/utils.py:120-121): same pipeline at that crop size
+    cap64 = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=64)
+    p64 = ScreenParser(det, cap64, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=640)
+    sec = time_region(lambda: p64.parse_batch(frames, ocr), 3)
+    ex["e2e_r64_batch8"] = {"value": round(8 / sec, 2), "unit": "screenshots/s", "ms_per_step": round(1000 * sec, 2),
+                            "workload": "configs[2] pipeline with 64x64 crops (the reference's cuda-branch crop size), batch 8"}
+    del p64, cap64
+    torch.cuda.empty_cache()
+    # configs[4]: 3840x2160 frames, 2x2 overlapping tiles + global NMS (policy is ours), 64-crop caption micro-batches at 768x768
+    ptile = ScreenParser(det, parser.cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=640,
+                         batch_size=64, tile_large=True)
+    f4k = [torch.from_numpy(synthetic_screenshot(100 + s, 3840, 2160)).to(dev) for s in range(2)]
+    o4k = [synthetic_ocr(100 + s, 3840, 2160, 40) for s in range(2)]
+    ptile.parse_batch(f4k, o4k)
+    torch.cuda.synchronize(dev)
+    t0 = time.perf_counter()
+    ptile.parse_batch(f4k, o4k)
+    torch.cuda.synchronize(dev)
+    sec = time.perf_counter() - t0
+    ex["tiled_4k_r768"] = {"value": round(2 / sec, 3), "unit": "screenshots/s", "ms_per_step": round(1000 * sec, 1),
+                           "workload": "BASELINE configs[4] on one GPU: 2 frames of 3840x2160, 2x2 tiles of 1952x1112 (64 px overlap) -> global NMS, "
+                                       "64-crop caption micro-batches at 768x768",
+                           "crops_per_frame": ptile.stats["crops"], "boxes_per_frame": ptile.stats["boxes"]}
+    return ex
 
 
 def cpu_baseline(args, blob, imgsz, mean_crops):

@@ -190,6 +190,11 @@ int omni_resample_coeffs(int in_size, int out_size, int filter, int32_t* h_bound
  * stop, synchronises and returns mean milliseconds per iteration in *ms. */
 int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms);
 
+/* One EAGER replay with a HIP event around every op (on `stream`): h_ms[i] = device milliseconds of op i in its real
+ * sequence.  bench.py derives `roofline.achieved` and the per-kernel-family split of a step from it; the numbers are
+ * directly comparable with `rocprofv3 --kernel-trace --stats` of the same replay.  h_ms holds omni_plan_num_ops floats. */
+int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms);
+
 /* Host mirror of the GEMM kernels' block -> output-tile permutation (XCD-aware order with an optional N partition
  * over XCD groups; csrc/conv_igemm.hip::tile_of_block).  Test/diagnostic entry point, no device work: for block
  * `bid` of a grid over mtiles x ntiles tiles writes the tile (or -1/-1 for a padding block), the grid size and the

@@ -20,7 +20,7 @@ EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
-    "omni_debug_host_op",
+    "omni_debug_host_op", "omni_plan_profile",
 ]
 
 
@@ -69,6 +69,8 @@ def lib():
     L.omni_resample_coeffs.restype = c_int
     L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
     L.omni_plan_time.restype = c_int
+    L.omni_plan_profile.argtypes = [c_void_p, c_void_p, POINTER(c_float)]
+    L.omni_plan_profile.restype = c_int
     L.omni_debug_tile_map.argtypes = [c_int, c_int, c_int, ctypes.c_longlong, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                       POINTER(c_int)]
     L.omni_debug_tile_map.restype = c_int
@@ -139,6 +141,12 @@ class Plan:
         ms = c_float()
         check(lib().omni_plan_time(self._h, _stream_ptr(stream), iters, ctypes.byref(ms)))
         return ms.value
+
+    def profile(self, stream=None):
+        """device milliseconds of every op of ONE eager replay, in sequence (HIP events around each op)."""
+        arr = (c_float * len(self.ops))()
+        check(lib().omni_plan_profile(self._h, _stream_ptr(stream), arr))
+        return list(arr)
 
     def __len__(self):
         return len(self.ops)

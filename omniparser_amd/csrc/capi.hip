@@ -146,6 +146,35 @@ extern "C" int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float*
   return OMNI_OK;
 }
 
+// Per-op device time of one eager replay: an event in front of every op and one behind the last, all on `stream`, so each
+// op is timed in its real sequence (caches as its predecessors left them, neighbours interleaved) — what a kernel trace
+// of the same replay reports per launch.  h_ms[i] = milliseconds between the events around op i (ops that launch several
+// kernels, e.g. a split-K conv + its reduce, are timed as one).
+extern "C" int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms) {
+  if (!plan || !h_ms) { omni_set_error("omni_plan_profile: bad arguments"); return OMNI_E_ARG; }
+  hipStream_t s = (hipStream_t)stream;
+  const size_t n = plan->ops.size();
+  std::vector<hipEvent_t> ev(n + 1, nullptr);
+  int rc = OMNI_OK;
+  for (size_t i = 0; i <= n && rc == OMNI_OK; ++i)
+    if (hipEventCreate(&ev[i]) != hipSuccess) { omni_set_error("omni_plan_profile: hipEventCreate failed"); rc = OMNI_E_HIP; }
+  for (size_t i = 0; i < n && rc == OMNI_OK; ++i) {
+    hipEventRecord(ev[i], s);
+    rc = dispatch(&plan->ops[i], s);
+  }
+  if (rc == OMNI_OK) {
+    hipEventRecord(ev[n], s);
+    if (hipEventSynchronize(ev[n]) != hipSuccess) { omni_set_error("omni_plan_profile: synchronize failed"); rc = OMNI_E_HIP; }
+  }
+  for (size_t i = 0; i < n && rc == OMNI_OK; ++i) {
+    float t = 0.f;
+    hipEventElapsedTime(&t, ev[i], ev[i + 1]);
+    h_ms[i] = t;
+  }
+  for (hipEvent_t e : ev) if (e) hipEventDestroy(e);
+  return rc;
+}
+
 // ---------------------------------------------------------------------------------------------
 // Pillow precompute_coeffs + normalize_coeffs_8bpc (host, double precision).
 static double sinc_filter(double x) {

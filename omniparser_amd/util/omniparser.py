@@ -42,6 +42,13 @@ class Omniparser(object):
         self.caption_model_processor = U.get_caption_model_processor(
             model_name=config["caption_model_name"], model_name_or_path=config["caption_model_path"], device=device)
         self.ocr_provider: Optional[Callable] = config.get("ocr_provider")
+        # crop resolution of the captioner: 768 = the reference's CPU branch (bicubic to 768x768; the parity target and the
+        # default here), 64 = its cuda branch (do_resize=False, ref:util/utils.py:120-121).  An explicit choice, not a device side effect.
+        if config.get("caption_resolution") is not None:
+            res = int(config["caption_resolution"])
+            if res not in (64, 768):
+                raise ValueError(f"caption_resolution must be 64 or 768, got {res}")
+            self.caption_model_processor["model"].resolution = res
 
     def _ocr(self, image: Image.Image, ocr=None):
         """`ocr` = (texts, xyxy px boxes) handed over by the caller for THIS image; else the configured provider."""

@@ -103,14 +103,81 @@ def get_caption_model_processor(model_name, model_name_or_path="Salesforce/blip2
     return {"model": model, "processor": processor}
 
 
+def get_xywh(input):
+    """ref:util/utils.py:498-501 (quad corners -> truncated x, y, w, h)."""
+    x, y, w, h = input[0][0], input[0][1], input[2][0] - input[0][0], input[2][1] - input[0][1]
+    return int(x), int(y), int(w), int(h)
+
+
+def get_xyxy(input):
+    """ref:util/utils.py:503-506."""
+    x, y, xp, yp = input[0][0], input[0][1], input[2][0], input[2][1]
+    return int(x), int(y), int(xp), int(yp)
+
+
+_OCR_ENGINES = {"easyocr": None, "paddleocr": None}      # process-wide engines, created on first use (the reference builds both at import)
+
+
+def set_ocr_engine(easyocr_reader=None, paddle_ocr=None):
+    """Install the OCR engine objects `check_ocr_box` calls: an EasyOCR-compatible `reader.readtext(image_np, **easyocr_args)` ->
+    [(quad, text, conf)] and/or a PaddleOCR-compatible `ocr(image_np, cls=False)` -> [[[quad, (text, conf)], ...]]."""
+    if easyocr_reader is not None:
+        _OCR_ENGINES["easyocr"] = easyocr_reader
+    if paddle_ocr is not None:
+        _OCR_ENGINES["paddleocr"] = paddle_ocr
+
+
+def _ocr_engine(kind):
+    if _OCR_ENGINES[kind] is None:
+        try:
+            if kind == "easyocr":
+                import easyocr
+                _OCR_ENGINES[kind] = easyocr.Reader(["en"])                                  # ref:util/utils.py:21
+            else:
+                from paddleocr import PaddleOCR
+                _OCR_ENGINES[kind] = PaddleOCR(lang="en", use_angle_cls=False, use_gpu=False, show_log=False, max_batch_size=1024,
+                                               use_dilation=True, det_db_score_mode="slow", rec_batch_num=1024)   # ref:util/utils.py:22-30
+        except ImportError:
+            return None
+    return _OCR_ENGINES[kind]
+
+
 def check_ocr_box(image_source, display_img=True, output_bb_format="xywh", goal_filtering=None, easyocr_args=None,
                   use_paddleocr=False, ocr_result=None):
-    """OCR front-end (ref:util/utils.py:514-549) is a separate model family and out of scope: callers
-    pass `ocr_result=(texts, xyxy boxes)` (e.g. omniparser_amd.synth.synthetic_ocr) or get no text boxes."""
-    texts, boxes = ocr_result if ocr_result is not None else ([], [])
-    if output_bb_format == "xywh":
-        boxes = [[b[0], b[1], b[2] - b[0], b[3] - b[1]] for b in boxes]
-    return (list(texts), [list(b) for b in boxes]), goal_filtering
+    """ref:util/utils.py:514-549 — the OCR front-end of every caller (`Omniparser.parse`, the Gradio demo).
+
+    Everything the reference does AROUND its OCR engine is reproduced (fixture: tests/golden/reference_ocr_glue.json, recorded
+    from the reference's own function): RGBA -> RGB, PaddleOCR's strict `> text_threshold` filter (default 0.5), `easyocr_args`
+    handed to `readtext` untouched, int() truncation of the quad corners, xywh / xyxy output, and display_img=True always
+    yielding xywh.  The engines themselves (EasyOCR = CRAFT + CRNN, PaddleOCR = PP-OCR) are third-party model packages that
+    are not part of this path: they are used when importable or installed with `set_ocr_engine`; `ocr_result=(texts, xyxy
+    boxes)` feeds precomputed OCR through the same formatting; with neither, the frame simply has no text boxes."""
+    if isinstance(image_source, str):
+        image_source = Image.open(image_source)
+    if image_source.mode == "RGBA":
+        image_source = image_source.convert("RGB")
+    if ocr_result is not None:
+        texts, boxes = ocr_result
+        coord = [[[b[0], b[1]], [b[2], b[1]], [b[2], b[3]], [b[0], b[3]]] for b in boxes]
+        text = list(texts)
+    elif use_paddleocr:
+        text_threshold = 0.5 if easyocr_args is None else easyocr_args["text_threshold"]
+        engine = _ocr_engine("paddleocr")
+        result = engine.ocr(np.array(image_source), cls=False)[0] if engine is not None else []
+        coord = [item[0] for item in result if item[1][1] > text_threshold]
+        text = [item[1][0] for item in result if item[1][1] > text_threshold]
+    else:
+        engine = _ocr_engine("easyocr")
+        result = engine.readtext(np.array(image_source), **(easyocr_args or {})) if engine is not None else []
+        coord = [item[0] for item in result]
+        text = [item[1] for item in result]
+    if display_img or output_bb_format == "xywh":        # the reference's display branch draws and keeps xywh
+        bb = [get_xywh(item) for item in coord]
+    elif output_bb_format == "xyxy":
+        bb = [get_xyxy(item) for item in coord]
+    else:
+        raise UnboundLocalError(f"output_bb_format must be 'xywh' or 'xyxy', got {output_bb_format!r}")   # the reference leaves `bb` unbound
+    return (text, bb), goal_filtering
 
 
 # ------------------------------------------------------------------------------------------ glue (App. E)

@@ -157,3 +157,44 @@ def test_omniparser_facade_on_fake_adapters(monkeypatch):
     cfg.pop("ocr_provider")
     _, icons_only = F.Omniparser(cfg).parse(b64)
     assert [e["type"] for e in icons_only] == ["icon"] * 3
+
+
+def test_check_ocr_box_glue_matches_reference():
+    """tests/golden/reference_ocr_glue.json: the reference's own check_ocr_box run with fake engines (gen_ocr_golden.py)."""
+    import json
+    from pathlib import Path
+    import numpy as np
+    from PIL import Image
+    from omniparser_amd.util import utils as U
+    recs = json.loads((Path(__file__).resolve().parent / "golden" / "reference_ocr_glue.json").read_text())
+    assert len(recs) >= 6
+    saved = dict(U._OCR_ENGINES)
+    try:
+        for r in recs:
+            c, res = r["case"], r["results"]
+            seen = {}
+
+            class Reader:
+                def readtext(self, image, **kw):
+                    seen["easyocr_kwargs"], seen["shape"] = kw, list(image.shape)
+                    return [(q, t, s) for q, t, s in res]
+
+            class Paddle:
+                def ocr(self, image, cls=False):
+                    seen["shape"] = list(image.shape)
+                    return [[[q, (t, s)] for q, t, s in res]]
+            U.set_ocr_engine(Reader(), Paddle())
+            w, h = c["size"]
+            img = Image.fromarray(np.zeros((h, w, 4 if c["mode"] == "RGBA" else 3), dtype=np.uint8), c["mode"])
+            (text, bb), gf = U.check_ocr_box(img, display_img=c["display_img"], output_bb_format=c["fmt"], goal_filtering="gf",
+                                             easyocr_args=c["args"], use_paddleocr=c["paddle"])
+            assert text == r["text"] and [list(b) for b in bb] == r["bb"] and gf == r["goal_filtering"], c
+            assert seen == r["engine_saw"], c
+        # precomputed OCR goes through the same formatting; no engine and no result -> no text boxes
+        (t, b), _ = U.check_ocr_box(img, display_img=False, output_bb_format="xywh", ocr_result=(["a"], [[10, 20, 50, 44]]))
+        assert t == ["a"] and b == [(10, 20, 40, 24)]
+        U._OCR_ENGINES.update(easyocr=None, paddleocr=None)
+        (t, b), _ = U.check_ocr_box(img, display_img=False, output_bb_format="xyxy")
+        assert t == [] and b == []
+    finally:
+        U._OCR_ENGINES.update(saved)
