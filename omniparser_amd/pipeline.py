@@ -115,13 +115,7 @@ class ScreenParser:
         start = next((i for i, b in enumerate(elems) if b["content"] is None), -1)
         boxes = [e["bbox"] for e in elems]
         non_ocr = boxes[start:] if start else boxes        # ref:util/utils.py:92-95 quirk kept
-        crops = []
-        for c in non_ocr:
-            x0, x1, y0, y1 = int(c[0] * w), int(c[2] * w), int(c[1] * h), int(c[3] * h)
-            if x1 - x0 <= 0 or y1 - y0 <= 0 or x0 < 0 or y0 < 0:
-                continue
-            crops.append([x0, y0, min(x1, w), min(y1, h)])
-        return elems, crops
+        return elems, U.crop_boxes_px(non_ocr, w, h)
 
     # ---- stage 3: caption all crops of all frames in packed micro-batches
     def caption(self, frames: Sequence[torch.Tensor], crops_per_frame: List[List[List[int]]], max_new_tokens=20):

@@ -320,6 +320,22 @@ def remove_overlap_new(boxes, iou_threshold, ocr_bbox=None):
     return [t for t_i, t in enumerate(ocr_bbox) if alive[t_i]] + appended
 
 
+def crop_boxes_px(ratio_boxes, W, H):
+    """Integer crop rectangles exactly as ref:util/utils.py:95-102 cuts them: `int(coord[k] * side)` there multiplies an element
+    of an f32 TENSOR by a Python int — an f32 product, then truncation (NOT Python-float arithmetic: 100/1920 * 1920 is 100 in
+    f32 and 99.99999 in f64).  Empty crops make cv2.resize raise and are skipped by the reference's bare `except`; numpy slicing
+    clips the far edge at the image border.  Fixture: tests/golden/reference_glue.json::crop_shapes."""
+    out = []
+    fw, fh = np.float32(W), np.float32(H)
+    for c in ratio_boxes:
+        x0, x1 = int(np.float32(c[0]) * fw), int(np.float32(c[2]) * fw)
+        y0, y1 = int(np.float32(c[1]) * fh), int(np.float32(c[3]) * fh)
+        if x1 - x0 <= 0 or y1 - y0 <= 0 or x0 < 0 or y0 < 0:
+            continue
+        out.append([x0, y0, min(x1, W), min(y1, H)])
+    return out
+
+
 @torch.inference_mode()
 def get_parsed_content_icon(filtered_boxes, starting_idx, image_source, caption_model_processor, prompt=None, batch_size=128):
     """ref:util/utils.py:88-132.  Crops are cut/resized/normalised on device and captioned by the HIP
@@ -327,13 +343,7 @@ def get_parsed_content_icon(filtered_boxes, starting_idx, image_source, caption_
     model, processor = caption_model_processor["model"], caption_model_processor["processor"]
     non_ocr = filtered_boxes[starting_idx:] if starting_idx else filtered_boxes
     H, W = image_source.shape[0], image_source.shape[1]
-    boxes_px = []
-    for coord in (non_ocr.tolist() if isinstance(non_ocr, torch.Tensor) else non_ocr):
-        x0, x1 = int(coord[0] * W), int(coord[2] * W)
-        y0, y1 = int(coord[1] * H), int(coord[3] * H)
-        if x1 - x0 <= 0 or y1 - y0 <= 0 or x0 < 0 or y0 < 0:
-            continue           # cv2.resize raises on empty crops; the reference's bare `except` skips them
-        boxes_px.append([x0, y0, min(x1, W), min(y1, H)])
+    boxes_px = crop_boxes_px(non_ocr.tolist() if isinstance(non_ocr, torch.Tensor) else non_ocr, W, H)
     if not boxes_px:
         return []
     img_dev = image_source if isinstance(image_source, torch.Tensor) else torch.from_numpy(np.array(image_source, order="C"))   # writable copy (PIL views are read-only)

@@ -172,6 +172,34 @@ def main():
         som.append({"w": w, "h": h, "seed": 10 + ci, "ocr_seed": ci, "xyxy": xyxy.tolist(), "elems": elems,
                     "label_keys": list(lab.keys())})
     out["get_som_labeled_img"] = som
+    # ---- crop geometry of get_parsed_content_icon (ref:util/utils.py:95-102): `int(coord * W)` multiplies an f32 TENSOR element by a
+    # Python int, i.e. in f32 — near-integer pixel coordinates truncate differently than in Python-float arithmetic
+    import cv2 as cv2shim
+    crops = []
+    real_resize = cv2shim.resize
+    for ci, (w, h) in enumerate([(1920, 1080), (1919, 1079), (1280, 800)]):
+        r3 = np.random.default_rng(500 + ci)
+        px = rand_boxes(r3, 48, w, h, 6, 120)
+        px[::3] = np.round(px[::3])                                  # exact integer pixel corners
+        px[1::6] = np.round(px[1::6]) + r3.uniform(-2e-4, 2e-4, size=px[1::6].shape)
+        px[5] = [40.0, 50.0, 40.0, 90.0]                             # empty crop: cv2.resize raises, the reference skips it
+        px[9] = [w - 30.5, h - 20.25, w, h]                          # touches the image border
+        ratio = torch.tensor(px, dtype=torch.float32) / torch.Tensor([w, h, w, h])
+        shapes = []
+
+        def rec_resize(img, dsize, **k):
+            if img.shape[0] == 0 or img.shape[1] == 0:
+                raise ValueError("empty")
+            shapes.append([int(img.shape[0]), int(img.shape[1])])
+            return real_resize(img, dsize, **k)
+        RU.cv2.resize = rec_resize
+        img = np.zeros((h, w, 3), dtype=np.uint8)
+        for start in (0, 7):
+            shapes.clear()
+            RU.get_parsed_content_icon(ratio, start, img, {"model": FakeCap(), "processor": FakeProc()}, batch_size=64)
+            crops.append({"w": w, "h": h, "start": start, "ratio": ratio.tolist(), "shapes": [list(x) for x in shapes]})
+        RU.cv2.resize = real_resize
+    out["crop_shapes"] = crops
     (Path(__file__).parent / "reference_glue.json").write_text(json.dumps(out))
     print("wrote", Path(__file__).parent / "reference_glue.json", {k: len(v) for k, v in out.items()})
 

@@ -198,3 +198,19 @@ def test_check_ocr_box_glue_matches_reference():
         assert t == [] and b == []
     finally:
         U._OCR_ENGINES.update(saved)
+
+
+def test_crop_rectangles_match_reference_f32_truncation():
+    """reference_glue.json::crop_shapes — recorded from the reference's own get_parsed_content_icon (crop shapes seen by cv2.resize)."""
+    from omniparser_amd.util.utils import crop_boxes_px
+    assert len(GOLD["crop_shapes"]) >= 6
+    differs_from_f64 = 0
+    for rec in GOLD["crop_shapes"]:
+        w, h, start = rec["w"], rec["h"], rec["start"]
+        boxes = rec["ratio"][start:] if start else rec["ratio"]
+        got = [[b[3] - b[1], b[2] - b[0]] for b in crop_boxes_px(boxes, w, h)]
+        assert got == rec["shapes"]
+        f64 = [[min(int(c[3] * h), h) - int(c[1] * h), min(int(c[2] * w), w) - int(c[0] * w)] for c in boxes
+               if int(c[2] * w) - int(c[0] * w) > 0 and int(c[3] * h) - int(c[1] * h) > 0]
+        differs_from_f64 += f64 != rec["shapes"]
+    assert differs_from_f64 >= 1          # the fixture does exercise the f32-vs-f64 difference
