@@ -152,6 +152,18 @@ enum {
   /* f32 channel slice of a token matrix -> format B (OMNI_OP_CONV i20 = 2), in place when p0 == p4 and the slices coincide.
    *  p0 x [rows, ldi] p4 y [rows, ldo]; i0*i1 rows i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (all multiples of 16) */
   OMNI_OP_SPLIT_CONVERT = 19,
+  /* Detect -> caption hand-off of ONE screenshot on the device: ref:util/utils.py:432-453 (ratio boxes, int_box_area filter),
+   * remove_overlap_new (:241-319, incl. its list.remove quirk), the "content is None last" ordering (:449-451) and the crop
+   * rectangles of get_parsed_content_icon (:90-98), in the reference's own mix of f32 / Python-float (f64) arithmetic.
+   *  p0 boxes f32[max_det,4] (px, score order; ratios if i5) p1 box count i32* p2 OCR boxes f64[cap,4] (ratios, already
+   *  int_box_area-filtered by the host) p3 OCR table i32[2 + 2*cap]: {live OCR count, 0, (equality class, rank in class) per box}
+   *  p4 out element table i32[i6,2]: (kind 0 OCR | 1 icon with OCR text | 2 icon to caption, source index) in output order
+   *  p5 out crop rectangles i32[max_det,4] (x0,y0,x1,y1 px, caption order) p6 out i32[4]: {elements, crops, index of the
+   *  first caption-less element or -1, surviving OCR boxes} p7 out donor bit masks u64[max_det, i4] (OCR boxes whose text an
+   *  icon collects)
+   *  i0 max_det (<= 512) i1 OCR capacity (<= 1024) i2 W i3 H i4 mask words per icon i5 boxes are ratios i6 element capacity
+   *  i7 = 1: the overlap threshold is the f64 with bit pattern i9:i8 (Python passes 0.7 as a double), else f0 */
+  OMNI_OP_GLUE = 20,
   OMNI_OP__COUNT
 };
 

@@ -77,3 +77,4 @@ int omni_launch_layernorm(const omni_op_t* op, hipStream_t s);
 int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s);
 int omni_launch_attention(const omni_op_t* op, hipStream_t s);
 int omni_launch_misc(const omni_op_t* op, hipStream_t s);
+int omni_launch_glue(const omni_op_t* op, hipStream_t s);

@@ -17,12 +17,55 @@ from .util import utils as U
 from .util.yolov9 import YOLOv9Detector
 
 
+OCR_CAP = 1024           # OMNI_OP_GLUE capacities (csrc/glue_ops.hip)
+MASK_WORDS = OCR_CAP // 64
+
+
+def _f64_bits(x: float):
+    import struct
+    lo, hi = struct.unpack("<ii", struct.pack("<d", float(x)))
+    return lo, hi
+
+
+class _GlueState:
+    """Device side of the detect -> caption hand-off for one detector plan (batch B): fixed buffers + one small plan of B
+    OMNI_OP_GLUE ops replayed right behind the detector graph on the detector's stream."""
+
+    def __init__(self, dp, det, iw, ih, thr):
+        dev, B, md = det.device, dp.batch, dp.out_boxes.shape[1]
+        self.B, self.md = B, md
+        with torch.cuda.stream(det.stream):
+            self.ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64, device=dev)
+            self.meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32, device=dev)
+            self.elems = torch.zeros(B, md + OCR_CAP, 2, dtype=torch.int32, device=dev)
+            self.crops = torch.zeros(B, md, 4, dtype=torch.int32, device=dev)
+            self.counts = torch.zeros(B, 4, dtype=torch.int32, device=dev)
+            self.donors = torch.zeros(B, md, MASK_WORDS, dtype=torch.int64, device=dev)
+        self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64).pin_memory()
+        self.h_meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32).pin_memory()
+        lo, hi = _f64_bits(thr)
+        ops = [L.make_op(L.OP_GLUE, L.F32,
+                         p=[dp.out_boxes[b].data_ptr(), dp.out_count[b:].data_ptr(), self.ocr[b].data_ptr(), self.meta[b].data_ptr(),
+                            self.elems[b].data_ptr(), self.crops[b].data_ptr(), self.counts[b].data_ptr(), self.donors[b].data_ptr()],
+                         i={0: md, 1: OCR_CAP, 2: iw, 3: ih, 4: MASK_WORDS, 5: 0, 6: md + OCR_CAP, 7: 1, 8: lo, 9: hi})
+               for b in range(B)]
+        self.plan = L.Plan(ops)
+        det.stream.synchronize()
+        if det.use_graph:
+            self.plan.run(det.stream)
+            det.stream.synchronize()
+            self.plan.capture(det.stream)
+
+
 class ScreenParser:
     def __init__(self, detector: YOLOv9Detector, captioner: Florence2Captioner, processor=None,
                  box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640, batch_size=128,
                  tile_large=False):
         self.det, self.cap = detector, captioner
         self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
+        # detect -> caption hand-off on the device (csrc/glue_ops.hip); OMNI_DEVICE_GLUE=0 = the host twin (`glue`, numpy)
+        import os
+        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "1") != "0"
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
@@ -117,11 +160,95 @@ class ScreenParser:
         non_ocr = boxes[start:] if start else boxes        # ref:util/utils.py:92-95 quirk kept
         return elems, U.crop_boxes_px(non_ocr, w, h)
 
+    # ---- stage 2': the same hand-off on the device.  Host work before the launch touches the OCR list only (its ratio
+    #      boxes, int_box_area filter and dict-equality classes do not depend on the detector); after the launch the host
+    #      reads four counters per frame, and builds the element dicts at the very end from the device tables.
+    @staticmethod
+    def ocr_elements(w, h, ocr_bbox, ocr_text):
+        if ocr_bbox:
+            ocr_r = (torch.tensor(ocr_bbox) / torch.Tensor([w, h, w, h])).tolist()
+        else:
+            ocr_r, ocr_text = [], []
+        return [{"type": "text", "bbox": b, "interactivity": False, "content": t, "source": "box_ocr_content_ocr"}
+                for b, t in zip(ocr_r, ocr_text) if U.int_box_area(b, w, h) > 0]
+
+    def detect_glue(self, frames, ocr, pad_to=None):
+        ih, iw = frames[0].shape[:2]
+        det = self.det
+        dp = det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
+        key = ("glue", float(self.iou_threshold))
+        gs = getattr(dp, "_glue", {}).get(key)
+        if gs is None:
+            with torch.cuda.device(det.device):
+                gs = _GlueState(dp, det, iw, ih, self.iou_threshold)
+            dp._glue = {**getattr(dp, "_glue", {}), key: gs}
+        ocr_els = []
+        gs.h_meta.zero_()
+        for fi in range(len(frames)):
+            texts, boxes = ocr[fi] if ocr is not None else ([], [])
+            els = self.ocr_elements(iw, ih, boxes, texts)
+            if len(els) > OCR_CAP:
+                raise ValueError(f"{len(els)} OCR boxes exceed the device hand-off capacity ({OCR_CAP}); set OMNI_DEVICE_GLUE=0")
+            ocr_els.append(els)
+            m = len(els)
+            if m:
+                gs.h_ocr[fi, :m] = torch.tensor([e["bbox"] for e in els], dtype=torch.float64)
+                first, seen = {}, {}
+                tab = gs.h_meta[fi, 2:2 + 2 * m].view(m, 2)
+                for j, e in enumerate(els):                      # list.remove() works on dict equality: bbox + content decide it
+                    k = (tuple(e["bbox"]), e["content"])
+                    cls = first.setdefault(k, j)
+                    tab[j, 0] = cls
+                    tab[j, 1] = seen.get(cls, 0)
+                    seen[cls] = seen.get(cls, 0) + 1
+            gs.h_meta[fi, 0] = m
+        with torch.cuda.stream(det.stream):
+            for bi, f in enumerate(frames):
+                dp.img[bi].copy_(f, non_blocking=True)
+            gs.ocr.copy_(gs.h_ocr, non_blocking=True)
+            gs.meta.copy_(gs.h_meta, non_blocking=True)
+            dp.launch(det)
+            gs.plan.replay(det.stream) if det.use_graph else gs.plan.run(det.stream)
+            counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
+        return dp, gs, ocr_els, counts
+
+    def assemble(self, dp, gs, ocr_els, counts, iw, ih, n_frames):
+        """element dicts of every frame from the device tables (called once, after the caption micro-batches were queued)."""
+        with torch.cuda.stream(self.det.stream):
+            boxes = dp.out_boxes.cpu(); kcnt = dp.out_count.cpu(); elems = gs.elems.cpu(); donors = gs.donors.cpu()
+        out = []
+        for f in range(n_frames):
+            k = int(kcnt[f])
+            ratios = (boxes[f, :k] / torch.Tensor([iw, ih, iw, ih])).tolist()
+            els = []
+            for kind, src in elems[f, : int(counts[f, 0])].tolist():
+                if kind == 0:
+                    els.append(ocr_els[f][src])
+                    continue
+                label = None
+                if kind == 1:
+                    label = ""
+                    for wd in range(MASK_WORDS):
+                        bits = int(donors[f, src, wd]) & 0xFFFFFFFFFFFFFFFF
+                        while bits:
+                            low = bits & -bits
+                            label += ocr_els[f][wd * 64 + low.bit_length() - 1]["content"] + " "
+                            bits ^= low
+                els.append({"type": "icon", "bbox": ratios[src], "interactivity": True, "content": label,
+                            "source": "box_yolo_content_ocr" if kind == 1 else "box_yolo_content_yolo"})
+            out.append(els)
+        return out
+
     # ---- stage 3: caption all crops of all frames in packed micro-batches
-    def caption(self, frames: Sequence[torch.Tensor], crops_per_frame: List[List[List[int]]], max_new_tokens=20):
+    def caption(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=20, crops_dev: Optional[torch.Tensor] = None):
+        """crops_per_frame: host rectangles per frame, or — with `crops_dev` (int32 [frames, max_det, 4] on the device, rows in
+        caption order) — just the number of crops per frame: the rectangles then never visit the host."""
         cap = self.cap
         R = cap.resolution
-        flat = [(fi, b) for fi, cl in enumerate(crops_per_frame) for b in cl]
+        if crops_dev is not None:
+            flat = [(fi, k) for fi, n in enumerate(crops_per_frame) for k in range(int(n))]
+        else:
+            flat = [(fi, b) for fi, cl in enumerate(crops_per_frame) for b in cl]
         ids_all = []
         if cap._lut is None:
             cap._lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)).to(cap.device)
@@ -138,7 +265,8 @@ class ScreenParser:
                 c64 = torch.empty((n, 64, 64, 3), dtype=torch.uint8, device=cap.device)
                 tmp = torch.empty((n, 64, R, 3), dtype=torch.uint8, device=cap.device) if R != 64 else None
                 bb, kk, ks = cap._bic if R != 64 else (None, None, 0)
-                bx = torch.tensor([b for _, b in chunk], dtype=torch.int32).to(cap.device, non_blocking=True)
+                if crops_dev is None:
+                    bx = torch.tensor([b for _, b in chunk], dtype=torch.int32).to(cap.device, non_blocking=True)
                 o = 0
                 while o < n:                                   # one crop launch per source frame run
                     fi = chunk[o][0]
@@ -146,9 +274,10 @@ class ScreenParser:
                     while e < n and chunk[e][0] == fi:
                         e += 1
                     H, W = frames[fi].shape[:2]
+                    rects = crops_dev[fi, chunk[o][1]:] if crops_dev is not None else bx[o:]     # rows of one frame are contiguous
                     op = L.make_op(
                         L.OP_CROP_RESIZE, cap.dtype,
-                        p=[frames[fi].data_ptr(), bx[o:].data_ptr(), c64[o:].data_ptr(), tmp[o:].data_ptr() if tmp is not None else None,
+                        p=[frames[fi].data_ptr(), rects.data_ptr(), c64[o:].data_ptr(), tmp[o:].data_ptr() if tmp is not None else None,
                            cp.x_in.ptr + o * R * R * cp.x_in.ld * esz, bb.data_ptr() if bb is not None else None,
                            kk.data_ptr() if kk is not None else None, cap._lut.data_ptr()],
                         i={0: e - o, 1: H, 2: W, 3: R, 4: ks, 13: cp.x_in.ld},
@@ -176,7 +305,25 @@ class ScreenParser:
             return self._parse_batch_locked(frames, ocr, return_ids, iw, ih, pad_to)
 
     def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih, pad_to=None):
-        if self.tile_large and (iw > 1952 or ih > 1112):
+        tiled = self.tile_large and (iw > 1952 or ih > 1112)
+        if self.device_glue and not tiled:
+            dp, gs, ocr_els, counts = self.detect_glue(frames, ocr, pad_to)
+            n_crops = [int(counts[f, 1]) for f in range(len(frames))]
+            if self.cap.stream is not self.det.stream:
+                self.cap.stream.wait_stream(self.det.stream)           # crop rectangles are produced on the detector's stream
+            caps = self.caption(frames, n_crops, crops_dev=gs.crops)
+            elems_all = self.assemble(dp, gs, ocr_els, counts, iw, ih, len(frames))
+            ids_out = []
+            for el, cl in zip(elems_all, caps):
+                q = list(cl)
+                for e in el:
+                    if e["content"] is None and q:
+                        e["content"] = q.pop(0)[0]
+                ids_out.append([r for _, r in cl])
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()]}
+            self.last_crops = [gs.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
+            return (elems_all, ids_out) if return_ids else elems_all
+        if tiled:
             det_boxes = [self.detect_tiled(f)[0] for f in frames]      # >1080p: overlapping tiles + global NMS (our policy)
         else:
             det_boxes = self.detect(frames, pad_to)

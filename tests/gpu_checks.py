@@ -978,3 +978,107 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
         got = cp.x_in.t[j, :, :, :3].float().cpu()
         assert torch.equal(got, pv), f"crop tensor differs for frame {f} crop {k}: max abs {(got - pv).abs().max().item():.3e}"
     return out
+
+
+# ------------------------------------------------------------------------------------------ device hand-off (OMNI_OP_GLUE)
+def _run_glue_op(icons_f32, n_icons, ocr_els, w, h, thr, ratio_input, max_det=None):
+    """one OMNI_OP_GLUE launch; returns (elements [(kind, src)], donor masks, crop rectangles, counts)."""
+    from omniparser_amd.pipeline import MASK_WORDS, OCR_CAP, _f64_bits
+    md = max_det or max(int(icons_f32.shape[0]), 1)
+    boxes = torch.zeros(md, 4, dtype=torch.float32)
+    boxes[: icons_f32.shape[0]] = icons_f32
+    m = len(ocr_els)
+    ocr = torch.zeros(OCR_CAP, 4, dtype=torch.float64)
+    meta = torch.zeros(2 + 2 * OCR_CAP, dtype=torch.int32)
+    meta[0] = m
+    first, seen = {}, {}
+    for j, e in enumerate(ocr_els):
+        ocr[j] = torch.tensor(e["bbox"], dtype=torch.float64)
+        k = (tuple(e["bbox"]), e["content"])
+        cls = first.setdefault(k, j)
+        meta[2 + 2 * j] = cls
+        meta[3 + 2 * j] = seen.get(cls, 0)
+        seen[cls] = seen.get(cls, 0) + 1
+    d = {"boxes": boxes.to(DEV), "count": torch.tensor([n_icons], dtype=torch.int32, device=DEV), "ocr": ocr.to(DEV), "meta": meta.to(DEV),
+         "elems": torch.full((md + OCR_CAP, 2), -7, dtype=torch.int32, device=DEV), "crops": torch.full((md, 4), -7, dtype=torch.int32, device=DEV),
+         "counts": torch.zeros(4, dtype=torch.int32, device=DEV), "donors": torch.zeros(md, MASK_WORDS, dtype=torch.int64, device=DEV)}
+    lo, hi = _f64_bits(thr)
+    L.launch(L.make_op(L.OP_GLUE, L.F32, p=[d[k].data_ptr() for k in ("boxes", "count", "ocr", "meta", "elems", "crops", "counts", "donors")],
+                       i={0: md, 1: OCR_CAP, 2: w, 3: h, 4: MASK_WORDS, 5: 1 if ratio_input else 0, 6: md + OCR_CAP, 7: 1, 8: lo, 9: hi}))
+    _sync()
+    counts = d["counts"].cpu().tolist()
+    return d["elems"].cpu()[: counts[0]].tolist(), d["donors"].cpu(), d["crops"].cpu()[: counts[1]].tolist(), counts
+
+
+def _elements_from_tables(table, donors, icon_ratio_lists, ocr_els):
+    from omniparser_amd.pipeline import MASK_WORDS
+    out = []
+    for kind, src in table:
+        if kind == 0:
+            out.append(ocr_els[src]); continue
+        label = None
+        if kind == 1:
+            label = ""
+            for wd in range(MASK_WORDS):
+                bits = int(donors[src, wd]) & 0xFFFFFFFFFFFFFFFF
+                while bits:
+                    low = bits & -bits
+                    label += ocr_els[wd * 64 + low.bit_length() - 1]["content"] + " "
+                    bits ^= low
+        out.append({"type": "icon", "bbox": icon_ratio_lists[src], "interactivity": True, "content": label,
+                    "source": "box_yolo_content_ocr" if kind == 1 else "box_yolo_content_yolo"})
+    return out
+
+
+def check_glue(seed=0, trials=40):
+    """OMNI_OP_GLUE (a) against the fixtures recorded from the reference's own remove_overlap_new / int_box_area
+    (tests/golden/reference_glue.json, exact, incl. the list.remove quirk) and (b) against the host twin ScreenParser.glue on
+    random boxes: element lists, order, OCR labels, crop rectangles — exact."""
+    import json
+    from pathlib import Path
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.util import utils as U
+    gold = json.loads((Path(__file__).resolve().parent / "golden" / "reference_glue.json").read_text())
+    n_cases = 0
+    for c in gold["remove_overlap_new"]:
+        w, h, thr = c["w"], c["h"], c["thr"]
+        raw = torch.tensor(c["icons_raw"], dtype=torch.float32).reshape(-1, 4)
+        table, donors, crops, counts = _run_glue_op(raw, raw.shape[0], c["ocr"], w, h, thr, ratio_input=True)
+        got = _elements_from_tables(table, donors, raw.tolist(), c["ocr"])
+        exp = c["out"]
+        if not c["ocr"]:             # the reference returns bare boxes without an OCR list
+            exp = [e if isinstance(e, dict) else {"type": "icon", "bbox": e, "interactivity": True, "content": None, "source": "box_yolo_content_yolo"} for e in exp]
+        exp = sorted(exp, key=lambda x: x["content"] is None)
+        assert got == exp, f"fixture case w={w} thr={thr}: {len(got)} vs {len(exp)} elements"
+        n_cases += 1
+    rng = np.random.default_rng(seed)
+    sp = ScreenParser(None, None, processor=object())
+    for trial in range(trials):
+        w, h = [(1920, 1080), (1919, 1079), (1280, 800)][trial % 3]
+        n, m = int(rng.integers(0, 300)), int(rng.integers(0, 60))
+        xy = rng.uniform(0, 1, (n, 2)) * [w - 150, h - 150]
+        ic = np.concatenate([xy, xy + rng.uniform(0.4, 150, (n, 2))], 1)
+        for j in range(0, max(n - 1, 0), 3):
+            ic[j + 1] = ic[j] + rng.uniform(-6, 6, 4)
+        if n > 4:
+            ic[3] = np.round(ic[3]); ic[4, 2:] = ic[4, :2] + [0.3, 40]            # integer corners; zero integer area
+        oc = np.concatenate([rng.uniform(0, 1, (m, 2)) * [w - 200, h - 60], np.zeros((m, 2))], 1)
+        oc[:, 2:] = oc[:, :2] + rng.uniform(8, 200, (m, 2))
+        for j in range(0, min(n, m), 2):
+            oc[j] = ic[j] + ([3, 3, -3, -3] if j % 4 == 0 else [-20, -20, 20, 20])
+        if m > 3:
+            oc[2] = oc[1]
+        oc = np.clip(np.round(oc), 0, [w, h, w, h]).astype(np.int64)
+        texts = [f"t{j % 5}" for j in range(m)]
+        sp.iou_threshold = thr = [0.1, 0.7, 0.9][trial % 3]
+        px = torch.tensor(ic, dtype=torch.float32).reshape(-1, 4)
+        elems, crops_h = sp.glue(px, w, h, oc.tolist(), texts)
+        ocr_els = sp.ocr_elements(w, h, oc.tolist(), texts)
+        table, donors, crops_d, counts = _run_glue_op(px, n, ocr_els, w, h, thr, ratio_input=False, max_det=300)
+        ratios = (px / torch.Tensor([w, h, w, h])).tolist()
+        got = _elements_from_tables(table, donors, ratios, ocr_els)
+        assert got == elems, f"trial {trial}: element lists differ ({len(got)} vs {len(elems)})"
+        assert crops_d == crops_h, f"trial {trial}: crop rectangles differ"
+        start = next((i for i, e in enumerate(elems) if e["content"] is None), -1)
+        assert counts[2] == start and counts[0] == len(elems)
+    return {"fixture_cases": n_cases, "random_trials": trials}
