@@ -61,8 +61,18 @@ IW, IH = 1920, 1080
 CONF, NMS_IOU, OVERLAP_IOU, MAX_DET = 0.05, 0.1, 0.7, 300   # ref:util/omniparser.py:30, ref:util/utils.py:431
 
 
+_T0 = time.perf_counter()
+
+
+def note(msg):
+    """progress line on stderr (the JSON line on stdout stays the only stdout output)"""
+    print(f"[bench {time.perf_counter() - _T0:7.1f}s] {msg}", file=sys.stderr, flush=True)
+
+
 def main():
     args = parse_args()
+    import faulthandler
+    faulthandler.dump_traceback_later(int(os.environ.get("OMNI_BENCH_WATCHDOG", "240")), repeat=True, file=sys.stderr)   # where is it, if it stalls
     import torch
     import torch.distributed as dist
     from omniparser_amd import _lib as L
@@ -86,7 +96,9 @@ def main():
         dist.barrier()
     blob = default_path(0, 1, args.width)
     assert blob.exists(), blob
+    note("stand-in checkpoints ready")
     det = YOLOv9Detector(model_path=blob, device=dev, precision=args.precision)
+    note("detector loaded (blob imported and verified against itself)")
     B = args.batch
     frames = [torch.from_numpy(synthetic_screenshot(s, IW, IH)).to(dev) for s in range(8)]
     ocr = [synthetic_ocr(s, IW, IH, 40) for s in range(8)]
@@ -143,6 +155,7 @@ def main():
 
     for w in range(args.warmup):
         step(w)
+        note(f"warm-up step {w} done")
     sync_all()
     crop_counts.clear()
     t0 = time.perf_counter()
@@ -152,6 +165,7 @@ def main():
         allr = OD.gather_records(recs, n_items, rank, world)
     sync_all()
     elapsed = time.perf_counter() - t0
+    note(f"timed region done: {elapsed:.2f} s for {args.steps} steps")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -189,10 +203,13 @@ def main():
 
     if rank == 0:
         out["roofline"] = roofline(args, det, parser, locals().get("dp"), crop_counts, B)
+        note("roofline replay done")
         if world == 1 and not args.no_extra:
             out["extra"] = extras(args, det, parser, frames, ocr, dev)
+            note("extras done")
         if world == 1 and not args.no_cpu_baseline:
             out["cpu_baseline"] = cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0))
+        faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.barrier()

@@ -584,6 +584,7 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
             iou_mat = inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)
             best = iou_mat.max(1)
             rec["matched_min_iou"] = best.values.min().item()
+            rec["matched_frac_iou95"] = float(((best.values >= 0.95) & (gc[best.indices] == rc)).float().mean())
             rec["matched_is_bijection"] = bool(len(rb) == len(gb) and len(set(best.indices.tolist())) == len(gb))
             rec["matched_cls_equal"] = bool((gc[best.indices] == rc).all())
             rec["matched_max_score_diff"] = (gs[best.indices] - rs).abs().max().item()
@@ -772,7 +773,7 @@ def logit_margins(model, cap, cp, pix, ids_ref, max_new):
     with torch.inference_mode():
         ref = model.generate(input_ids=inp, pixel_values=pix, max_new_tokens=max_new, num_beams=1, do_sample=False,
                              output_logits=True, return_dict_in_generate=True)
-    with torch.cuda.stream(cap.stream):
+    with torch.inference_mode(), torch.cuda.stream(cap.stream):
         cp.reset()
         cp.x_in.t[:n, :, :, :3] = pix.to(cap.device).permute(0, 2, 3, 1).to(cp.x_in.t.dtype)
         cp.encode_plan.run(cap.stream)
