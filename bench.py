@@ -268,7 +268,8 @@ def roofline(args, det, parser, dp, crop_counts, B):
             if cp is None:
                 continue
             cnt = mbs.count(bucket)
-            with torch_stream(cap.stream):
+            import torch
+            with torch.inference_mode(), torch_stream(cap.stream):
                 cp.reset()
             be, ne = profile_plan(cp.encode_plan, cap.stream)
             bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20)

@@ -84,8 +84,11 @@ extern "C" int omni_plan_num_ops(const omni_plan_t* plan) { return plan ? (int)p
 extern "C" int omni_plan_run(omni_plan_t* plan, void* stream) {
   if (!plan) { omni_set_error("omni_plan_run: null plan"); return OMNI_E_ARG; }
   hipStream_t s = (hipStream_t)stream;
+  static const bool trace = getenv("OMNI_PLAN_TRACE") != nullptr;      // debugging aid: synchronise and name every op (eager replays only)
   for (size_t i = 0; i < plan->ops.size(); ++i) {
+    if (trace) { fprintf(stderr, "[omni] op %zu/%zu kind %d ...", i, plan->ops.size(), plan->ops[i].kind); fflush(stderr); }
     int rc = dispatch(&plan->ops[i], s);
+    if (trace) { hipError_t e = hipStreamSynchronize(s); fprintf(stderr, " %s\n", e == hipSuccess ? "ok" : hipGetErrorString(e)); fflush(stderr); }
     if (rc) {
       char prev[400];
       strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;

@@ -450,7 +450,7 @@ class Florence2Captioner:
         self.w = FlorenceWeights(model_dir)
         self.config = _Config(name_or_path=str(model_dir) if "florence" in str(model_dir).lower() else f"florence:{model_dir}",
                               model_type="florence2")
-        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"
+        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0" and os.environ.get("OMNI_HIPGRAPH_CAP", "1") != "0"
         self.stream = torch.cuda.Stream(device=device)
         self._wcache = {}
         self._plans = {}

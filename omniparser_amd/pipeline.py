@@ -49,12 +49,8 @@ class _GlueState:
                             self.elems[b].data_ptr(), self.crops[b].data_ptr(), self.counts[b].data_ptr(), self.donors[b].data_ptr()],
                          i={0: md, 1: OCR_CAP, 2: iw, 3: ih, 4: MASK_WORDS, 5: 0, 6: md + OCR_CAP, 7: 1, 8: lo, 9: hi})
                for b in range(B)]
-        self.plan = L.Plan(ops)
-        det.stream.synchronize()
-        if det.use_graph:
-            self.plan.run(det.stream)
-            det.stream.synchronize()
-            self.plan.capture(det.stream)
+        self.plan = L.Plan(ops)        # replayed EAGERLY (B one-workgroup launches): as a captured hipGraph its second replay behind the
+        det.stream.synchronize()       # detector graph never completed on ROCm 7.2 (profiles/r2_notes.md); eager costs ~5 us per frame
 
 
 class ScreenParser:
@@ -208,7 +204,7 @@ class ScreenParser:
             gs.ocr.copy_(gs.h_ocr, non_blocking=True)
             gs.meta.copy_(gs.h_meta, non_blocking=True)
             dp.launch(det)
-            gs.plan.replay(det.stream) if det.use_graph else gs.plan.run(det.stream)
+            gs.plan.run(det.stream)
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
         return dp, gs, ocr_els, counts
 
