@@ -41,8 +41,11 @@ class _GlueState:
             self.crops = torch.zeros(B, md, 4, dtype=torch.int32, device=dev)
             self.counts = torch.zeros(B, 4, dtype=torch.int32, device=dev)
             self.donors = torch.zeros(B, md, MASK_WORDS, dtype=torch.int64, device=dev)
-        self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64).pin_memory()
-        self.h_meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32).pin_memory()
+        # plain (pageable) staging + BLOCKING uploads: a non_blocking copy from pinned memory makes torch record an event on the
+        # detector's stream, and on ROCm 7.2 the detector hipGraph's next replay behind such an event never completed
+        # (bisected in profiles/r2_notes.md); the tables are a few KB per frame
+        self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64)
+        self.h_meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32)
         lo, hi = _f64_bits(thr)
         ops = [L.make_op(L.OP_GLUE, L.F32,
                          p=[dp.out_boxes[b].data_ptr(), dp.out_count[b:].data_ptr(), self.ocr[b].data_ptr(), self.meta[b].data_ptr(),
@@ -59,9 +62,9 @@ class ScreenParser:
                  tile_large=False):
         self.det, self.cap = detector, captioner
         self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
-        # detect -> caption hand-off on the device (csrc/glue_ops.hip); OMNI_DEVICE_GLUE=0 = the host twin (`glue`, numpy)
+        # detect -> caption hand-off: host twin (`glue`, numpy) by default; OMNI_DEVICE_GLUE=1 = on the device (csrc/glue_ops.hip)
         import os
-        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "1") != "0"
+        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") == "1"
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
@@ -201,8 +204,8 @@ class ScreenParser:
         with torch.cuda.stream(det.stream):
             for bi, f in enumerate(frames):
                 dp.img[bi].copy_(f, non_blocking=True)
-            gs.ocr.copy_(gs.h_ocr, non_blocking=True)
-            gs.meta.copy_(gs.h_meta, non_blocking=True)
+            gs.ocr.copy_(gs.h_ocr)
+            gs.meta.copy_(gs.h_meta)
             dp.launch(det)
             gs.plan.run(det.stream)
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
@@ -305,8 +308,7 @@ class ScreenParser:
         if self.device_glue and not tiled:
             dp, gs, ocr_els, counts = self.detect_glue(frames, ocr, pad_to)
             n_crops = [int(counts[f, 1]) for f in range(len(frames))]
-            if self.cap.stream is not self.det.stream:
-                self.cap.stream.wait_stream(self.det.stream)           # crop rectangles are produced on the detector's stream
+            # crop rectangles were produced on the detector's stream, which the counts read-back above has drained: no event needed
             caps = self.caption(frames, n_crops, crops_dev=gs.crops)
             elems_all = self.assemble(dp, gs, ocr_els, counts, iw, ih, len(frames))
             ids_out = []
