@@ -202,13 +202,22 @@ def main():
         out["config"]["caption_micro_batch"] = 128
 
     if rank == 0:
-        out["roofline"] = roofline(args, det, parser, locals().get("dp"), crop_counts, B)
-        note("roofline replay done")
+        # the timed result above is final: nothing below may keep the JSON line from being printed
+        def guarded(name, fn):
+            try:
+                with torch.inference_mode():
+                    out[name] = fn()
+                note(f"{name} done")
+            except Exception as e:      # noqa: BLE001 — reported in the line itself
+                import traceback
+                traceback.print_exc(file=sys.stderr)
+                out[name] = {"error": f"{type(e).__name__}: {e}"[:400]}
+        dp_obj = dp if args.mode == "detect" else None
+        guarded("roofline", lambda: roofline(args, det, parser, dp_obj, crop_counts, B))
         if world == 1 and not args.no_extra:
-            out["extra"] = extras(args, det, parser, frames, ocr, dev)
-            note("extras done")
+            guarded("extra", lambda: extras(args, det, parser, frames, ocr, dev))
         if world == 1 and not args.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0))
+            guarded("cpu_baseline", lambda: cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0)))
         faulthandler.cancel_dump_traceback_later()
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -116,10 +116,11 @@ enum {
    * 12x12 window attention incl. the unmasked zero-padded window tokens (florence2 :338-398).
    *  p0 q p1 k p2 v (token matrices) p4 o p5 kbias f32 p6 vbias f32 (window padding rows)
    *  i0 ldq i1 ldk i2 ldv i3 ldo i4 qoff i5 koff i6 voff i7 ooff i8 heads i9 nq i10 nk i11 groups
-   *  i12 mode i13 H i14 W i15 head_dim (32|64); f0 scale */
+   *  i12 mode i13 H i14 W i15 head_dim (32|64); f0 scale
+   *  i16 = 1 (f32 plans, MFMA kernels): write o in format B (see OMNI_OP_CONV i20 = 2) for the LDS-DMA GEMM that follows */
   OMNI_OP_ATTN_ROWS = 10,
   /* DaViT grouped channel attention (florence2 :223-259): p0 qkv [B*N,3C] p4 o [B*N,C] p5 ws f32[B*G*chunks*1024]
-   *  i0 B i1 N i3 C i4 G i5 chunk_tokens; f0 scale (0 => N^-0.5) */
+   *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5) */
   OMNI_OP_CHAN_ATTN = 11,
   /* projector input (florence2 :568-590): y[b] = [mean_n(x+pos+t) ; x+pos+t]; p0 x [B,N,C] p1 pos2d f32[N,C] p2 temporal f32[C] p4 y [B,N+1,C]
    *  i0 B i1 N i3 C */
@@ -147,7 +148,7 @@ enum {
   OMNI_OP_CROP_RESIZE = 17,
   /* fused x1 = x + depthwise3x3(x) + bias ; h = LayerNorm(x1) (DaViT half-block prologue, hf florence2 :432-441).
    *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p3 h [B,H,W,C] p4 x1 [B,H,W,C] p5 gamma f32 p6 beta f32
-   *  i0 B i1 H i2 W i3 C (<= 1024); f0 eps */
+   *  i0 B i1 H i2 W i3 C (<= 1024) i6 = 1: h in format B (f32 plans); f0 eps */
   OMNI_OP_DWCONV3_LN = 18,
   /* f32 channel slice of a token matrix -> format B (OMNI_OP_CONV i20 = 2), in place when p0 == p4 and the slices coincide.
    *  p0 x [rows, ldi] p4 y [rows, ldo]; i0*i1 rows i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (all multiples of 16) */

@@ -312,7 +312,7 @@ inline bool launch_layernorm_v4(const LnArgs& a, hipStream_t s) {
 // registers for the statistics, so x1 is written once and never re-read (saves one full tensor read per DaViT
 // half-block compared with dwconv3_kernel followed by layernorm_kernel).
 struct DwLnArgs { const void* x; const void* w; const float* bias; const float* g; const float* b; void* y1; void* h;
-                  int B, H, W, C; long long pixels; float eps; };
+                  int B, H, W, C; long long pixels; float eps; int osplit; };
 
 template <typename T>
 __global__ __launch_bounds__(256) void dwconv3_ln_kernel(DwLnArgs a) {
@@ -383,6 +383,17 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(DwLnArgs a) {
       Vec out;
 #pragma unroll
       for (int e = 0; e < V; ++e) out.v[e] = ElemTraits<T>::from_f32((y[i][e] - mean) * rstd * a.g[c + e] + a.b[c + e]);
+      if constexpr (V == 4) {
+        if (a.osplit) {                     // format B for the LDS-DMA GEMM that consumes h (f32 plans)
+          float o[4] = {ElemTraits<T>::to_f32(out.v[0]), ElemTraits<T>::to_f32(out.v[1]), ElemTraits<T>::to_f32(out.v[2]), ElemTraits<T>::to_f32(out.v[3])};
+          uint2 hi, lo;
+          omni_split4(o, hi, lo);
+          unsigned char* p = (unsigned char*)a.h + pix * a.C * 4 + omni_split_off(c);
+          *reinterpret_cast<uint2*>(p) = hi;
+          *reinterpret_cast<uint2*>(p + 32) = lo;
+          continue;
+        }
+      }
       *reinterpret_cast<u32x4*>((T*)a.h + pix * a.C + c) = __builtin_bit_cast(u32x4, out);
     }
   }
@@ -395,7 +406,22 @@ struct AttnArgs {
   int heads, nq, nk, groups;                         // per group: nq queries, nk keys
   int mode, H, W, wy, wx;                            // window mode: image H x W, wy x wx windows of 12x12
   float scale;
+  int osplit;                                        // f32 plans: write o in "format B" (hi|lo f16 pairs) for the LDS-DMA GEMM that follows
 };
+
+// store one f32 output element of channel c of row `row` (f32 elements per row: ld): plain, or as the two halves of format B
+template <typename T>
+__device__ __forceinline__ void store_out(void* base, long long row, int ld, int c, float v, int osplit) {
+  if (osplit) {
+    unsigned short hi, lo;
+    omni_split1(v, hi, lo);
+    unsigned short* p = (unsigned short*)base + row * ld * 2 + omni_split_half_index(c);
+    p[0] = hi;
+    p[16] = lo;
+  } else {
+    stf((T*)base + row * ld + c, v);
+  }
+}
 
 // token row (into the [B*H*W] token matrix) of window-local index i (0..143), or -1 for padding
 __device__ __forceinline__ long long window_row(const AttnArgs& a, int g, int i) {
@@ -649,10 +675,10 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
       float rs = __shfl(sum, ql_);                         // row sum of query ql_ (replicated in every lane group)
       long long orow = window_row(a, g, qt * 16 + ql_);
       if (orow >= 0) {
-        T* O = (T*)a.o + orow * a.ldo + a.ooff + h * D;
         float inv = 1.0f / rs;
 #pragma unroll
-        for (int dt = 0; dt < 2; ++dt) stf(O + dt * 16 + qc, (oM[dt][r] + oC[dt][r] * inv2048) * inv);
+        for (int dt = 0; dt < 2; ++dt)
+          store_out<T>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, (oM[dt][r] + oC[dt][r] * inv2048) * inv, a.osplit);
       }
     }
   }
@@ -804,10 +830,10 @@ __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
       int qi = q0 + t * 16 + grp * 4 + r;
       float rs = __shfl(tot, grp * 4 + r);
       if (qi < a.nq) {
-        T* O = (T*)a.o + ((long long)g * a.nq + qi) * a.ldo + a.ooff + h * D;
         float inv = 1.0f / rs;
 #pragma unroll
-        for (int dt = 0; dt < 4; ++dt) stf(O + dt * 16 + qc, (oM[t][dt][r] + oC[t][dt][r] * inv2048) * inv);
+        for (int dt = 0; dt < 4; ++dt)
+          store_out<T>(a.o, (long long)g * a.nq + qi, a.ldo, a.ooff + h * D + dt * 16 + qc, (oM[t][dt][r] + oC[t][dt][r] * inv2048) * inv, a.osplit);
       }
     }
   }
@@ -816,7 +842,7 @@ __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
 // ------------------------------------------------------------------------------------ channel attention
 struct ChanArgs {
   const void* qkv; void* o; float* ws;    // qkv [B*N, 3C]; ws [B][G][chunks][32][32]
-  int B, N, C, G, chunks, chunk_tokens; float scale;
+  int B, N, C, G, chunks, chunk_tokens; float scale; int osplit;
 };
 
 template <typename T>
@@ -890,12 +916,27 @@ __global__ __launch_bounds__(256) void chan_apply_kernel(ChanArgs a) {
 #pragma unroll
   for (int j = 0; j < 32; ++j) v[j] = ldf(vrow + j);
   T* orow = (T*)a.o + ((long long)b * a.N + n) * a.C + g * 32;
-#pragma unroll 4
-  for (int i = 0; i < 32; ++i) {
-    float s = 0.f;
+  unsigned char* srow = (unsigned char*)a.o + (((long long)b * a.N + n) * a.C) * 4;
+#pragma unroll 2
+  for (int i4 = 0; i4 < 32; i4 += 4) {
+    float s4[4];
 #pragma unroll
-    for (int j = 0; j < 32; ++j) s = fmaf(sa[i][j], v[j], s);
-    stf(orow + i, s);
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s = fmaf(sa[i4 + e][j], v[j], s);
+      s4[e] = s;
+    }
+    if (a.osplit) {
+      uint2 hi, lo;
+      omni_split4(s4, hi, lo);
+      unsigned char* p = srow + omni_split_off(g * 32 + i4);
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + 32) = lo;
+    } else {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) stf(orow + i4 + e, s4[e]);
+    }
   }
 }
 
@@ -1199,9 +1240,10 @@ int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
   DwLnArgs a;
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.h = op->p[3]; a.y1 = op->p[4];
   a.g = (const float*)op->p[5]; a.b = (const float*)op->p[6];
-  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3]; a.eps = op->f[0];
+  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3]; a.eps = op->f[0]; a.osplit = op->i[6];
   const int V = op->dtype == OMNI_F32 ? 4 : 8;
   OMNI_REQUIRE(a.x && a.w && a.bias && a.h && a.y1 && a.g && a.b, "dwconv3_ln: null pointer");
+  OMNI_REQUIRE(!a.osplit || (op->dtype == OMNI_F32 && a.C % 16 == 0), "dwconv3_ln: split output needs an f32 plan and C %% 16 == 0");
   OMNI_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= 1024 && a.C % V == 0, "dwconv3_ln: bad shape (C <= 1024, C %% %d == 0)", V);
   a.pixels = (long long)a.B * a.H * a.W;
   unsigned blocks = (unsigned)((a.pixels + 3) / 4);
@@ -1245,7 +1287,9 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
   a.mode = op->i[12]; a.H = op->i[13]; a.W = op->i[14];
   int D = op->i[15];
   a.scale = op->f[0];
+  a.osplit = op->i[16];
   OMNI_REQUIRE(a.q && a.k && a.v && a.o && a.heads > 0 && a.nq > 0 && a.nk > 0 && a.groups > 0, "attn_rows: bad arguments");
+  OMNI_REQUIRE(!a.osplit || (op->dtype == OMNI_F32 && a.ldo % 16 == 0 && a.ooff % 16 == 0), "attn_rows: split output needs an f32 plan, 16-channel aligned");
   OMNI_REQUIRE(D == 32 || D == 64, "attn_rows: head_dim %d unsupported", D);
   if (a.mode == 1) {
     OMNI_REQUIRE(a.nq == 144 && a.nk == 144 && a.H > 0 && a.W > 0, "attn_rows: window mode needs 12x12 windows");
@@ -1254,6 +1298,7 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
   } else { a.wy = a.wx = 0; }
   int rc;
   static const bool use_mfma = !(getenv("OMNI_ATTN_MFMA") && atoi(getenv("OMNI_ATTN_MFMA")) == 0);
+  OMNI_REQUIRE(!a.osplit || (use_mfma && ((a.mode == 1 && D == 32) || (a.mode == 0 && D == 64))), "attn_rows: split output exists on the MFMA kernels only");
   if (a.mode == 1 && D == 32 && use_mfma) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
     rc = by_dtype(op->dtype, "attn_rows",
@@ -1286,8 +1331,9 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
 static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   ChanArgs a;
   a.qkv = op->p[0]; a.o = op->p[4]; a.ws = (float*)op->p[5];
-  a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3]; a.G = op->i[4]; a.chunk_tokens = op->i[5];
+  a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3]; a.G = op->i[4]; a.chunk_tokens = op->i[5]; a.osplit = op->i[6];
   OMNI_REQUIRE(a.qkv && a.o && a.ws && a.B > 0 && a.N > 0 && a.C == a.G * 32 && a.chunk_tokens > 0, "chan_attn: bad arguments");
+  OMNI_REQUIRE(!a.osplit || op->dtype == OMNI_F32, "chan_attn: split output needs an f32 plan");
   a.chunks = (a.N + a.chunk_tokens - 1) / a.chunk_tokens;
   a.scale = 1.0f / sqrtf((float)a.N);
   if (op->f[0] != 0.0f) a.scale = op->f[0];

@@ -59,6 +59,16 @@ __device__ __forceinline__ void omni_split4(const float* v, uint2& hi, uint2& lo
   hi.x = __builtin_bit_cast(unsigned, h01); hi.y = __builtin_bit_cast(unsigned, h23);
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
+// one value -> (hi, lo) halves, and its place in a split row of halves: element index of the hi half (lo = +16 halves)
+__device__ __forceinline__ void omni_split1(float v, unsigned short& hi, unsigned short& lo) {
+  typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+  v = __builtin_fminf(__builtin_fmaxf(v, -65504.0f), 65504.0f);
+  hv2 h = __builtin_amdgcn_cvt_pkrtz(v, 0.0f);
+  hv2 l = __builtin_amdgcn_cvt_pkrtz(v - (float)h[0], 0.0f);
+  hi = (unsigned short)(__builtin_bit_cast(unsigned, h) & 0xffffu);
+  lo = (unsigned short)(__builtin_bit_cast(unsigned, l) & 0xffffu);
+}
+__device__ __forceinline__ int omni_split_half_index(int c) { return (c >> 4) * 32 + (c & 15); }
 // byte offset of channel c (c % 4 == 0) inside a split row: hi halves; the lo halves sit 32 bytes further
 __device__ __forceinline__ int omni_split_off(int c) { return (c >> 4) * 64 + (c & 15) * 2; }
 

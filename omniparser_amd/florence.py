@@ -174,7 +174,9 @@ class _CaptionPlans:
                                 i={0: x.B, 1: x.H, 2: x.W, 3: x.C}))
             return out
 
-        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "0") == "1"    # measured neutral on MI355X (6.87 vs 6.90 screenshots/s): opt-in
+        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "0") == "1"    # measured neutral on MI355X in round 1 (6.87 vs 6.90 screenshots/s): opt-in
+        # OMNI_ATTN_SPLIT_OUT=1: the attention kernels write their output pre-split for the projection GEMM (no split_convert pass)
+        attn_split = use_dma and os.environ.get("OMNI_ATTN_SPLIT_OUT", "0") == "1" and os.environ.get("OMNI_ATTN_MFMA", "1") != "0"
 
         def dwconv_ln(conv_key, norm_key, x: View, y1: View, hout: View):
             """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
@@ -190,8 +192,8 @@ class _CaptionPlans:
             pb.add_op(L.make_op(L.OP_DWCONV3_LN, dt,
                                 p=[x.ptr, wp.data_ptr(), bp.data_ptr(), hout.ptr, y1.ptr,
                                    f32(norm_key + ".weight").data_ptr(), f32(norm_key + ".bias").data_ptr()],
-                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C}, f={0: 1e-5}))
-            hout.fmt = "f32"
+                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 6: 1 if (use_dma and x.C % 16 == 0) else 0}, f={0: 1e-5}))
+            hout.fmt = "split" if (use_dma and x.C % 16 == 0) else "f32"
             return hout
 
         # ---------------- input + vision tower
@@ -241,15 +243,15 @@ class _CaptionPlans:
                             L.OP_ATTN_ROWS, dt,
                             p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr, qb.data_ptr() + 4 * C, qb.data_ptr() + 8 * C],
                             i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
-                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s]},
+                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if attn_split else 0},
                             f={0: (C // w.heads[s]) ** -0.5}))
-                        att.fmt = "f32"
+                        att.fmt = "split" if attn_split else "f32"
                         linear(pre + "window_attn.proj", att, B_, res=B_)
                     else:
                         linear(pre + "channel_attn.qkv", hbuf, qkv)
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
-                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens}))
-                        att.fmt = "f32"
+                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if attn_split else 0}))
+                        att.fmt = "split" if attn_split else "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
                     linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU, out_split=True)
@@ -311,8 +313,8 @@ class _CaptionPlans:
             linear(None, xin, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
             pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
                                 i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
-                                   12: 0, 15: 64}, f={0: 64 ** -0.5}))
-            att.fmt = "f32"
+                                   12: 0, 15: 64, 16: 1 if attn_split else 0}, f={0: 64 ** -0.5}))
+            att.fmt = "split" if attn_split else "f32"
             linear(pre + "self_attn.out_proj", att, tmp, res=xa)
             layernorm(pre + "self_attn_layer_norm", tmp, xa, split=xs)
             linear(pre + "fc1", xin, ffn, act=L.ACT_GELU, out_split=True)

@@ -249,30 +249,36 @@ def letterbox_tensor(img_u8, imgsz):
     return x
 
 
-def _calibration_input(seeds=(0, 1, 2, 3)):
+def _calibration_input(seeds=tuple(range(8))):
     """640x640 letterboxes of synthetic screenshots."""
     from omniparser_amd.synth import synthetic_screenshot
     return torch.cat([letterbox_tensor(synthetic_screenshot(sd), 640) for sd in seeds])
 
 
 def max_class_logits(model, x):
+    res = []
     with torch.no_grad():
-        out = model(x)
-    return torch.cat([out[i].flatten(2) for i in (0, 2, 4)], 2).max(1).values.flatten()
+        for f in x.split(1):
+            out = model(f)
+            res.append(torch.cat([out[i].flatten(2) for i in (0, 2, 4)], 2).max(1).values.flatten())
+    return torch.cat(res)
 
 
-def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05, margin_frames=()):
+def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False):
     """Seeded random YOLOv9-E that is WELL CONDITIONED, so that box-for-box parity can be asserted on every frame:
 
       * BatchNorm gains are small (gamma ~ 0.25) and shifts sizeable (beta ~ 0.5 randn): every Conv+BN+SiLU then works
         around the near-linear part of SiLU and the net stops amplifying rounding noise (the round-1 stand-in, gamma ~ 1,
         amplified f32 noise 1e3-1e4x: its own f32 and f64 evaluations disagreed by 5e-3 in the logits).  Measured here:
         f32-vs-f64 head difference ~3e-5 of the logit spread (tools/make_weights.py --report);
-      * running statistics are calibrated on synthetic screenshots; the class head is rescaled to a logit spread of ~1.5
-        and biased so that ~`pass_rate` of the anchors exceed `conf` (SURVEY 8d config 2);
-      * `margin_frames` ([1,3,H,W] letterboxed inputs the parity tests run on): the threshold logit is moved (by < 0.1)
-        into the widest gap between neighbouring anchor logits of those frames, so no candidate sits within rounding
-        distance of `conf` — the tests can then demand identical candidate sets unconditionally."""
+      * running statistics are calibrated on the eight synthetic bench screenshots; the class head is rescaled to a logit spread
+        of ~1.5 and biased so that ~`pass_rate` of the anchors exceed `conf`: 0.15 gives ~1 260 candidates (the per-class branch
+        of batched_nms, > 4000 elements), ~100 boxes, ~87 elements and ~48 caption crops per 1920x1080 screenshot — the load of
+        round 1's bench (85.5 elements / 46 crops);
+      * `margin_frames` ([1,3,H,W] letterboxed inputs the parity tests run on): the threshold is centred in the widest gap
+        between neighbouring DISTINCT anchor logits of the calibration + those frames around the requested pass rate, so no
+        candidate sits within rounding distance of `conf` — the tests can then demand identical candidate sets
+        unconditionally (model.margin / model.pass_rate record the half gap and the rate obtained)."""
     g = torch.Generator().manual_seed(seed)
     model = YOLOv9E(nc=nc, width=width)
     with torch.no_grad():
@@ -293,7 +299,10 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05, ma
             bins = torch.arange(16, dtype=torch.float32)
             seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
         x = _calibration_input()
-        model(x)                      # running stats <- batch stats of the calibration frames
+        # running stats <- POOLED batch statistics of all eight frames (per-frame statistics would leave the frames' global
+        # differences un-normalised: whole frames then sit above / below the score threshold).  The pass runs on the 2x
+        # box-filtered frames: a quarter of the working set, same per-channel statistics to within a few percent.
+        model(F.avg_pool2d(x, 2) if calib_half else x)
         model.eval()
         for m in model.modules():
             if isinstance(m, nn.BatchNorm2d):
@@ -304,22 +313,38 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.03, conf=0.05, ma
         for seq in model.head.cv3:
             seq[-1].weight.mul_(gain)
             seq[-1].bias.mul_(gain)
-        logits = max_class_logits(model, x)
+        # threshold placement: the `pass_rate` quantile of the anchor logits of the calibration + parity frames, moved into the
+        # WIDEST gap between neighbouring distinct logits nearby (+-3 % of the anchors), so that no candidate sits within
+        # rounding distance of `conf`.  Flat regions (the letterbox padding alone is 44 % of a 640x640 input) produce big
+        # clusters of IDENTICAL logits: a quantile that falls into such a cluster would let a 1e-6 perturbation flip
+        # thousands of anchors, and a cluster must not end up above the threshold (it would flood NMS with junk boxes) —
+        # gaps are therefore searched among distinct values, above the dominant cluster when it lies in the window.
         thr = math.log(conf / (1 - conf))
-        shift = thr - torch.quantile(logits, 1.0 - pass_rate).item()
-        for seq in model.head.cv3:
-            seq[-1].bias.add_(shift)
-        # margin: centre the threshold in the widest gap of the parity frames' anchor logits within +-0.1
+        frames = [x]
         if len(margin_frames):
-            lg = torch.cat([max_class_logits(model, f) for f in margin_frames])
-            near = torch.sort(lg[(lg > thr - 0.1) & (lg < thr + 0.1)]).values
-            if near.numel() >= 2:
-                gaps = near[1:] - near[:-1]
-                i = int(torch.argmax(gaps))
-                centre = 0.5 * float(near[i] + near[i + 1])
-                for seq in model.head.cv3:
-                    seq[-1].bias.add_(thr - centre)
-                model.margin = 0.5 * float(gaps[i])
+            by_shape = {}
+            for f in margin_frames:
+                by_shape.setdefault(tuple(f.shape[1:]), []).append(f)
+            frames += [torch.cat(fs) for fs in by_shape.values()]
+        lgx = max_class_logits(model, x)                               # the 640x640 calibration frames define the pass rate
+        lg = torch.cat([lgx] + [max_class_logits(model, f) for f in frames[1:]])
+        v_lo = float(torch.quantile(lgx, max(1.0 - pass_rate - 0.03, 0.0)))
+        v_hi = float(torch.quantile(lgx, min(1.0 - pass_rate + 0.03, 1.0)))
+        xv, xc = torch.unique(lgx, return_counts=True)
+        big = int(torch.argmax(xc))
+        if xc[big] > 0.02 * lgx.numel() and v_lo <= float(xv[big]) <= v_hi:
+            v_lo = float(xv[big])                                       # stay above the dominant cluster
+        vals = torch.unique(lg)                                         # sorted distinct logits of ALL frames
+        vals = vals[(vals >= v_lo) & (vals <= v_hi)]
+        if vals.numel() < 2:
+            vals = torch.tensor([v_lo, max(v_hi, v_lo + 1e-3)])
+        gaps = vals[1:] - vals[:-1]
+        k = int(torch.argmax(gaps))
+        centre = 0.5 * float(vals[k] + vals[k + 1])
+        for seq in model.head.cv3:
+            seq[-1].bias.add_(thr - centre)
+        model.margin = 0.5 * float(gaps[k])
+        model.pass_rate = float((lgx > centre).float().mean())
     return model.eval()
 
 

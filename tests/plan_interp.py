@@ -152,7 +152,7 @@ def run_op(op, m):
         y1 = (F.conv2d(x, w, m.at(p[2], torch.float32)[:C], padding=1, groups=C) + x).permute(0, 2, 3, 1).to(dt)
         m.at(p[4], dt)[: B * H * W * C].view(B, H, W, C).copy_(y1)
         hn = F.layer_norm(y1.float(), (C,), m.at(p[5], torch.float32)[:C], m.at(p[6], torch.float32)[:C], f[0])
-        m.at(p[3], dt)[: B * H * W * C].view(B, H, W, C).copy_(hn.to(dt))
+        m.at(p[3], dt)[: B * H * W * C].view(B, H, W, C).copy_(split_encode(hn.reshape(-1, C)).view(B, H, W, C) if i[6] else hn.to(dt))
     elif k == L.OP_LAYERNORM:
         rows, C, period = i[0] * max(i[1], 1), i[3], i[5]
         x = m.at(p[0], dt)[: rows * C].view(rows, C).float()
@@ -178,7 +178,8 @@ def run_op(op, m):
             v = v.view(groups, nk, heads, D).transpose(1, 2)
             o = torch.softmax(q @ kx.transpose(2, 3) * scale, -1) @ v
             out = m.at(p[4], dt)[: rows * ldo].view(groups, nq, ldo)
-            out[..., ooff:ooff + heads * D] = o.transpose(1, 2).reshape(groups, nq, heads * D).to(dt)
+            oo = o.transpose(1, 2).reshape(groups, nq, heads * D)
+            out[..., ooff:ooff + heads * D] = split_encode(oo.reshape(rows, heads * D)).view(groups, nq, heads * D) if i[16] else oo.to(dt)
         else:
             wy, wx = (H + 11) // 12, (W + 11) // 12
             B = groups // (wy * wx)
@@ -197,14 +198,16 @@ def run_op(op, m):
             o = torch.softmax(q @ kx.transpose(2, 3) * scale, -1) @ v
             o = o.transpose(1, 2).reshape(B, wy, wx, 12, 12, C).permute(0, 1, 3, 2, 4, 5).reshape(B, wy * 12, wx * 12, C)
             out = m.at(p[4], dt)[: B * H * W * ldo].view(B, H, W, ldo)
-            out[..., ooff:ooff + C] = o[:, :H, :W].to(dt)
+            oo = o[:, :H, :W]
+            out[..., ooff:ooff + C] = split_encode(oo.reshape(B * H * W, C)).view(B, H, W, C) if i[16] else oo.to(dt)
     elif k == L.OP_CHAN_ATTN:
         B, N, C, G = i[0], i[1], i[3], i[4]
         qkv = m.at(p[0], dt)[: B * N * 3 * C].view(B, N, 3, G, C // G).float().permute(2, 0, 3, 4, 1)
         q, kx, v = qkv.unbind(0)
         scale = f[0] if f[0] != 0.0 else N ** -0.5
         o = torch.softmax(q @ kx.transpose(2, 3) * scale, -1) @ v          # [B,G,32,N]
-        m.at(p[4], dt)[: B * N * C].view(B, N, C).copy_(o.permute(0, 3, 1, 2).reshape(B, N, C).to(dt))
+        oo = o.permute(0, 3, 1, 2).reshape(B, N, C)
+        m.at(p[4], dt)[: B * N * C].view(B, N, C).copy_(split_encode(oo.reshape(B * N, C)).view(B, N, C) if i[6] else oo.to(dt))
     elif k == L.OP_PROJ_PREP:
         B, N, C = i[0], i[1], i[3]
         x = m.at(p[0], dt)[: B * N * C].view(B, N, C).float()
