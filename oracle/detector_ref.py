@@ -19,8 +19,10 @@ STRIDES = (8, 16, 32)
 
 
 # ------------------------------------------------------------------ torchvision.ops restatement
-def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torch.Tensor:
-    """torchvision nms_kernel_impl (CPU): stable descending sort, greedy, strict `>`."""
+def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, stats: dict = None) -> torch.Tensor:
+    """torchvision nms_kernel_impl (CPU): stable descending sort, greedy, strict `>`.
+    stats (test diagnostics): counts the suppression decisions whose IoU lies within 1e-5 of the threshold ("near_ties") — those
+    are the decisions a 1e-6 perturbation of the boxes can flip, in ANY implementation (the oracle's own f64 run included)."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
     b = boxes.detach().cpu().numpy().astype(np.float32)
@@ -47,17 +49,19 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float) -> torc
         inter = (w * h).astype(np.float32)
         with np.errstate(divide="ignore", invalid="ignore"):
             ovr = inter / ((areas[i] + areas[rest]).astype(np.float32) - inter)
+        if stats is not None:
+            stats["near_ties"] = stats.get("near_ties", 0) + int((np.abs(ovr[~suppressed[rest]] - thr) <= 1e-5).sum())
         suppressed[rest[ovr > thr]] = True
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
 
-def batched_nms(boxes, scores, idxs, iou_threshold):
+def batched_nms(boxes, scores, idxs, iou_threshold, stats: dict = None):
     """torchvision.ops.batched_nms with the CPU dispatch threshold (numel > 4000 -> per-class loop)."""
     if boxes.numel() > 4000:
         keep_mask = torch.zeros_like(scores, dtype=torch.bool)
         for class_id in torch.unique(idxs):
             curr = torch.where(idxs == class_id)[0]
-            k = nms(boxes[curr], scores[curr], iou_threshold)
+            k = nms(boxes[curr], scores[curr], iou_threshold, stats)
             keep_mask[curr[k]] = True
         keep_indices = torch.where(keep_mask)[0]
         return keep_indices[scores[keep_indices].sort(descending=True, stable=True)[1]]
@@ -65,7 +69,7 @@ def batched_nms(boxes, scores, idxs, iou_threshold):
         return torch.empty((0,), dtype=torch.int64)
     max_coordinate = boxes.max()
     offsets = idxs.to(boxes) * (max_coordinate + torch.tensor(1).to(boxes))
-    return nms(boxes + offsets[:, None], scores, iou_threshold)
+    return nms(boxes + offsets[:, None], scores, iou_threshold, stats)
 
 
 # ------------------------------------------------------------------ ref:util/yolov9.py restated
@@ -134,11 +138,12 @@ def postprocess(outputs, image_width, image_height, scale, pad_left, pad_top, co
     boxes[:, [0, 2]] = (boxes[:, [0, 2]] - pad_left) / scale
     boxes[:, [1, 3]] = (boxes[:, [1, 3]] - pad_top) / scale
     cand = (boxes.clone(), scores.clone(), class_ids.clone())
-    keep = batched_nms(boxes, scores, class_ids, iou)[:max_det]
+    nms_stats = {}
+    keep = batched_nms(boxes, scores, class_ids, iou, nms_stats)[:max_det]
     boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
     boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, image_width)
     boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, image_height)
-    return boxes, scores, class_ids, {"cand": cand, "valid": valid, "keep": keep}
+    return boxes, scores, class_ids, {"cand": cand, "valid": valid, "keep": keep, "near_ties": nms_stats.get("near_ties", 0)}
 
 
 @torch.inference_mode()

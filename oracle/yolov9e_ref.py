@@ -264,7 +264,7 @@ def max_class_logits(model, x):
     return torch.cat(res)
 
 
-def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False):
+def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False, box_gain=1.0):
     """Seeded random YOLOv9-E that is WELL CONDITIONED, so that box-for-box parity can be asserted on every frame:
 
       * BatchNorm gains are small (gamma ~ 0.25) and shifts sizeable (beta ~ 0.5 randn): every Conv+BN+SiLU then works
@@ -295,9 +295,10 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, ma
             if isinstance(m, nn.BatchNorm2d):
                 m.momentum = 1.0
         model.train()
-        for seq in model.head.cv2:   # icon-sized boxes: DFL mass centred near 1.5 strides per side
+        for seq in model.head.cv2:   # icon-sized boxes: DFL mass centred near 1.5 strides per side, sizes that vary with the content
             bins = torch.arange(16, dtype=torch.float32)
             seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
+            seq[-1].weight.mul_(box_gain)
         x = _calibration_input()
         # running stats <- POOLED batch statistics of all eight frames (per-frame statistics would leave the frames' global
         # differences un-normalised: whole frames then sit above / below the score threshold).  The pass runs on the 2x
