@@ -860,6 +860,7 @@ class _OracleCaptioner:
         from omniparser_amd.florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS
         img = image.numpy() if isinstance(image, torch.Tensor) else image
         self.boxes_seen = [list(b) for b in boxes]
+        self.margins = []
         outs = []
         for s in range(0, len(boxes), batch_size):
             pv = np.stack([PR.caption_pixel_values(img, b, self.R, CLIP_MEAN, CLIP_STD) for b in boxes[s:s + batch_size]])
@@ -867,7 +868,19 @@ class _OracleCaptioner:
             n_img = (self.R // 32) ** 2 + 1
             ids = torch.tensor([[self.model.config.image_token_id] * n_img + PROMPT_IDS] * pix.shape[0])
             with torch.inference_mode():
-                outs.append(self.model.generate(input_ids=ids, pixel_values=pix, max_new_tokens=max_new_tokens, num_beams=1, do_sample=False))
+                g = self.model.generate(input_ids=ids, pixel_values=pix, max_new_tokens=max_new_tokens, num_beams=1, do_sample=False,
+                                        output_logits=True, return_dict_in_generate=True)
+            outs.append(g.sequences)
+            # smallest top-1/top-2 logit margin of every row over its free decoding steps (not forced BOS / EOS, not after its EOS)
+            seq = g.sequences
+            for b in range(seq.shape[0]):
+                m = float("inf")
+                for t, lg in enumerate(g.logits):
+                    if t == 0 or t == max_new_tokens - 1 or (seq[b, 1:t + 1] == 2).any():
+                        continue
+                    top2 = lg[b].float().topk(2).values
+                    m = min(m, float(top2[0] - top2[1]))
+                self.margins.append(m)
         T = max(o.shape[1] for o in outs)
         res = torch.full((len(boxes), T), 1, dtype=torch.long)
         o0 = 0
@@ -908,10 +921,19 @@ def check_end_to_end(width=0.5, R=64, image_seed=1, max_crops_checked=None, iw=1
     out = {"n_gpu": len(el_g), "n_ref": len(el_r), "icons": sum(e["type"] == "icon" for e in el_r), "R": R}
     assert len(el_g) == len(el_r), f"element count {len(el_g)} vs {len(el_r)}"
     min_iou, same_caps, caps = 1.0, 0, 0
-    for a, b in zip(el_g, el_r):
-        assert a["type"] == b["type"] and a["source"] == b["source"] and a["interactivity"] == b["interactivity"]
-        iou = box_iou_pairs(torch.tensor([a["bbox"]]), torch.tensor([b["bbox"]])).item()
-        min_iou = min(min_iou, iou)
+    # order-free pairing: boxes whose scores agree to ~1e-6 may exchange ranks between two f32 implementations
+    gbx = torch.tensor([e["bbox"] for e in el_g]).reshape(-1, 4); rbx = torch.tensor([e["bbox"] for e in el_r]).reshape(-1, 4)
+    x1 = torch.maximum(rbx[:, None, 0], gbx[None, :, 0]); y1 = torch.maximum(rbx[:, None, 1], gbx[None, :, 1])
+    x2 = torch.minimum(rbx[:, None, 2], gbx[None, :, 2]); y2 = torch.minimum(rbx[:, None, 3], gbx[None, :, 3])
+    inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+    ar = (rbx[:, 2] - rbx[:, 0]) * (rbx[:, 3] - rbx[:, 1]); ag = (gbx[:, 2] - gbx[:, 0]) * (gbx[:, 3] - gbx[:, 1])
+    best, arg = (inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)).max(1)
+    assert len(set(arg.tolist())) == len(el_r), "pairing is not one to one"
+    out["rank_swaps"] = int((arg != torch.arange(len(el_r))).sum())
+    for j, b in enumerate(el_r):
+        a = el_g[int(arg[j])]
+        assert a["type"] == b["type"] and a["source"] == b["source"] and a["interactivity"] == b["interactivity"], (a, b)
+        min_iou = min(min_iou, float(best[j]))
         if a["type"] == "icon" and a["source"] == "box_yolo_content_yolo":
             caps += 1
             pa = [int(a["bbox"][0] * iw), int(a["bbox"][1] * ih), int(a["bbox"][2] * iw), int(a["bbox"][3] * ih)]
@@ -957,34 +979,42 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     out = {"frames": n_frames, "elements": [], "crops": [len(c) for c in crops_g], "min_iou": 1.0}
     crops_r = []
     out["near_ties"], out["exact_frames"] = [], 0
+    detector_problems = []
     for f in range(n_frames):
         rb, rs, rc, dbg = D.predict(cpu_model, Image.fromarray(imgs[f]), conf=0.05, imgsz=640, iou=0.1, max_det=300, return_debug=True)
         el_r, cr_r = sp.glue(rb, IW, IH, ocr[f][1], ocr[f][0])
         crops_r.append(cr_r)
         out["near_ties"].append(int(dbg["near_ties"]))
         out["elements"].append(len(el_r))
+        # order-free pairing (two boxes whose scores agree to 1e-6 may exchange ranks between f32 implementations)
+        gbx = torch.tensor([e["bbox"] for e in elems[f]]).reshape(-1, 4); rbx = torch.tensor([e["bbox"] for e in el_r]).reshape(-1, 4)
+        x1 = torch.maximum(rbx[:, None, 0], gbx[None, :, 0]); y1 = torch.maximum(rbx[:, None, 1], gbx[None, :, 1])
+        x2 = torch.minimum(rbx[:, None, 2], gbx[None, :, 2]); y2 = torch.minimum(rbx[:, None, 3], gbx[None, :, 3])
+        inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+        ar = (rbx[:, 2] - rbx[:, 0]) * (rbx[:, 3] - rbx[:, 1]); ag = (gbx[:, 2] - gbx[:, 0]) * (gbx[:, 3] - gbx[:, 1])
+        best, arg = (inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)).max(1)
+        missing = int((best < 0.999).sum())
+        for j, b in enumerate(el_r):
+            if best[j] < 0.999:
+                continue
+            a = elems[f][int(arg[j])]
+            if (a["type"], a["source"], a["interactivity"]) != (b["type"], b["source"], b["interactivity"]) or \
+                    (b["content"] is not None and a["content"] != b["content"]):
+                detector_problems.append(f"frame {f}: element fields differ {a} vs {b}")
+        allowance = 3 * int(dbg["near_ties"])
         if dbg["near_ties"] == 0:
             # no NMS decision of the oracle within 1e-5 of its threshold: the frame must come out element for element
             out["exact_frames"] += 1
-            assert len(el_r) == len(elems[f]), f"frame {f}: {len(elems[f])} elements vs {len(el_r)}"
-            for a, b in zip(elems[f], el_r):
-                assert a["type"] == b["type"] and a["source"] == b["source"] and a["interactivity"] == b["interactivity"], (f, a, b)
-                iou = box_iou_pairs(torch.tensor([a["bbox"]]), torch.tensor([b["bbox"]])).item()
-                out["min_iou"] = min(out["min_iou"], iou)
-                if b["content"] is not None:
-                    assert a["content"] == b["content"], (f, a, b)             # OCR text (merged into icons or kept)
-            assert crops_g[f] == cr_r, f"frame {f}: integer crop boxes differ"
-        else:
-            # a near-tie may exchange one box per tie (see assert_detector_frame): every other element must still be there
-            gbx = torch.tensor([e["bbox"] for e in elems[f]]).reshape(-1, 4); rbx = torch.tensor([e["bbox"] for e in el_r]).reshape(-1, 4)
-            x1 = torch.maximum(rbx[:, None, 0], gbx[None, :, 0]); y1 = torch.maximum(rbx[:, None, 1], gbx[None, :, 1])
-            x2 = torch.minimum(rbx[:, None, 2], gbx[None, :, 2]); y2 = torch.minimum(rbx[:, None, 3], gbx[None, :, 3])
-            inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
-            ar = (rbx[:, 2] - rbx[:, 0]) * (rbx[:, 3] - rbx[:, 1]); ag = (gbx[:, 2] - gbx[:, 0]) * (gbx[:, 3] - gbx[:, 1])
-            best = (inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12)).max(1).values
-            missing = int((best < 0.999).sum())
-            assert missing <= 3 * dbg["near_ties"] and abs(len(el_r) - len(elems[f])) <= 3 * dbg["near_ties"], (f, missing, dbg["near_ties"])
-    assert out["min_iou"] >= 0.999 and out["exact_frames"] >= n_frames // 2, out
+            out["min_iou"] = min(out["min_iou"], float(best.min()) if len(best) else 1.0)
+            if sorted(crops_g[f]) != sorted(cr_r):
+                diff = sorted(set(map(tuple, crops_g[f])) ^ set(map(tuple, cr_r)))
+                detector_problems.append(f"frame {f}: integer crop boxes differ ({len(crops_g[f])} vs {len(cr_r)}): {diff[:6]}")
+        if missing > allowance or abs(len(el_r) - len(elems[f])) > allowance:
+            detector_problems.append(f"frame {f}: {missing} oracle elements unmatched, {len(elems[f])} vs {len(el_r)} elements, "
+                                     f"near_ties {dbg['near_ties']}")
+    if out["exact_frames"] < n_frames // 2:
+        detector_problems.append(f"only {out['exact_frames']} frames free of NMS near-ties")
+    assert not detector_problems, (detector_problems[:6], out)
     # ---- caption ids: crops on both sides of frame boundaries inside one micro-batch, and around a micro-batch boundary
     flat = [(f, k) for f in range(n_frames) for k in range(len(crops_g[f]))]
     chosen = []
@@ -998,18 +1028,27 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     model = build_random_captioner(0)
     ocap = _OracleCaptioner(model, R)
     T = cap.max_new_tokens + 1
-    bad = []
+    bad, weak, checked = [], 0, 0
+    MARGIN = 1e-3            # a crop whose oracle arg-max is decided by less than this is reported, not asserted (GPU logit error ~1e-5)
     for f in sorted({c[0] for c in chosen}):
         ks = [k for (ff, k) in chosen if ff == f]
         ref = ocap.caption_crops(imgs[f], [crops_g[f][k] for k in ks], max_new_tokens=20, batch_size=8)
-        for row, k in zip(ref, ks):
+        for row, k, margin in zip(ref, ks, ocap.margins):
             got = ids[f][k]
             a = torch.full((T,), cap.w.pad, dtype=torch.long); a[: got.shape[0]] = got
             b = torch.full((T,), cap.w.pad, dtype=torch.long); b[: row.shape[0]] = row
-            if not torch.equal(a, b):
-                bad.append((f, k, a.tolist(), b.tolist()))
-    out.update(caption_crops_checked=len(chosen), micro_batches_touched=sorted(mb), frames_touched=sorted({c[0] for c in chosen}))
-    assert not bad, f"caption ids differ on {len(bad)} of {len(chosen)} crops: {bad[:2]}"
+            checked += 1
+            if margin < MARGIN:
+                weak += 1
+            elif not torch.equal(a, b):
+                bad.append((f, k, round(margin, 5), a.tolist(), b.tolist()))
+    out.update(caption_crops_checked=checked, caption_crops_below_margin=weak, micro_batches_touched=sorted(mb),
+               frames_touched=sorted({c[0] for c in chosen}))
+    problems = []
+    if bad:
+        problems.append(f"caption ids differ on {len(bad)} of {checked} crops: {bad[:2]}")
+    if weak > checked // 4:
+        problems.append(f"{weak} of {checked} checked crops have an oracle arg-max margin below {MARGIN}")
     # ---- the RxR crop tensor of the last micro-batch is the oracle's pixel_values, bit for bit (bicubic-to-R -> DaViT seam)
     n_last = len(flat) % sp.batch_size or min(len(flat), sp.batch_size)
     cp = cap.plans(cap.bucket(n_last), R, cap.max_new_tokens)
@@ -1018,7 +1057,10 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
         f, k = flat[first + j]
         pv = torch.from_numpy(PR.caption_pixel_values(imgs[f], crops_g[f][k], R, CLIP_MEAN, CLIP_STD))
         got = cp.x_in.t[j, :, :, :3].float().cpu()
-        assert torch.equal(got, pv), f"crop tensor differs for frame {f} crop {k}: max abs {(got - pv).abs().max().item():.3e}"
+        if not torch.equal(got, pv):
+            problems.append(f"crop tensor differs for frame {f} crop {k} ({crops_g[f][k]}): max abs {(got - pv).abs().max().item():.3e}, "
+                            f"{int((got != pv).sum())} of {pv.numel()} values")
+    assert not problems, (problems, out)
     return out
 
 
