@@ -22,13 +22,16 @@ STRIDES = (8, 16, 32)
 def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, stats: dict = None) -> torch.Tensor:
     """torchvision nms_kernel_impl (CPU): stable descending sort, greedy, strict `>`.
     stats (test diagnostics): counts the suppression decisions whose IoU lies within 1e-5 of the threshold ("near_ties") — those
-    are the decisions a 1e-6 perturbation of the boxes can flip, in ANY implementation (the oracle's own f64 run included)."""
+    are the decisions a 1e-6 perturbation of the boxes can flip, in ANY implementation (the oracle's own f64 run included) — and the
+    suppressions of a live box by a kept box whose score is no more than 4e-6 higher ("score_ties": with the two scores exchanged the
+    other box of the pair survives; flat GUI regions give many anchors identical logits, so these are common on synthetic frames)."""
     if boxes.numel() == 0:
         return torch.empty((0,), dtype=torch.int64)
     b = boxes.detach().cpu().numpy().astype(np.float32)
     x1, y1, x2, y2 = b[:, 0], b[:, 1], b[:, 2], b[:, 3]
     areas = ((x2 - x1) * (y2 - y1)).astype(np.float32)
     order = torch.sort(scores.detach().cpu(), stable=True, descending=True).indices.numpy()
+    sc = scores.detach().cpu().numpy().astype(np.float32)
     n = len(order)
     suppressed = np.zeros(n, dtype=bool)
     keep = []
@@ -50,7 +53,14 @@ def nms(boxes: torch.Tensor, scores: torch.Tensor, iou_threshold: float, stats: 
         with np.errstate(divide="ignore", invalid="ignore"):
             ovr = inter / ((areas[i] + areas[rest]).astype(np.float32) - inter)
         if stats is not None:
-            stats["near_ties"] = stats.get("near_ties", 0) + int((np.abs(ovr[~suppressed[rest]] - thr) <= 1e-5).sum())
+            live = ~suppressed[rest]
+            stats["near_ties"] = stats.get("near_ties", 0) + int((np.abs(ovr[live] - thr) <= 1e-5).sum())
+            hit = live & (ovr > thr)
+            stats["score_ties"] = stats.get("score_ties", 0) + int((hit & (sc[i] - sc[rest] <= 4e-6)).sum())
+            if live.any():
+                stats["min_iou_margin"] = min(stats.get("min_iou_margin", 1.0), float(np.abs(ovr[live] - thr).min()))
+            if hit.any():
+                stats["min_score_gap"] = min(stats.get("min_score_gap", 1.0), float((sc[i] - sc[rest][hit]).min()))
         suppressed[rest[ovr > thr]] = True
     return torch.as_tensor(np.asarray(keep, dtype=np.int64))
 
@@ -143,7 +153,9 @@ def postprocess(outputs, image_width, image_height, scale, pad_left, pad_top, co
     boxes, scores, class_ids = boxes[keep], scores[keep], class_ids[keep]
     boxes[:, [0, 2]] = boxes[:, [0, 2]].clamp(0, image_width)
     boxes[:, [1, 3]] = boxes[:, [1, 3]].clamp(0, image_height)
-    return boxes, scores, class_ids, {"cand": cand, "valid": valid, "keep": keep, "near_ties": nms_stats.get("near_ties", 0)}
+    return boxes, scores, class_ids, {"cand": cand, "valid": valid, "keep": keep, "near_ties": nms_stats.get("near_ties", 0),
+                                     "score_ties": nms_stats.get("score_ties", 0), "min_iou_margin": nms_stats.get("min_iou_margin", 1.0),
+                                     "min_score_gap": nms_stats.get("min_score_gap", 1.0)}
 
 
 @torch.inference_mode()
