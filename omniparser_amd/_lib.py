@@ -46,6 +46,10 @@ def lib():
     if _lib is not None:
         return _lib
     path = _build.ensure_built()
+    # torch first: its wheel ships its own libamdhip64.so.7, and the device pointers / streams handed to the library come from that
+    # runtime.  Loaded afterwards, libomni_amd.so binds to it by SONAME; loaded BEFORE torch it would pull /opt/rocm's copy into the
+    # process as a second HIP runtime, whose launches fail with "no ROCm-capable device is detected".
+    import torch  # noqa: F401
     L = ctypes.CDLL(str(path))
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:

@@ -208,3 +208,17 @@ def test_dwconv3_strip_kernel_source_on_host_is_bit_identical_to_point_kernel():
     with pytest.raises(L.OmniError):
         L.host_op(op, 1)
     L.host_op(op, 0)
+
+
+def test_library_binds_to_one_hip_runtime():
+    """Loading libomni_amd.so before anything imported torch must not bring a second HIP runtime into the process (torch's wheel
+    ships its own libamdhip64.so.7; with /opt/rocm's copy loaded next to it every launch fails with "no ROCm-capable device")."""
+    import subprocess
+    import sys
+    from pathlib import Path
+    code = ("from omniparser_amd import _lib as L; L.lib(); import torch; "
+            "print(sorted({l.split()[-1] for l in open('/proc/self/maps') if 'libamdhip64' in l}))")
+    out = subprocess.run([sys.executable, "-c", code], capture_output=True, text=True, cwd=str(Path(__file__).resolve().parents[1]), timeout=300)
+    assert out.returncode == 0, out.stderr[-2000:]
+    libs = eval(out.stdout.strip().splitlines()[-1])
+    assert len(libs) == 1 and "torch" in libs[0], libs
