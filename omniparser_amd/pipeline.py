@@ -206,7 +206,9 @@ class ScreenParser:
                 dp.img[bi].copy_(f, non_blocking=True)
             gs.ocr.copy_(gs.h_ocr)
             gs.meta.copy_(gs.h_meta)
-            dp.launch(det)
+            # the detector plan runs EAGERLY on this path: the second replay of its hipGraph never completed when the hand-off
+            # kernels followed it on the same stream (ROCm 7.2, profiles/r2_notes.md); eager launches of the same ops are fine
+            dp.plan.run(det.stream)
             gs.plan.run(det.stream)
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
         return dp, gs, ocr_els, counts

@@ -43,8 +43,9 @@ def test_bench_path_parity_batch8_full_width_r768():
 
 def test_parse_batch_device_handoff_equals_host_handoff(monkeypatch):
     """same frames through parse_batch with the hand-off on the device (OMNI_DEVICE_GLUE=1) and on the host (default): identical element
-    lists, crop rectangles and caption ids.  (One call per parser: a SECOND replay of the detector hipGraph followed by the hand-off
-    kernels did not complete on ROCm 7.2 — profiles/r2_notes.md — which is why the device hand-off is opt-in.)"""
+    lists, crop rectangles and caption ids.  (The device path launches the detector plan eagerly: a second replay of the detector
+    hipGraph followed by the hand-off kernels did not complete on ROCm 7.2 — profiles/r2_notes.md — which is also why the device
+    hand-off is opt-in.)"""
     import torch
     from omniparser_amd.florence import Florence2Captioner
     from omniparser_amd.pipeline import ScreenParser
