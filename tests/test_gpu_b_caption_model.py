@@ -1,0 +1,62 @@
+"""`-m gpu`: Florence-2 captioner kernels and the whole caption / end-to-end path vs CPU references."""
+import pytest
+
+from omniparser_amd import _lib as L
+
+pytestmark = pytest.mark.gpu
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_caption_kernels_vs_interpreter(dtype):
+    import gpu_checks as G
+    G.check_caption_ops(dtype)
+
+
+def test_captioner_token_exact_r64():
+    """reference cuda-branch shape (64x64 crops, 5 image tokens): greedy ids == transformers CPU."""
+    import gpu_checks as G
+    out, _ = G.check_captioner(R=64, n=5)
+    assert out["ids_equal"], out
+    assert out["feat_rel_err"] < 1e-4 and out["enc_rel_err"] < 1e-4
+    assert out["max_logit_err"] < out["min_top1_top2_margin"], out
+    print(out)
+
+
+def test_captioner_token_exact_r768():
+    """reference CPU-branch shape (768x768 crops, 577 image tokens) — the parity target."""
+    import gpu_checks as G
+    out, _ = G.check_captioner(R=768, n=2)
+    assert out["ids_equal"], out
+    assert out["feat_rel_err"] < 3e-4 and out["enc_rel_err"] < 3e-4
+    assert out["max_logit_err"] < out["min_top1_top2_margin"], out      # token-exactness is not a coin flip: error below the smallest arg-max margin
+    print(out)
+
+
+def test_omniparser_facade_parse_roundtrip():
+    """ref:util/omniparser.py contract: Omniparser(config).parse(base64) -> (base64 PNG, element list)."""
+    import base64
+    import io
+    from PIL import Image
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.omniparser import Omniparser
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    import os
+    os.environ["OMNI_CAPTION_RES"] = "64"
+    try:
+        cfg = {"som_model_path": str(ensure_blob(seed=0, nc=1, width=0.5)), "caption_model_name": "florence2",
+               "caption_model_path": str(ensure_caption_checkpoint(0)), "BOX_TRESHOLD": 0.05,
+               "ocr_provider": lambda image: synthetic_ocr(2, image.size[0], image.size[1], 24)}
+        op = Omniparser(cfg)
+        buf = io.BytesIO()
+        Image.fromarray(synthetic_screenshot(2, 1280, 800)).save(buf, format="PNG")
+        png_b64, elems = op.parse(base64.b64encode(buf.getvalue()).decode("ascii"))
+    finally:
+        os.environ.pop("OMNI_CAPTION_RES", None)
+    img = Image.open(io.BytesIO(base64.b64decode(png_b64)))
+    assert img.size == (1280, 800)
+    assert len(elems) > 10
+    for e in elems:
+        assert set(e) == {"type", "bbox", "interactivity", "content", "source"}
+        assert e["type"] in ("text", "icon") and len(e["bbox"]) == 4 and isinstance(e["content"], str)
+        assert all(0.0 <= v <= 1.0 for v in e["bbox"])
+    assert any(e["source"] == "box_yolo_content_yolo" for e in elems) and any(e["type"] == "text" for e in elems)

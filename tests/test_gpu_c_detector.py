@@ -19,47 +19,6 @@ def test_detector_half_width_640():
     G.assert_detector_frame(out["images"][0])
 
 
-def test_detector_native_resolution_path():
-    """scale_img=True path: 1080x1920 -> 1088x1920 network input, no resample (Pillow same-size copy).  The stand-in was calibrated
-    on 640x640 letterboxes: at this size its own f32 and f64 evaluations differ by ~0.1 in the logits, so the head bound is 8x that
-    difference; NMS on the device's candidates is bit-exact as everywhere."""
-    import gpu_checks as G
-    out, det = G.check_detector(width=0.25, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
-    G.assert_detector_frame(out["images"][0])
-
-
-def test_detector_full_width_boxes_640():
-    """Full YOLOv9-E at the reference's default 640x640 network input on the tie-free, well-conditioned frames: box for box —
-    same candidates, same count, identical class ids, IoU >= 0.999, head tensors within 1e-4 absolute."""
-    import gpu_checks as G
-    from tools.make_weights import EXACT_FRAMES
-    out, det = G.check_detector(width=1.0, image_seeds=EXACT_FRAMES[(1.0, 640)], imgsz=640)
-    for rec in out["images"]:
-        G.assert_detector_frame(rec, exact=True)
-    print(out)
-
-
-def test_detector_full_width_boxes_native():
-    """Full YOLOv9-E at 1088x1920 (configs[1] native path): ~35 000 anchors pass the threshold at this size and the oracle's NMS sits
-    on thousands of ties, so heads (within 8x the oracle's f32-vs-f64 difference), candidate count and NMS-on-identical-candidates
-    are the statement."""
-    import gpu_checks as G
-    out, det = G.check_detector(width=1.0, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
-    for rec in out["images"]:
-        G.assert_detector_frame(rec)
-    print(out)
-
-
-def test_oracle_is_well_conditioned():
-    """On an EXACT_FRAMES frame the stand-in's own f32-vs-f64 head difference stays far below the parity epsilon (round 1: 5e-3)."""
-    import gpu_checks as G
-    from tools.make_weights import EXACT_FRAMES
-    out, det = G.check_detector(width=0.5, image_seeds=EXACT_FRAMES[(0.5, 640)][:1], imgsz=640, with_f64=True)
-    rec = out["images"][0]
-    for n_cls, n_dist, g_cls in rec["oracle_noise(cls,dist,gpu_vs_f64)"]:
-        assert n_cls <= 3e-5 and n_dist <= 3e-5 and g_cls <= G.HEAD_TOL, rec
-
-
 def test_tiled_detection_4k_matches_oracle_policy():
     """3840x2160 frame -> 2x2 overlapping tiles -> global NMS (BASELINE configs[4]; policy is ours).  The merge
     (shift + global NMS + clamp) must be exact given the per-tile boxes; end to end the result must match the
@@ -113,3 +72,44 @@ def test_detector_f16_mode_is_reference_gpu_branch_class():
         assert abs(rec["n_gpu"] - rec["n_ref"]) <= max(3, 0.15 * rec["n_ref"]), rec
         assert rec["nms_exact_on_gpu_candidates"], rec
     print([(r["head_err(cls,dist)"], r["n_ref"], r["n_gpu"], r["matched_frac_iou95"]) for r in out["images"]])
+
+
+def test_oracle_is_well_conditioned():
+    """On an EXACT_FRAMES frame the stand-in's own f32-vs-f64 head difference stays far below the parity epsilon (round 1: 5e-3)."""
+    import gpu_checks as G
+    from tools.make_weights import EXACT_FRAMES
+    out, det = G.check_detector(width=0.5, image_seeds=EXACT_FRAMES[(0.5, 640)][:1], imgsz=640, with_f64=True)
+    rec = out["images"][0]
+    for n_cls, n_dist, g_cls in rec["oracle_noise(cls,dist,gpu_vs_f64)"]:
+        assert n_cls <= 3e-5 and n_dist <= 3e-5 and g_cls <= G.HEAD_TOL, rec
+
+
+def test_detector_full_width_boxes_640():
+    """Full YOLOv9-E at the reference's default 640x640 network input on the tie-free, well-conditioned frames: box for box —
+    same candidates, same count, identical class ids, IoU >= 0.999, head tensors within 1e-4 absolute."""
+    import gpu_checks as G
+    from tools.make_weights import EXACT_FRAMES
+    out, det = G.check_detector(width=1.0, image_seeds=EXACT_FRAMES[(1.0, 640)], imgsz=640)
+    for rec in out["images"]:
+        G.assert_detector_frame(rec, exact=True)
+    print(out)
+
+
+def test_detector_native_resolution_path():
+    """scale_img=True path: 1080x1920 -> 1088x1920 network input, no resample (Pillow same-size copy).  The stand-in was calibrated
+    on 640x640 letterboxes: at this size its own f32 and f64 evaluations differ by ~0.1 in the logits, so the head bound is 8x that
+    difference; NMS on the device's candidates is bit-exact as everywhere."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=0.25, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
+    G.assert_detector_frame(out["images"][0])
+
+
+def test_detector_full_width_boxes_native():
+    """Full YOLOv9-E at 1088x1920 (configs[1] native path): ~35 000 anchors pass the threshold at this size and the oracle's NMS sits
+    on thousands of ties, so heads (within 8x the oracle's f32-vs-f64 difference), candidate count and NMS-on-identical-candidates
+    are the statement."""
+    import gpu_checks as G
+    out, det = G.check_detector(width=1.0, image_seeds=(0,), imgsz=(1080, 1920), with_f64=True)
+    for rec in out["images"]:
+        G.assert_detector_frame(rec)
+    print(out)

@@ -16,7 +16,7 @@ grep -v "Warning\|warnings.warn\|^$\|_create_method" "$OUT/pytest.log" | tail -4
 echo "=== smoke"
 ( timeout 150 python __graft_entry__.py --smoke 2>&1 | tail -3 | cut -c1-600 )
 echo "=== opt-in: attention kernels write format B"
-( OMNI_ATTN_SPLIT_OUT=1 timeout 200 python -m pytest tests/test_gpu_caption.py -q -p no:cacheprovider -k "r64 or r768" 2>&1 | tail -3 | cut -c1-300 )
+( OMNI_ATTN_SPLIT_OUT=1 timeout 200 python -m pytest tests/test_gpu_b_caption_model.py -q -p no:cacheprovider -k "r64 or r768" 2>&1 | tail -3 | cut -c1-300 )
 for v in "OMNI_ATTN_SPLIT_OUT=1"; do
   tag=$(echo "$v" | tr ' =' '__')
   ( env $v OMNI_BENCH_WATCHDOG=60 timeout 100 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_$tag.json" 2> "$OUT/ab_$tag.err"; echo "$v -> exit $?" )

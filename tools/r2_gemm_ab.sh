@@ -22,5 +22,5 @@ for d in "$OUT"/pmc_*; do
   [ -d "$d" ] && python tools/pmc_summary.py "$d" > "$d.json" 2>>"$OUT/log.txt"
 done
 find "$OUT" -name "*.csv" -size +8M -delete
-step "pytest detector (unconditional parity)" timeout 1200 python -m pytest tests/test_gpu_detector.py -x -q
+step "pytest detector (unconditional parity)" timeout 1200 python -m pytest tests/test_gpu_c_detector.py -x -q
 tail -5 "$OUT/log.txt"
