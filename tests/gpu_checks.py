@@ -1029,12 +1029,17 @@ def compare_frame_elements(f, elems_g, crops_g, el_r, cr_r, dbg, listed_exact, o
         out["crop_coords_off_by_one"] += off
         if off > 2 or left:
             problems.append(f"frame {f}: {off} crop coordinates off by one, {len(left)} device crops without a twin")
+    elif listed_exact:
+        # well-conditioned frame, but the oracle's NMS decides on ties: each may exchange one box for another
+        ties = int(dbg["near_ties"]) + int(dbg["score_ties"])
+        if missing > 2 * ties or abs(len(el_r) - len(elems_g)) > ties:
+            problems.append(f"frame {f}: {missing} oracle elements unmatched, {len(elems_g)} vs {len(el_r)} elements with {ties} NMS ties")
     elif abs(len(el_r) - len(elems_g)) > max(3, 0.15 * len(el_r)):
         problems.append(f"frame {f}: {len(elems_g)} vs {len(el_r)} elements (ties {dbg['near_ties']}+{dbg['score_ties']})")
     out["matched_fraction"].append(round(1.0 - missing / max(len(el_r), 1), 4))
 
 
-def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4):
+def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=2):
     """Parity of the EXACT composition bench.py times (BASELINE configs[2]): ScreenParser.parse_batch on a batch of
     1920x1080 screenshots — batch detector plan, full-width YOLOv9-E, product glue, crops of all frames packed into 128-crop
     caption micro-batches at RxR, deferred id read-back — against the oracle pipeline (oracle.detector_ref.predict per frame
@@ -1076,7 +1081,7 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
         out["near_ties"].append(int(dbg["near_ties"]))
         out["elements"].append(len(el_r))
         compare_frame_elements(f, elems[f], crops_g[f], el_r, cr_r, dbg, f in exact_frames, out, detector_problems)
-    if out["exact_frames"] < min(2, n_frames):
+    if out["exact_frames"] < min(min_exact, n_frames):
         detector_problems.append(f"only {out['exact_frames']} frames compared element for element")
     assert not detector_problems, (detector_problems[:6], out)
     # ---- caption ids: crops on both sides of frame boundaries inside one micro-batch, and around a micro-batch boundary

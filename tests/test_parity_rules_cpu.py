@@ -136,8 +136,12 @@ def test_bench_path_element_rules(frame):
     assert run(bad, cr_r)[1]
     crops = [list(c) for c in cr_r]; crops[3][0] += 2
     assert run(el_r, crops)[1]
-    # on a frame with an NMS tie (or outside the list) only the element count is compared
+    # a listed frame whose oracle NMS decides on a tie: one exchanged element per tie, not more
     tied = dict(dbg); tied["near_ties"] = 1
-    out, problems = run(el_r[:-2], cr_r[:-2], d=tied)
+    out, problems = run(el_r[:-1], cr_r[:-1], d=tied)
     assert not problems and out["exact_frames"] == 0
-    assert run(el_r[: len(el_r) // 2], cr_r, d=tied)[1]
+    assert run(el_r[:-4], cr_r, d=tied)[1]
+    # outside the list (oracle ill conditioned there) only the element count is compared
+    out, problems = run(el_r[:-2], cr_r[:-2], d=tied, listed=False)
+    assert not problems and out["exact_frames"] == 0
+    assert run(el_r[: len(el_r) // 2], cr_r, d=tied, listed=False)[1]
