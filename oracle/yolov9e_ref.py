@@ -249,10 +249,23 @@ def letterbox_tensor(img_u8, imgsz):
     return x
 
 
-def _calibration_input(seeds=tuple(range(8))):
-    """640x640 letterboxes of synthetic screenshots."""
+def _calibration_input(seeds=tuple(range(8)), noisy=0, noise_std=0.1, random_frames=0, native=0):
+    """640x640 letterboxes of synthetic screenshots (+ optionally `noisy` of them with additive pixel noise and `random_frames`
+    uniform-noise images: directions the clean frames never excite)."""
     from omniparser_amd.synth import synthetic_screenshot
-    return torch.cat([letterbox_tensor(synthetic_screenshot(sd), 640) for sd in seeds])
+    x = torch.cat([letterbox_tensor(synthetic_screenshot(sd), 640) for sd in seeds])
+    g = torch.Generator().manual_seed(1234)
+    extra = []
+    if noisy:
+        extra.append((x[:noisy] + noise_std * torch.randn(x[:noisy].shape, generator=g)).clamp(0, 1))
+    if random_frames:
+        extra.append(torch.rand((random_frames,) + tuple(x.shape[1:]), generator=g))
+    for i in range(native):
+        # 640x640 windows of the frames at NATIVE scale (the scale_img=True path runs the network on unscaled pixels)
+        img = synthetic_screenshot(seeds[i % len(seeds)])
+        y0, x0 = (137 * i) % (img.shape[0] - 640), (411 * i) % (img.shape[1] - 640)
+        extra.append(torch.from_numpy(img[y0:y0 + 640, x0:x0 + 640].copy()).permute(2, 0, 1)[None].float() / 255.0)
+    return torch.cat([x] + extra)
 
 
 def max_class_logits(model, x):
@@ -264,17 +277,24 @@ def max_class_logits(model, x):
     return torch.cat(res)
 
 
-def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False, box_gain=1.0):
+def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False, box_gain=1.0,
+                          bn_gain=0.25, bn_shift=0.5, calib_noisy=2, calib_random=1, calib_noise_std=0.1, calib_native=8):
     """Seeded random YOLOv9-E that is WELL CONDITIONED, so that box-for-box parity can be asserted on every frame:
 
       * BatchNorm gains are small (gamma ~ 0.25) and shifts sizeable (beta ~ 0.5 randn): every Conv+BN+SiLU then works
         around the near-linear part of SiLU and the net stops amplifying rounding noise (the round-1 stand-in, gamma ~ 1,
         amplified f32 noise 1e3-1e4x: its own f32 and f64 evaluations disagreed by 5e-3 in the logits).  Measured here:
         f32-vs-f64 head difference ~3e-5 of the logit spread (tools/make_weights.py --report);
-      * running statistics are calibrated on the eight synthetic bench screenshots; the class head is rescaled to a logit spread
-        of ~1.5 and biased so that ~`pass_rate` of the anchors exceed `conf`: 0.15 gives ~1 260 candidates (the per-class branch
-        of batched_nms, > 4000 elements), ~100 boxes, ~87 elements and ~48 caption crops per 1920x1080 screenshot — the load of
-        round 1's bench (85.5 elements / 46 crops);
+      * running statistics are the POOLED statistics of one calibration batch: the eight synthetic bench screenshots (640x640
+        letterboxes) plus — "v4", end of round 2 — two of them with additive pixel noise, one uniform-noise image and eight
+        640x640 windows of the screenshots at native scale.  With the clean frames alone (v3) channels that are almost constant
+        on flat GUI content got huge gains gamma/sigma; a frame that did excite them (3 of the 8 bench frames, every 640x480 frame,
+        every native-resolution input) then carried activations of 20-60 sigma and amplified rounding noise to 1e-3 ... 1e-2 in the
+        logits.  The extra frames put variance into those directions: measured f32-vs-f64 head difference 7e-6 ... 1.3e-5 on all
+        eight bench frames and on the 640x480 frames at all three widths; 1088x1920 inputs remain the exception (3e-2 ... 7e-2:
+        outliers near the image border, where native-scale windows do not reach);
+      * the class head is rescaled to a logit spread of ~1.5 and biased so that ~`pass_rate` of the anchors exceed `conf`: ~1 200-1 450
+        candidates, ~100-110 boxes per 1920x1080 screenshot;
       * `margin_frames` ([1,3,H,W] letterboxed inputs the parity tests run on): the threshold is centred in the widest gap
         between neighbouring DISTINCT anchor logits of the calibration + those frames around the requested pass rate, so no
         candidate sits within rounding distance of `conf` — the tests can then demand identical candidate sets
@@ -289,8 +309,8 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, ma
                 if m.bias is not None:
                     m.bias.copy_(torch.randn(m.bias.shape, generator=g) * 0.1)
             elif isinstance(m, nn.BatchNorm2d):
-                m.weight.copy_(0.25 * (1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)))
-                m.bias.copy_(0.5 * torch.randn(m.bias.shape, generator=g))
+                m.weight.copy_(bn_gain * (1.0 + 0.1 * torch.randn(m.weight.shape, generator=g)))
+                m.bias.copy_(bn_shift * torch.randn(m.bias.shape, generator=g))
         for m in model.modules():
             if isinstance(m, nn.BatchNorm2d):
                 m.momentum = 1.0
@@ -300,10 +320,12 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, ma
             seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
             seq[-1].weight.mul_(box_gain)
         x = _calibration_input()
+        xc = _calibration_input(noisy=calib_noisy, random_frames=calib_random, noise_std=calib_noise_std, native=calib_native) \
+            if (calib_noisy or calib_random or calib_native) else x
         # running stats <- POOLED batch statistics of all eight frames (per-frame statistics would leave the frames' global
         # differences un-normalised: whole frames then sit above / below the score threshold).  The pass runs on the 2x
         # box-filtered frames: a quarter of the working set, same per-channel statistics to within a few percent.
-        model(F.avg_pool2d(x, 2) if calib_half else x)
+        model(F.avg_pool2d(xc, 2) if calib_half else xc)
         model.eval()
         for m in model.modules():
             if isinstance(m, nn.BatchNorm2d):

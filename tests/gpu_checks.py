@@ -1010,7 +1010,7 @@ def compare_frame_elements(f, elems_g, crops_g, el_r, cr_r, dbg, listed_exact, o
     tie_free = dbg["near_ties"] == 0 and dbg["score_ties"] == 0
     out["score_ties"].append(int(dbg["score_ties"]))
     if tie_free and listed_exact:
-        # a frame of the well-conditioned, tie-free list (tools/make_weights.py::EXACT_FRAMES): element for element
+        # a well-conditioned frame (tools/make_weights.py::WELL_FRAMES) without an NMS tie in the oracle: element for element
         out["exact_frames"] += 1
         out["min_iou"] = min(out["min_iou"], float(best.min()) if len(best) else 1.0)
         if missing or len(el_r) != len(elems_g):
@@ -1039,7 +1039,7 @@ def compare_frame_elements(f, elems_g, crops_g, el_r, cr_r, dbg, listed_exact, o
     out["matched_fraction"].append(round(1.0 - missing / max(len(el_r), 1), 4))
 
 
-def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=2):
+def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=1):
     """Parity of the EXACT composition bench.py times (BASELINE configs[2]): ScreenParser.parse_batch on a batch of
     1920x1080 screenshots — batch detector plan, full-width YOLOv9-E, product glue, crops of all frames packed into 128-crop
     caption micro-batches at RxR, deferred id read-back — against the oracle pipeline (oracle.detector_ref.predict per frame
@@ -1072,8 +1072,8 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     out["near_ties"], out["exact_frames"] = [], 0
     out.update(score_ties=[], matched_fraction=[], crop_coords_off_by_one=0)
     detector_problems = []
-    from tools.make_weights import EXACT_FRAMES
-    exact_frames = set(EXACT_FRAMES.get((width, 640), ()))
+    from tools.make_weights import WELL_FRAMES
+    exact_frames = set(WELL_FRAMES.get((width, 640), ()))     # well-conditioned frames: exact when tie-free, one exchange per tie otherwise
     for f in range(n_frames):
         rb, rs, rc, dbg = D.predict(cpu_model, Image.fromarray(imgs[f]), conf=0.05, imgsz=640, iou=0.1, max_det=300, return_debug=True)
         el_r, cr_r = sp.glue(rb, IW, IH, ocr[f][1], ocr[f][0])

@@ -15,7 +15,7 @@ def test_detector_half_width_640():
     for rec in out["images"]:
         G.assert_detector_frame(rec, exact=True)
     # a frame on which the oracle's NMS does take a decision on a score tie: everything up to the NMS input is still exact
-    out, det = G.check_detector(width=0.5, image_seeds=(0,), imgsz=640, with_f64=True)
+    out, det = G.check_detector(width=0.5, image_seeds=(0,), imgsz=640)
     G.assert_detector_frame(out["images"][0])
 
 
@@ -85,13 +85,15 @@ def test_oracle_is_well_conditioned():
 
 
 def test_detector_full_width_boxes_640():
-    """Full YOLOv9-E at the reference's default 640x640 network input on the tie-free, well-conditioned frames: box for box —
-    same candidates, same count, identical class ids, IoU >= 0.999, head tensors within 1e-4 absolute."""
+    """Full YOLOv9-E at the reference's default 640x640 network input: head tensors within 1e-4 absolute and identical candidate
+    sets on every frame; box for box (same count, identical class ids, IoU >= 0.999) on the tie-free frame, one exchanged box per
+    tie of the oracle's own NMS on the others (frames 0 and 2 of the bench batch: 0 / 1 ties in the CPU scan)."""
     import gpu_checks as G
     from tools.make_weights import EXACT_FRAMES
-    out, det = G.check_detector(width=1.0, image_seeds=EXACT_FRAMES[(1.0, 640)], imgsz=640)
+    out, det = G.check_detector(width=1.0, image_seeds=EXACT_FRAMES[(1.0, 640)] + (0, 2), imgsz=640)
     for rec in out["images"]:
-        G.assert_detector_frame(rec, exact=True)
+        assert max(max(e) for e in rec["head_err(cls,dist)"]) <= G.HEAD_TOL, rec          # every bench frame is well conditioned
+        G.assert_detector_frame(rec, exact=rec["seed"] in EXACT_FRAMES[(1.0, 640)])
     print(out)
 
 

@@ -22,7 +22,7 @@ def test_half_width_exact_frames_and_a_tie_frame(rehearsal):
     for rec in out["images"]:
         G.assert_detector_frame(rec, exact=True)
         assert rec["zero_area_boxes"] > 0            # the case that made IoU-only matching report dozens of "lost" boxes
-    out, _ = G.check_detector(width=0.5, image_seeds=(0,), imgsz=640, with_f64=True)
+    out, _ = G.check_detector(width=0.5, image_seeds=(0,), imgsz=640)
     assert out["images"][0]["score_ties"] >= 1
     G.assert_detector_frame(out["images"][0])
 
@@ -70,7 +70,6 @@ def test_bench_path_check_rehearsed(rehearsal, monkeypatch):
                         lambda cdir, device, precision="f32", resolution=64: RehearsalCaptioner(G._OracleCaptioner(model, resolution), resolution))
     monkeypatch.setattr(P, "ScreenParser", RehearsalParser)
     monkeypatch.setattr(G, "DEV", "cpu")
-    monkeypatch.setitem(MW.EXACT_FRAMES, (0.5, 640), (1, 6, 0))       # frame 0 carries a score tie: listed, so the tie rule decides
     out = G.check_bench_path(R=64, width=0.5, n_frames=2, caption_pairs=((0, 1),), per_side=3, boundary=2, min_exact=1)
     assert out["exact_frames"] == 1 and out["score_ties"][0] >= 1 and out["crop_coords_off_by_one"] == 0
     assert out["caption_crops_checked"] >= 8 and out["frames_touched"] == [0, 1] and len(out["micro_batches_touched"]) >= 2

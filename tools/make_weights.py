@@ -19,19 +19,22 @@ sys.path.insert(0, str(ROOT))
 # Frames the GPU parity tests / smoke / bench run the detector on, per stand-in width: (image seed, iw, ih, imgsz, tiled).
 # build_random_detector centres the score threshold in a gap of THESE frames' anchor logits (oracle/yolov9e_ref.py).
 PARITY_FRAMES = {
-    1.0: [(s, 1920, 1080, 640, False) for s in range(8)] + [(0, 1920, 1080, (1080, 1920), False)],
+    1.0: [(0, 1920, 1080, (1080, 1920), False)],          # the eight 640x640 bench frames are the calibration batch itself
     0.5: [(s, 1920, 1080, 640, False) for s in (0, 1, 2)] + [(4, 3840, 2160, 640, True), (2, 1280, 800, 640, False)],
     0.25: [(0, 1920, 1080, (1080, 1920), False), (0, 640, 480, 320, False)],
 }
 
 
 # Frames (synthetic_screenshot seed at 1920x1080 — 640x480 for the 320 entry — letterboxed to the given network size) on which the
-# CPU oracle is (a) well conditioned: its own f32 and f64 evaluations of the head tensors differ by <= 3.3e-5, and (b) takes no NMS
-# decision on a tie: no IoU within 1e-5 of the threshold, no suppression by a box whose score is within 4e-6 of its victim's
-# (margins of the listed frames: IoU >= 3.4e-5, score >= 8.8e-6; GPU-vs-oracle differences are ~1e-6 in the scores, ~2e-4 px in the
-# boxes).  On these the parity tests demand the oracle's boxes one for one.  Scan: tools/scan_parity_frames.py ->
-# profiles/r2_parity_frame_scan.md.  Must be re-scanned whenever oracle/yolov9e_ref.py::build_random_detector or synth.py changes.
-EXACT_FRAMES = {(1.0, 640): (2, 5, 7), (0.5, 640): (6, 1), (0.25, 640): (3,), (0.25, 320): (3, 2)}
+# CPU oracle takes no NMS decision on a tie, with margin: no IoU within 1e-5 of the threshold (listed frames: >= 5.6e-5), no suppression
+# by a box whose score is within 4e-6 of its victim's (listed frames: >= 1.0e-5); GPU-vs-oracle differences are ~1e-6 in the scores,
+# ~2e-4 px in the boxes, ~1e-5 in the logits (threshold margin of the listed frames >= 1.0e-4).  With the v4 stand-in EVERY 640x640 and
+# 320x320 frame is well conditioned (f32 vs f64 <= 1.3e-5), so the list only selects for ties.  On these frames the parity tests
+# demand the oracle's boxes one for one and fail if the oracle on the test box disagrees that they are tie-free.
+# Scan: tools/scan_parity_frames.py -> profiles/r2_parity_frame_scan.md.  Re-scan whenever build_random_detector or synth.py changes.
+EXACT_FRAMES = {(1.0, 640): (1,), (0.5, 640): (4, 2), (0.25, 640): (1, 3), (0.25, 320): (2, 0)}
+# frames the scan found well conditioned (ties or not): candidate sets must be identical there, final boxes up to one exchange per tie
+WELL_FRAMES = {(1.0, 640): tuple(range(8)), (0.5, 640): tuple(range(8)), (0.25, 640): (0, 1, 2, 3), (0.25, 320): (0, 1, 2, 3)}
 
 
 def parity_inputs(width):
@@ -61,7 +64,7 @@ def make_blob(path, seed=0, nc=1, width=1.0):
 
 
 def default_path(seed=0, nc=1, width=1.0):
-    tag = f"v3_s{seed}_nc{nc}_w{width:g}"       # v3: well-conditioned stand-in, 8-frame calibration, pass rate 0.15 (round 2)
+    tag = f"v4_s{seed}_nc{nc}_w{width:g}"       # v4: calibration batch with noisy / random / native-scale frames (end of round 2)
     return ROOT / "weights" / f"icon_detect_v3_{tag}" / "icon_detect_v3" / "model.pt"
 
 
