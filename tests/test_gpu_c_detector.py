@@ -51,7 +51,7 @@ def test_tiled_detection_4k_matches_oracle_policy():
     cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
     rb, rs, rc, ties = TR.predict_tiled(cpu_model, img, origins, tw, th, return_stats=True)
     assert len(rb) > 0 and abs(len(rb) - len(gb)) <= max(3, 0.15 * len(rb))
-    # (CPU rehearsal with the oracle's f64 evaluation as the "device": no ties on this frame, 300 of 300 boxes found again)
+    # (CPU rehearsal with the oracle's f64 evaluation as the "device": one score tie on this frame, 300 of 300 boxes found again)
     n_ties = ties.get("near_ties", 0) + ties.get("score_ties", 0)
     unmatched = int((G.box_similarity(rb, gb).max(1).values < 0.999).sum())
     assert unmatched <= max(2 * n_ties, 0.03 * len(rb)), (unmatched, len(rb), len(gb), ties)
