@@ -1,0 +1,48 @@
+#!/usr/bin/env bash
+# Round-3 opening GPU session (one gpurun call, ~25 GPU-minutes): everything round 2 left unmeasured.
+#   1. default bench line (the v4 stand-in has never run on a GPU: expect ~8.4 screenshots/s at 43.6 crops per screenshot)
+#   2. whole GPU suite, file by file so that one failure does not hide the rest
+#   3. A/B of the opt-in format-B producers (attention / channel attention / fused dwconv+LN write split output)
+#   4. rocprofv3 kernel stats and PMC traffic of the SAME bench command at the final load -> copy summaries to profiles/r3_*
+# usage: gpurun --timeout 1700 -- 'bash tools/r3_open.sh'
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out/r3open
+mkdir -p "$OUT"
+python tools/make_weights.py --ensure detector > /dev/null 2>&1
+python tools/make_weights.py --ensure caption > /dev/null 2>&1
+echo "=== 1. default bench line"
+( OMNI_BENCH_WATCHDOG=120 timeout 420 python bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "exit $?" >> "$OUT/bench.err" )
+grep -v "^  File\|^Thread" "$OUT/bench.err" | tail -6 | cut -c1-300
+echo "=== 2. GPU suite"
+for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/test_gpu_c_detector.py tests/test_gpu_d_pipeline.py; do
+  n=$(basename "$f" .py)
+  ( timeout 600 python -m pytest "$f" -q -p no:cacheprovider --durations=5 > "$OUT/$n.log" 2>&1; echo "exit $?" >> "$OUT/$n.log" )
+  echo "--- $n"; grep -v "Warning\|warnings.warn\|^$\|_create_method\|^tests/test_gpu" "$OUT/$n.log" | tail -12 | cut -c1-1200
+done
+echo "=== 3. opt-in format-B producers"
+( OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1 timeout 240 python -m pytest tests/test_gpu_b_caption_model.py -q -p no:cacheprovider -k "r64 or r768" 2>&1 | tail -3 | cut -c1-400 )
+for v in "OMNI_ATTN_SPLIT_OUT=1" "OMNI_FUSE_DWLN=1" "OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1"; do
+  tag=$(echo "$v" | tr ' =' '__')
+  ( env $v OMNI_BENCH_WATCHDOG=60 timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_$tag.json" 2> "$OUT/ab_$tag.err"; echo "$v -> exit $?" )
+  python - "$OUT/ab_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("   ", d["value"], "screenshots/s", d["ms_per_step"], "ms/step; gemm", r.get("gemm_ms_per_step"), "non-gemm share", r.get("non_gemm_share"))
+except Exception as e:
+    print("    no line:", e)
+PY
+done
+echo "=== 4. kernel stats + PMC traffic of the bench command (same pattern as tools/r2_measure.sh)"
+( timeout 300 rocprofv3 --kernel-trace --stats --output-format csv -d "$OUT/stats" -- python bench.py --steps 2 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/stats_bench.json" 2> "$OUT/stats.err"; echo "stats exit $?" )
+for ctr in FETCH_SIZE WRITE_SIZE; do
+  ( timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/pmc_$ctr" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc_$ctr.err"; echo "pmc $ctr exit $?" )
+  python tools/pmc_summary.py "$OUT/pmc_$ctr" > "$OUT/pmc_$ctr.json" 2>> "$OUT/pmc_$ctr.err"
+done
+find "$OUT" -name "*_kernel_stats.csv" | head -3
+find "$OUT" -name "*.csv" -size +8M -delete
+find "$OUT" -name "*.db" -delete
+ls -la "$OUT" | head -40
