@@ -86,7 +86,7 @@ def main():
     rng = np.random.default_rng(0)
     # ---- remove_overlap_new / int_box_area
     cases = []
-    for ci in range(12):
+    for ci in range(36):
         w, h = (1920, 1080) if ci % 2 == 0 else (1280, 800)
         n_icon, n_ocr = int(rng.integers(5, 60)), int(rng.integers(0, 25))
         icons = rand_boxes(rng, n_icon, w, h, 10, 120)
@@ -97,11 +97,16 @@ def main():
         for j in range(0, min(n_ocr, n_icon), 4):      # some text inside icons, some icons inside text
             ic = icons[j]
             ocr[j] = [ic[0] + 2, ic[1] + 2, ic[2] - 2, ic[3] - 2] if j % 8 == 0 else [ic[0] - 30, ic[1] - 30, ic[2] + 30, ic[3] + 30]
-        if ci == 3 and n_ocr > 2:
+        if ci % 6 == 3 and n_ocr > 2:
             ocr[1] = ocr[0]              # duplicate OCR element: exercises list.remove of equal dicts
+            if ci > 12 and n_ocr > 6:
+                ocr[5] = ocr[4]; ocr[6] = ocr[4]
+        if ci % 6 == 5 and n_icon > 8:
+            icons[7] = icons[6]          # identical icon boxes (equal area: neither is "the larger")
+            icons[8, 2:] = icons[8, :2]  # a zero-area icon
         icons_r = (torch.tensor(icons, dtype=torch.float32) / torch.Tensor([w, h, w, h])).tolist()
         ocr_r = (torch.tensor(ocr.astype(np.int64)) / torch.Tensor([w, h, w, h])).tolist() if n_ocr else []
-        texts = [f"t{j % 7}" if ci == 3 else f"t{j}" for j in range(n_ocr)]
+        texts = [f"t{j % 7}" if ci % 6 == 3 else f"t{j}" for j in range(n_ocr)]
         thr = [0.7, 0.9, 0.1][ci % 3]
         ocr_el = [{"type": "text", "bbox": b, "interactivity": False, "content": t, "source": "box_ocr_content_ocr"}
                   for b, t in zip(ocr_r, texts) if RU.int_box_area(b, w, h) > 0]
