@@ -118,6 +118,7 @@ def main():
     recs = torch.zeros(args.steps * B, OD.REC_W, dtype=torch.int32, device=dev)
     crop_counts = []
 
+    @torch.inference_mode()
     def step(step_id, li=None):
         idx = [(step_id * B + j) % 8 for j in range(B)]
         if args.mode == "detect":

@@ -474,6 +474,7 @@ class Florence2Captioner:
                 return b
         return 128
 
+    @torch.inference_mode()
     def plans(self, B, R, max_new) -> _CaptionPlans:
         key = (B, R, max_new)
         if key in self._plans:

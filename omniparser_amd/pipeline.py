@@ -71,6 +71,7 @@ class ScreenParser:
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
+    @torch.inference_mode()
     def detect(self, frames: Sequence[torch.Tensor], pad_to: Optional[int] = None):
         """`pad_to`: run the plan of that batch size even for fewer frames (the unused slots keep whatever they held
         and their results are ignored) — streams with ragged batches then need ONE plan per resolution."""
@@ -98,6 +99,7 @@ class ScreenParser:
             return [int(round(i * step)) for i in range(k)]
         return [(x, y) for y in axis(ih, tile_h) for x in axis(iw, tile_w)], min(tile_w, iw), min(tile_h, ih)
 
+    @torch.inference_mode()
     def detect_tiled(self, frame: torch.Tensor):
         ih, iw = frame.shape[:2]
         origins, tw, th = self.tile_origins(iw, ih)
@@ -171,6 +173,7 @@ class ScreenParser:
         return [{"type": "text", "bbox": b, "interactivity": False, "content": t, "source": "box_ocr_content_ocr"}
                 for b, t in zip(ocr_r, ocr_text) if U.int_box_area(b, w, h) > 0]
 
+    @torch.inference_mode()
     def detect_glue(self, frames, ocr, pad_to=None):
         ih, iw = frames[0].shape[:2]
         det = self.det
@@ -213,6 +216,7 @@ class ScreenParser:
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
         return dp, gs, ocr_els, counts
 
+    @torch.inference_mode()
     def assemble(self, dp, gs, ocr_els, counts, iw, ih, n_frames):
         """element dicts of every frame from the device tables (called once, after the caption micro-batches were queued)."""
         with torch.cuda.stream(self.det.stream):
@@ -241,6 +245,7 @@ class ScreenParser:
         return out
 
     # ---- stage 3: caption all crops of all frames in packed micro-batches
+    @torch.inference_mode()
     def caption(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=20, crops_dev: Optional[torch.Tensor] = None):
         """crops_per_frame: host rectangles per frame, or — with `crops_dev` (int32 [frames, max_det, 4] on the device, rows in
         caption order) — just the number of crops per frame: the rectangles then never visit the host."""

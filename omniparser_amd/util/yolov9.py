@@ -217,6 +217,7 @@ class YOLOv9Detector:
         with Image.open(source) as image:
             return image.convert("RGB")
 
+    @torch.inference_mode()
     def get_plan(self, iw, ih, imgsz, conf, iou, max_det, batch=1) -> _DetectPlan:
         key = (iw, ih, self._normalize_image_size(imgsz), float(conf), float(iou), int(max_det), batch)
         if key in self._plans:
@@ -230,6 +231,7 @@ class YOLOv9Detector:
             self._plans[key] = _DetectPlan(self, iw, ih, imgsz, conf, iou, max_det, batch)
         return self._plans[key]
 
+    @torch.inference_mode()
     def predict_batch(self, images_u8, conf=0.25, imgsz=640, iou=0.7, max_det=300):
         """images_u8: list of equally sized uint8 [H,W,3] arrays/tensors.  Returns list of Result."""
         ih, iw = images_u8[0].shape[:2]
