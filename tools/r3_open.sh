@@ -42,6 +42,9 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   ( timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/pmc_$ctr" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc_$ctr.err"; echo "pmc $ctr exit $?" )
   python tools/pmc_summary.py "$OUT/pmc_$ctr" > "$OUT/pmc_$ctr.json" 2>> "$OUT/pmc_$ctr.err"
 done
+echo "=== 5. device hand-off (eager detector plan) A/B — last: the graph variant of this path stalled in round 2"
+( OMNI_DEVICE_GLUE=1 OMNI_BENCH_WATCHDOG=40 timeout 90 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_device_glue.json" 2> "$OUT/ab_device_glue.err"; echo "device glue -> exit $?" )
+tail -c 600 "$OUT/ab_device_glue.json"; echo
 find "$OUT" -name "*_kernel_stats.csv" | head -3
 find "$OUT" -name "*.csv" -size +8M -delete
 find "$OUT" -name "*.db" -delete
