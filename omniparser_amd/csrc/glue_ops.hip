@@ -15,7 +15,9 @@
 // stable sort "content is not None first": surviving OCR entries, icons with OCR text, icons without.
 // Outputs: element table (kind, source index), donor bit masks (the host builds the label strings), crop rectangles in
 // caption order, counts.  Host twin used as the test oracle: omniparser_amd/pipeline.py::ScreenParser.glue.
+#ifndef OMNI_HOST_EMU          // tests/emu/glue_emu.cpp compiles THIS file for the host (256 std::threads per workgroup) with its own prelude
 #include "omni_internal.h"
+#endif
 #include <string.h>
 
 namespace {
@@ -190,9 +192,8 @@ __global__ __launch_bounds__(256) void glue_kernel(GlueArgs a) {
 
 }  // namespace
 
-// OMNI_OP_GLUE (see include/omni_amd.h)
-int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
-  GlueArgs a;
+// argument unpacking shared by the launcher and the host emulation
+static int glue_args_from_op(const omni_op_t* op, GlueArgs& a, const char** why) {
   a.boxes = (const float*)op->p[0]; a.count = (const int*)op->p[1]; a.ocr = (const double*)op->p[2]; a.ocr_meta = (const int*)op->p[3];
   a.elems = (int*)op->p[4]; a.crops = (int*)op->p[5]; a.counts = (int*)op->p[6]; a.donors = (unsigned long long*)op->p[7];
   a.max_det = op->i[0]; a.n_ocr = op->i[1]; a.W = op->i[2]; a.H = op->i[3]; a.mw = op->i[4]; a.boxes_are_ratio = op->i[5]; a.cap_elems = op->i[6];
@@ -201,12 +202,23 @@ int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
     unsigned long long bits = ((unsigned long long)(unsigned)op->i[9] << 32) | (unsigned)op->i[8];
     memcpy(&a.thr, &bits, 8);
   }
-  OMNI_REQUIRE(a.boxes && a.count && a.elems && a.crops && a.counts && a.donors, "glue: null pointer");
-  OMNI_REQUIRE(a.max_det > 0 && a.max_det <= GLUE_MAX_ICONS && a.n_ocr >= 0 && a.n_ocr <= GLUE_MAX_OCR && a.W > 0 && a.H > 0,
-               "glue: capacity (icons <= %d, OCR boxes <= %d)", GLUE_MAX_ICONS, GLUE_MAX_OCR);
-  OMNI_REQUIRE(a.n_ocr == 0 || (a.ocr && a.ocr_meta), "glue: OCR boxes without their tables");
-  OMNI_REQUIRE(a.mw >= (a.n_ocr + 63) / 64 && a.mw >= 1 && a.cap_elems >= a.max_det + a.n_ocr, "glue: output capacity");
+  *why = nullptr;
+  if (!(a.boxes && a.count && a.elems && a.crops && a.counts && a.donors)) *why = "glue: null pointer";
+  else if (!(a.max_det > 0 && a.max_det <= GLUE_MAX_ICONS && a.n_ocr >= 0 && a.n_ocr <= GLUE_MAX_OCR && a.W > 0 && a.H > 0))
+    *why = "glue: capacity (icons <= 512, OCR boxes <= 1024)";
+  else if (!(a.n_ocr == 0 || (a.ocr && a.ocr_meta))) *why = "glue: OCR boxes without their tables";
+  else if (!(a.mw >= (a.n_ocr + 63) / 64 && a.mw >= 1 && a.cap_elems >= a.max_det + a.n_ocr)) *why = "glue: output capacity";
+  return *why ? 1 : 0;
+}
+
+#ifndef OMNI_HOST_EMU
+// OMNI_OP_GLUE (see include/omni_amd.h)
+int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
+  GlueArgs a;
+  const char* why = nullptr;
+  if (glue_args_from_op(op, a, &why)) { omni_set_error("%s", why); return OMNI_E_ARG; }
   hipLaunchKernelGGL(glue_kernel, dim3(1), dim3(256), 0, s, a);
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
 }
+#endif
