@@ -21,6 +21,7 @@ from . import _lib as L
 from .planner import PlanBuilder, View, torch_dtype
 
 PROMPT_IDS = [0, 2264, 473, 5, 2274, 6190, 116, 2]   # <s>What does the image describe?</s>  
+_BUCKETS = tuple(sorted({min(max(int(x), 1), 128) for x in os.environ.get("OMNI_CAPTION_BUCKETS", "8,16,32,64,128").split(",")} | {128}))
 CLIP_MEAN = (0.485, 0.456, 0.406)
 CLIP_STD = (0.229, 0.224, 0.225)
 
@@ -469,10 +470,12 @@ class Florence2Captioner:
 
     @staticmethod
     def bucket(n: int) -> int:
-        for b in (8, 16, 32, 64, 128):
+        """plan capacity for a micro-batch of n crops (rows beyond n are computed and ignored).  OMNI_CAPTION_BUCKETS adds sizes
+        (e.g. "8,16,32,64,96,128": a 93-crop tail then costs 96 rows instead of 128); every size is one more resident plan."""
+        for b in _BUCKETS:
             if n <= b:
                 return b
-        return 128
+        return _BUCKETS[-1]
 
     @torch.inference_mode()
     def plans(self, B, R, max_new) -> _CaptionPlans:

@@ -23,7 +23,7 @@ for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/tes
 done
 echo "=== 3. opt-in format-B producers"
 ( OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1 timeout 240 python -m pytest tests/test_gpu_b_caption_model.py -q -p no:cacheprovider -k "r64 or r768" 2>&1 | tail -3 | cut -c1-400 )
-for v in "OMNI_ATTN_SPLIT_OUT=1" "OMNI_FUSE_DWLN=1" "OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1"; do
+for v in "OMNI_ATTN_SPLIT_OUT=1" "OMNI_FUSE_DWLN=1" "OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1" "OMNI_CAPTION_BUCKETS=8,16,32,64,96,128"; do
   tag=$(echo "$v" | tr ' =' '__')
   ( env $v OMNI_BENCH_WATCHDOG=60 timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_$tag.json" 2> "$OUT/ab_$tag.err"; echo "$v -> exit $?" )
   python - "$OUT/ab_$tag.json" <<'PY'
