@@ -41,9 +41,9 @@ class _GlueState:
             self.crops = torch.zeros(B, md, 4, dtype=torch.int32, device=dev)
             self.counts = torch.zeros(B, 4, dtype=torch.int32, device=dev)
             self.donors = torch.zeros(B, md, MASK_WORDS, dtype=torch.int64, device=dev)
-        # plain (pageable) staging + BLOCKING uploads: a non_blocking copy from pinned memory makes torch record an event on the
-        # detector's stream, and on ROCm 7.2 the detector hipGraph's next replay behind such an event never completed
-        # (bisected in profiles/r2_notes.md); the tables are a few KB per frame
+        # plain (pageable) staging + blocking uploads (a few KB per frame).  Tried as a cure for the replay stall described in
+        # profiles/r2_notes.md (no event on the detector's stream between the upload and the graph launch) — it was not the cause;
+        # kept because it is the simplest correct form
         self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64)
         self.h_meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32)
         lo, hi = _f64_bits(thr)
@@ -52,8 +52,8 @@ class _GlueState:
                             self.elems[b].data_ptr(), self.crops[b].data_ptr(), self.counts[b].data_ptr(), self.donors[b].data_ptr()],
                          i={0: md, 1: OCR_CAP, 2: iw, 3: ih, 4: MASK_WORDS, 5: 0, 6: md + OCR_CAP, 7: 1, 8: lo, 9: hi})
                for b in range(B)]
-        self.plan = L.Plan(ops)        # replayed EAGERLY (B one-workgroup launches): as a captured hipGraph its second replay behind the
-        det.stream.synchronize()       # detector graph never completed on ROCm 7.2 (profiles/r2_notes.md); eager costs ~5 us per frame
+        self.plan = L.Plan(ops)        # run eagerly (B one-workgroup launches, ~5 us each), like the detector plan on this path:
+        det.stream.synchronize()       # see detect_glue and profiles/r2_notes.md
 
 
 class ScreenParser:
