@@ -39,6 +39,7 @@ class OmniError(RuntimeError):
 
 
 _lib = None
+EMULATION = False        # True only after bind_emulation(): the test suite's host build of the SAME device sources (tests/emu)
 
 
 def lib():
@@ -50,6 +51,13 @@ def lib():
     # runtime.  Loaded afterwards, libomni_amd.so binds to it by SONAME; loaded BEFORE torch it would pull /opt/rocm's copy into the
     # process as a second HIP runtime, whose launches fail with "no ROCm-capable device is detected".
     import torch  # noqa: F401
+    _lib = bind(path)
+    return _lib
+
+
+def bind(path):
+    """dlopen a library that implements include/omni_amd.h and declare its prototypes (libomni_amd.so; the test suite also binds the
+    host emulation tests/emu/libomni_emu.so, built from the same sources, to run the kernels without a GPU)."""
     L = ctypes.CDLL(str(path))
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:
@@ -82,8 +90,37 @@ def lib():
     L.omni_debug_host_op.restype = c_int
     if L.omni_abi_version() != 1:
         raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
-    _lib = L
     return L
+
+
+def bind_emulation(path):
+    """TEST SUITE ONLY: route this process's C-ABI calls to tests/emu/libomni_emu.so — csrc/*.hip compiled for the host against an
+    emulation of the HIP / gfx950 constructs they use (work-items as fibers, waves as collectives, MFMA, LDS-DMA).  Pointers handed
+    to it are host pointers; Detector / captioner objects then accept device "cpu".  Returns the previous binding."""
+    global _lib, EMULATION
+    prev = (_lib, EMULATION)
+    _lib, EMULATION = bind(path), True
+    return prev
+
+
+def unbind_emulation(prev):
+    global _lib, EMULATION
+    _lib, EMULATION = prev
+
+
+def require_device(device, what):
+    """The product runs on the MI355X only: anything but a cuda device raises — unless the test suite has bound the host emulation."""
+    import torch
+    device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
+    if EMULATION:
+        return torch.device("cpu")
+    if device.type == "cuda" and not torch.cuda.is_available():
+        raise RuntimeError(f"CUDA device requested but unavailable: {device}")   # ref:util/yolov9.py:40-41
+    if device.type != "cuda":
+        raise RuntimeError(f"omniparser_amd {what} is the MI355X path and has no CPU fallback; use the reference implementation on CPU")
+    if device.index is None:
+        device = torch.device("cuda", torch.cuda.current_device())
+    return device
 
 
 def check(rc: int):

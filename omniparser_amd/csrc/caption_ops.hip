@@ -1000,7 +1000,7 @@ struct DecArgs {
 template <typename T>
 __global__ __launch_bounds__(64) void attn_decode_kernel(DecArgs a) {
   // one wave per (b, head), head_dim 64: lanes split keys for the scores, then split d for P.V
-  extern __shared__ float sp[];               // nk probabilities
+  OMNI_DYN_LDS(float, sp);                    // nk probabilities
   const int h = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
   const int C = a.ldc;
   int nk;

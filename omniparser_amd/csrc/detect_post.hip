@@ -221,7 +221,7 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 
 // single wave: greedy pass over score-ordered boxes
 __global__ __launch_bounds__(64) void reduce_kernel(NmsArgs a, int max_words) {
-  extern __shared__ __attribute__((aligned(16))) unsigned long long remv[];
+  OMNI_DYN_LDS(__attribute__((aligned(16))) unsigned long long, remv);
   const int n = clamp_count(a.count, a.cap);
   const int nblk = (n + 63) >> 6;
   const int lane = threadIdx.x;

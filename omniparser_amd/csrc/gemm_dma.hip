@@ -159,7 +159,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   AF af[2];
   WF wf[2];
   if constexpr (ABL == 3) {
-    asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+    OMNI_WAIT_VMCNT(0);
     __builtin_amdgcn_s_barrier();
     loadW(lds, 0, wf[0]); loadW(lds, 1, wf[1]); loadA(lds, 0, 0, af[0]); loadA(lds, 1, 0, af[1]);
   }
@@ -170,8 +170,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
     // slice kt landed (this wave's pieces), later slices may stay in flight; then everybody's pieces landed and everybody is
     // done reading the stage that the next DMA overwrites (it was read in iteration kt - 1)
     if constexpr (ABL != 2 && ABL != 3) {
-      if constexpr (NSTAGE > 2 && decltype(more_tag)::value) asm volatile("s_waitcnt vmcnt(%0)" ::"n"((NSTAGE - 2) * DPS) : "memory");
-      else asm volatile("s_waitcnt vmcnt(0)" ::: "memory");
+      if constexpr (NSTAGE > 2 && decltype(more_tag)::value) OMNI_WAIT_VMCNT((NSTAGE - 2) * DPS);
+      else OMNI_WAIT_VMCNT(0);
       __builtin_amdgcn_s_barrier();
     }
     const unsigned char* st = lds + stage * STAGE;
@@ -197,10 +197,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
       if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);   // pin "next unit's ds_reads, then this unit's 12 MFMAs"
       if constexpr (ABL != 4) mma(ABL == 3 ? af[g & 1] : af[u & 1], wf[g & 1], ip);
       else {
+#ifndef OMNI_HOST_EMU
 #pragma unroll
         for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(af[u & 1].h[t]), "v"(af[u & 1].l[t]));
 #pragma unroll
         for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wf[g & 1].h[j]), "v"(wf[g & 1].l[j]));
+#endif
       }
       if constexpr (VAR == 1) {
         // one ds_read (then one DMA piece) behind each of the first MFMAs: they issue inside the 32-cycle MFMA slots

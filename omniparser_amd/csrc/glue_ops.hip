@@ -15,9 +15,7 @@
 // stable sort "content is not None first": surviving OCR entries, icons with OCR text, icons without.
 // Outputs: element table (kind, source index), donor bit masks (the host builds the label strings), crop rectangles in
 // caption order, counts.  Host twin used as the test oracle: omniparser_amd/pipeline.py::ScreenParser.glue.
-#ifndef OMNI_HOST_EMU          // tests/emu/glue_emu.cpp compiles THIS file for the host (256 std::threads per workgroup) with its own prelude
 #include "omni_internal.h"
-#endif
 #include <string.h>
 
 namespace {
@@ -211,7 +209,6 @@ static int glue_args_from_op(const omni_op_t* op, GlueArgs& a, const char** why)
   return *why ? 1 : 0;
 }
 
-#ifndef OMNI_HOST_EMU
 // OMNI_OP_GLUE (see include/omni_amd.h)
 int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
   GlueArgs a;
@@ -221,4 +218,3 @@ int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
 }
-#endif

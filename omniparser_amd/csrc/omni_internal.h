@@ -26,6 +26,16 @@ void omni_set_error(const char* fmt, ...);
     }                                           \
   } while (0)
 
+// counted wait on outstanding vector-memory operations (LDS-DMA pieces); the host emulation of tests/emu defines its own
+#ifndef OMNI_WAIT_VMCNT
+#define OMNI_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
+#endif
+
+// dynamically sized LDS array of a kernel (size = the launch's shared-memory argument)
+#ifndef OMNI_DYN_LDS
+#define OMNI_DYN_LDS(type, name) extern __shared__ type name[]
+#endif
+
 typedef _Float16 half_t;
 typedef float f32x4 __attribute__((ext_vector_type(4)));
 typedef float f32x16 __attribute__((ext_vector_type(16)));

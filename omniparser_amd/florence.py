@@ -439,11 +439,7 @@ class Florence2Captioner:
     (ref:util/utils.py:108-125): `.config.name_or_path`, `.config.model_type`, `.device`, `.generate`."""
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
-        device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
-        if device.type != "cuda" or not torch.cuda.is_available():
-            raise RuntimeError("omniparser_amd Florence2Captioner is the MI355X path and has no CPU fallback")
-        if device.index is None:
-            device = torch.device("cuda", torch.cuda.current_device())
+        device = L.require_device(device, "Florence2Captioner")
         L.lib()
         self.device = device
         precision = precision or os.environ.get("OMNI_PRECISION", "f32")

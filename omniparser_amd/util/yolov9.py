@@ -151,14 +151,7 @@ class YOLOv9Detector:
         revision: str = "main",
         precision: str = None,
     ):
-        self.device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
-        if self.device.type == "cuda" and not torch.cuda.is_available():
-            raise RuntimeError(f"CUDA device requested but unavailable: {self.device}")   # ref:util/yolov9.py:40-41
-        if self.device.type != "cuda":
-            raise RuntimeError("omniparser_amd.YOLOv9Detector is the MI355X path and has no CPU fallback; "
-                               "use the reference implementation on CPU")
-        if self.device.index is None:
-            self.device = torch.device("cuda", torch.cuda.current_device())
+        self.device = L.require_device(device, "YOLOv9Detector")
         L.lib()   # fail loudly if the HIP extension is missing
         if model_path is None:
             from huggingface_hub import hf_hub_download
