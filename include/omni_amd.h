@@ -165,6 +165,19 @@ enum {
    *  i0 max_det (<= 512) i1 OCR capacity (<= 1024) i2 W i3 H i4 mask words per icon i5 boxes are ratios i6 element capacity
    *  i7 = 1: the overlap threshold is the f64 with bit pattern i9:i8 (Python passes 0.7 as a double), else f0 */
   OMNI_OP_GLUE = 20,
+  /* Set-of-marks overlay rastered in place on the device (ref:util/utils.py:478-483 annotate() -> ref:util/box_annotator.py:86-162;
+   * the draw list comes from util/overlay.py::plan_overlay, pinned to the reference's cv2 call sequence): painter's algorithm over
+   * a primitive list, in order.  p0 frame u8[H,W,3] (in / out) p1 primitives i32[n,8] = {kind, x0, y0, x1, y1, r | g<<8 | b<<16,
+   * a, 0}: kind 0 filled rectangle (x1, y1 inclusive), 1 ring = the pixels of the rectangle that are not in its interior shrunk by
+   * a = width on every side, 2 coverage mask (x1, y1 exclusive; a = byte offset of its (y1-y0) x (x1-x0) u8 mask in p2) blended
+   * like Pillow's draw_bitmap; p2 masks u8.  i0 H i1 W i2 n */
+  OMNI_OP_OVERLAY = 21,
+  /* Frame -> PNG file -> base64, all on the device (ref:util/utils.py:485-488: PIL save(format="PNG") + base64.b64encode):
+   * signature, IHDR (8-bit RGB), ONE IDAT whose zlib stream holds stored deflate blocks (filter 0 scanlines; 65535-byte blocks),
+   * IEND; Adler-32 and the chunk CRC-32 are computed on the device.  File size = H (3 W + 1) + 5 ceil(H (3 W + 1) / 65535) + 63.
+   *  p0 frame u8[H,W,3] p1 out PNG bytes p2 scratch u32[2 H + ceil((size - 53) / 4096)] p3 out base64 ASCII (4 ceil(size / 3)
+   *  bytes) or NULL.  i0 H i1 W i2 scratch words i3 capacity of p1 in bytes (0 = not checked) */
+  OMNI_OP_PNG_PACK = 22,
   OMNI_OP__COUNT
 };
 

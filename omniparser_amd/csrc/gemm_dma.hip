@@ -371,9 +371,15 @@ int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(!a.res || (a.ldr % 4 == 0 && a.res_coff % 4 == 0), "gemm_dma: residual alignment");
   OMNI_REQUIRE((long long)a.ldi * 4 * 256 < (1ll << 31) && (long long)a.K * 4 * 256 < (1ll << 31), "gemm_dma: row stride too large");
   a.nk = a.K / 32;
-  // tile choice: 256x256 (one 8-wave block per CU, 128x64 per wave) when N allows; 256x128 otherwise.  OMNI_GEMM_TILE
-  // (256x256 | 256x128 | 128x128) is the A/B knob of tools/gemm_bench.py.
+  // tile choice: 256x256 (one 8-wave block per CU, 128x64 per wave) when N allows, 256x128 otherwise — as long as the launch
+  // still has a block for every CU; a short token matrix (small caption batches, 64x64 crops) takes 128x128 tiles instead, which
+  // quarter the padded rows and give the chip 4x the blocks.  OMNI_GEMM_TILE (256x256 | 256x128 | 128x128) is the A/B knob of
+  // tools/gemm_bench.py.
   int tile = (a.N % 256 == 0) ? 0 : 1;
+  {
+    const long long mt256 = (a.M + 255) / 256;
+    if (mt256 * (a.N / (tile == 0 ? 256 : 128)) < 256) tile = (tile == 0 && mt256 * (a.N / 128) >= 256) ? 1 : 2;
+  }
   if (const char* e = getenv("OMNI_GEMM_TILE")) {
     if (!strcmp(e, "256x128")) tile = 1;
     else if (!strcmp(e, "128x128")) tile = 2;

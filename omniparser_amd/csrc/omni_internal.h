@@ -98,3 +98,5 @@ int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s);
 int omni_launch_attention(const omni_op_t* op, hipStream_t s);
 int omni_launch_misc(const omni_op_t* op, hipStream_t s);
 int omni_launch_glue(const omni_op_t* op, hipStream_t s);
+int omni_launch_overlay(const omni_op_t* op, hipStream_t s);
+int omni_launch_png_pack(const omni_op_t* op, hipStream_t s);

@@ -1,0 +1,289 @@
+// Set-of-marks overlay and PNG / base64 packing on the device: the tail of get_som_labeled_img (ref:util/utils.py:478-491 —
+// annotate(), PIL save to PNG, base64) without a host raster or a host deflate.  Byte work, HBM-bound: every kernel touches each
+// byte of the 6.2 MB frame (1920x1080x3) once or twice.
+//
+//   OMNI_OP_OVERLAY   painter's algorithm per pixel over the primitive list of util/overlay.py::raster_primitives (filled
+//                     rectangle, ring = outline of a given width inside a rectangle, 8-bit coverage mask blended like Pillow's
+//                     draw_bitmap): one thread per pixel walks the primitives IN ORDER; a workgroup (64x4 pixels) first culls
+//                     them against its tile, 256 at a time, into LDS flags.
+//   OMNI_OP_PNG_PACK  frame -> complete PNG file image in device memory: signature, IHDR, one IDAT holding a zlib stream of
+//                     STORED deflate blocks (filter byte 0 per scanline), IEND; Adler-32 and CRC-32 are computed on the device
+//                     (per-segment partials, combined by one thread with the GF(2) shift operator x^(8 len) mod P), then the whole
+//                     file is base64-encoded.  Five small launches on one stream; the host reads back ASCII.
+// The byte layout is restated on the CPU in oracle/png_ref.py (test oracle); any PNG reader is the second check.
+#include "omni_internal.h"
+
+namespace {
+
+// ------------------------------------------------------------------------------------ overlay
+struct OvArgs {
+  unsigned char* img; const int* prim; const unsigned char* masks;
+  int H, W, n;
+};
+constexpr int PRIM_INTS = 8;     // {kind, x0, y0, x1, y1, r | g << 8 | b << 16, a, b}
+enum { PRIM_FILL = 0, PRIM_RING = 1, PRIM_MASK = 2 };
+
+// Pillow's BLEND8 / DIV255: round(in * (255 - m) / 255 + ink * m / 255) in its integer form
+__device__ __forceinline__ unsigned blend8(unsigned m, unsigned in, unsigned ink) {
+  const unsigned t = in * (255u - m) + ink * m + 128u;
+  return (t + (t >> 8)) >> 8;
+}
+
+__global__ __launch_bounds__(256) void overlay_kernel(OvArgs a) {
+  __shared__ int sp[256 * PRIM_INTS];
+  __shared__ unsigned char hit[256];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  const int bx0 = blockIdx.x * 64, by0 = blockIdx.y * 4;
+  const int x = bx0 + tx, y = by0 + ty;
+  const bool live = x < a.W && y < a.H;
+  unsigned r = 0, g = 0, b = 0;
+  unsigned char* px = a.img + ((long long)y * a.W + x) * 3;
+  if (live) { r = px[0]; g = px[1]; b = px[2]; }
+  bool dirty = false;
+  for (int base = 0; base < a.n; base += 256) {
+    const int c = base + (int)threadIdx.x;
+    unsigned char h = 0;
+    if (c < a.n) {
+      const int* p = a.prim + (long long)c * PRIM_INTS;
+#pragma unroll
+      for (int q = 0; q < PRIM_INTS; ++q) sp[threadIdx.x * PRIM_INTS + q] = p[q];
+      // bounding box of the primitive (masks: x1 / y1 exclusive) against this tile
+      const int kx1 = p[0] == PRIM_MASK ? p[3] - 1 : p[3], ky1 = p[0] == PRIM_MASK ? p[4] - 1 : p[4];
+      h = (p[1] <= bx0 + 63 && kx1 >= bx0 && p[2] <= by0 + 3 && ky1 >= by0) ? 1 : 0;
+    }
+    hit[threadIdx.x] = h;
+    __syncthreads();
+    const int cnt = min(256, a.n - base);
+    if (live) {
+      for (int q = 0; q < cnt; ++q) {
+        if (!hit[q]) continue;
+        const int* p = sp + q * PRIM_INTS;
+        const int kind = p[0], x0 = p[1], y0 = p[2], x1 = p[3], y1 = p[4];
+        const unsigned col = (unsigned)p[5];
+        if (kind == PRIM_MASK) {
+          if (x < x0 || x >= x1 || y < y0 || y >= y1) continue;
+          const unsigned m = a.masks[(long long)p[6] + (long long)(y - y0) * (x1 - x0) + (x - x0)];
+          if (m == 0) continue;
+          r = blend8(m, r, col & 255u); g = blend8(m, g, (col >> 8) & 255u); b = blend8(m, b, (col >> 16) & 255u);
+          dirty = true;
+          continue;
+        }
+        if (x < x0 || x > x1 || y < y0 || y > y1) continue;
+        if (kind == PRIM_RING) {
+          const int w = p[6];
+          if (x >= x0 + w && x <= x1 - w && y >= y0 + w && y <= y1 - w) continue;      // inside the hole
+        }
+        r = col & 255u; g = (col >> 8) & 255u; b = (col >> 16) & 255u;
+        dirty = true;
+      }
+    }
+    __syncthreads();
+  }
+  if (live && dirty) { px[0] = (unsigned char)r; px[1] = (unsigned char)g; px[2] = (unsigned char)b; }
+}
+
+// ------------------------------------------------------------------------------------ PNG (stored deflate) + base64
+constexpr unsigned CRC_POLY = 0xedb88320u;
+constexpr int STORED_MAX = 65535;
+constexpr int PNG_HEAD = 8 + 25 + 8;     // signature, IHDR chunk, IDAT length + type: first byte of the zlib stream
+constexpr int CRC_SEG = 4096;            // bytes per CRC partial (all but the first segment, which takes the remainder)
+constexpr unsigned ADLER_MOD = 65521u;
+
+struct PngArgs {
+  const unsigned char* img; unsigned char* png; unsigned* part; unsigned char* b64;
+  int H, W;
+  long long U, Z, total;       // uncompressed bytes, zlib stream bytes, file bytes
+  int nblk, nseg;
+  long long first_seg;         // length of CRC segment 0
+};
+
+__device__ __forceinline__ long long zpos(long long u) { return 2 + 5 * (u / STORED_MAX + 1) + u; }   // offset inside the zlib stream
+
+// bit-at-a-time CRC step table entry (reflected polynomial)
+__device__ __forceinline__ unsigned crc_entry(unsigned i) {
+  unsigned c = i;
+#pragma unroll
+  for (int k = 0; k < 8; ++k) c = (c & 1u) ? (c >> 1) ^ CRC_POLY : c >> 1;
+  return c;
+}
+
+__device__ __forceinline__ void put_be32(unsigned char* p, unsigned v) {
+  p[0] = (unsigned char)(v >> 24); p[1] = (unsigned char)(v >> 16); p[2] = (unsigned char)(v >> 8); p[3] = (unsigned char)v;
+}
+
+// scanlines (filter byte 0 + RGB) into the stored blocks; block headers, file header and trailer constants.
+// One thread per 4 uncompressed bytes.
+__global__ __launch_bounds__(256) void png_scatter_kernel(PngArgs a) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  unsigned char* z = a.png + PNG_HEAD;
+  const int RB = 3 * a.W + 1;
+  const long long u0 = t * 4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long u = u0 + e;
+    if (u >= a.U) break;
+    const long long row = u / RB;
+    const int col = (int)(u - row * RB);
+    z[zpos(u)] = col == 0 ? (unsigned char)0 : a.img[row * (long long)(3 * a.W) + col - 1];
+  }
+  if (t < a.nblk) {                                    // stored-block header t
+    const long long start = t * (long long)STORED_MAX;
+    const unsigned len = (unsigned)min((long long)STORED_MAX, a.U - start);
+    unsigned char* h = z + 2 + 5 * t + start;
+    h[0] = t == a.nblk - 1 ? 1 : 0;
+    h[1] = (unsigned char)(len & 255u); h[2] = (unsigned char)(len >> 8);
+    h[3] = (unsigned char)(~len & 255u); h[4] = (unsigned char)((~len >> 8) & 255u);
+  }
+  if (t == 0) {
+    const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+    for (int k = 0; k < 8; ++k) a.png[k] = sig[k];
+    unsigned char* ih = a.png + 8;
+    put_be32(ih, 13); ih[4] = 'I'; ih[5] = 'H'; ih[6] = 'D'; ih[7] = 'R';
+    put_be32(ih + 8, (unsigned)a.W); put_be32(ih + 12, (unsigned)a.H);
+    ih[16] = 8; ih[17] = 2; ih[18] = 0; ih[19] = 0; ih[20] = 0;                 // 8 bits, truecolour, deflate, adaptive, no interlace
+    unsigned c = 0xffffffffu;
+    for (int k = 4; k < 21; ++k) c = crc_entry((c ^ ih[k]) & 255u) ^ (c >> 8);
+    put_be32(ih + 21, c ^ 0xffffffffu);
+    unsigned char* id = a.png + 33;
+    put_be32(id, (unsigned)a.Z); id[4] = 'I'; id[5] = 'D'; id[6] = 'A'; id[7] = 'T';
+    z[0] = 0x78; z[1] = 0x01;
+    unsigned char* ie = a.png + PNG_HEAD + a.Z + 4;                              // behind the IDAT CRC
+    const unsigned char iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82};
+    for (int k = 0; k < 12; ++k) ie[k] = iend[k];
+  }
+}
+
+// Adler-32 partials of the scanlines: one wave per row, part[2 row] = sum of bytes, part[2 row + 1] = sum of (RB - i) * byte_i
+// (both mod 65521), i.e. the row's contribution to (A, B) when it is the LAST row.
+__global__ __launch_bounds__(64) void png_adler_rows_kernel(PngArgs a) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int RB = 3 * a.W + 1;
+  const unsigned char* src = a.img + (long long)row * (3 * a.W);
+  unsigned long long s1 = 0, s2 = 0;
+  for (int i = 1 + lane; i < RB; i += 64) {            // byte 0 of the scanline is the filter byte 0: contributes nothing
+    const unsigned v = src[i - 1];
+    s1 += v;
+    s2 += (unsigned long long)(RB - i) * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) { a.part[2 * row] = (unsigned)(s1 % ADLER_MOD); a.part[2 * row + 1] = (unsigned)(s2 % ADLER_MOD); }
+}
+
+// one thread: fold the row partials into Adler-32 and store it (big endian) behind the last stored block
+__global__ void png_adler_fold_kernel(PngArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  const unsigned RB = (unsigned)(3 * a.W + 1);
+  unsigned long long A = 1, B = 0;
+  for (int r = 0; r < a.H; ++r) {
+    // appending a row of RB bytes with byte sum s1 and weighted sum s2:  B += RB * A + s2,  A += s1
+    B = (B + (unsigned long long)(RB % ADLER_MOD) * A + a.part[2 * r + 1]) % ADLER_MOD;
+    A = (A + a.part[2 * r]) % ADLER_MOD;
+  }
+  put_be32(a.png + PNG_HEAD + a.Z - 4, (unsigned)((B << 16) | A));
+}
+
+// CRC-32 partials over "IDAT" + zlib stream: thread s covers segment s (segment 0 = the first `first_seg` bytes, the others
+// CRC_SEG each); raw register value after running from 0 — the partials combine linearly (crc_fold).
+__global__ __launch_bounds__(256) void png_crc_seg_kernel(PngArgs a) {
+  __shared__ unsigned tab[256];
+  tab[threadIdx.x] = crc_entry(threadIdx.x);
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  if (s >= a.nseg) return;
+  const unsigned char* base = a.png + 37;                                        // the chunk type field
+  const long long off = s == 0 ? 0 : a.first_seg + (long long)(s - 1) * CRC_SEG;
+  const long long len = s == 0 ? a.first_seg : CRC_SEG;
+  unsigned c = s == 0 ? 0xffffffffu : 0u;                                        // the initial value travels with segment 0
+  for (long long i = 0; i < len; ++i) c = tab[(c ^ base[off + i]) & 255u] ^ (c >> 8);
+  a.part[2 * a.H + s] = c;
+}
+
+__device__ unsigned gf2_mul(unsigned x, unsigned y) {      // product of two polynomials mod P, reflected bit order (zlib's multmodp)
+  unsigned m = 1u << 31, p = 0;
+  for (;;) {
+    if (x & m) {
+      p ^= y;
+      if ((x & (m - 1)) == 0) break;
+    }
+    m >>= 1;
+    y = (y & 1u) ? (y >> 1) ^ CRC_POLY : y >> 1;
+  }
+  return p;
+}
+
+// one thread: register after segment s = shift(register after segment s - 1, CRC_SEG bytes) ^ partial s, shift = multiply by
+// x^(8 CRC_SEG) mod P; final xor; store behind the zlib stream
+__global__ void png_crc_fold_kernel(PngArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned xp = 1u << 30;                                  // x^1
+  unsigned op = 1u << 31;                                  // x^0
+  for (unsigned n = 8u * CRC_SEG; n; n >>= 1) {            // op = x^(8 CRC_SEG) by square and multiply
+    if (n & 1u) op = gf2_mul(xp, op);
+    xp = gf2_mul(xp, xp);
+  }
+  unsigned c = a.part[2 * a.H];
+  for (int s = 1; s < a.nseg; ++s) c = gf2_mul(op, c) ^ a.part[2 * a.H + s];
+  put_be32(a.png + PNG_HEAD + a.Z, c ^ 0xffffffffu);
+}
+
+// base64 of the file image: one thread per 3 input bytes
+__global__ __launch_bounds__(256) void base64_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst, long long n) {
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = g * 3;
+  if (i >= n) return;
+  const unsigned b0 = src[i], b1 = i + 1 < n ? src[i + 1] : 0u, b2 = i + 2 < n ? src[i + 2] : 0u;
+  const unsigned v = (b0 << 16) | (b1 << 8) | b2;
+  auto enc = [](unsigned s) -> unsigned char {
+    return (unsigned char)(s < 26 ? 'A' + s : s < 52 ? 'a' + (s - 26) : s < 62 ? '0' + (s - 52) : s == 62 ? '+' : '/');
+  };
+  unsigned char* o = dst + g * 4;
+  o[0] = enc((v >> 18) & 63u);
+  o[1] = enc((v >> 12) & 63u);
+  o[2] = i + 1 < n ? enc((v >> 6) & 63u) : (unsigned char)'=';
+  o[3] = i + 2 < n ? enc(v & 63u) : (unsigned char)'=';
+}
+
+}  // namespace
+
+// OMNI_OP_OVERLAY (see include/omni_amd.h)
+int omni_launch_overlay(const omni_op_t* op, hipStream_t s) {
+  OvArgs a;
+  a.img = (unsigned char*)op->p[0]; a.prim = (const int*)op->p[1]; a.masks = (const unsigned char*)op->p[2];
+  a.H = op->i[0]; a.W = op->i[1]; a.n = op->i[2];
+  OMNI_REQUIRE(a.img && a.H > 0 && a.W > 0 && a.n >= 0 && (a.n == 0 || a.prim), "overlay: bad arguments");
+  if (a.n == 0) return OMNI_OK;
+  hipLaunchKernelGGL(overlay_kernel, dim3((a.W + 63) / 64, (a.H + 3) / 4), dim3(256), 0, s, a);
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+// OMNI_OP_PNG_PACK (see include/omni_amd.h)
+int omni_launch_png_pack(const omni_op_t* op, hipStream_t s) {
+  PngArgs a;
+  a.img = (const unsigned char*)op->p[0]; a.png = (unsigned char*)op->p[1]; a.part = (unsigned*)op->p[2]; a.b64 = (unsigned char*)op->p[3];
+  a.H = op->i[0]; a.W = op->i[1];
+  OMNI_REQUIRE(a.img && a.png && a.part && a.H > 0 && a.W > 0 && a.H <= 32768 && a.W <= 32768, "png_pack: bad arguments");
+  a.U = (long long)a.H * (3 * a.W + 1);
+  a.nblk = (int)((a.U + STORED_MAX - 1) / STORED_MAX);
+  a.Z = 2 + 5ll * a.nblk + a.U + 4;
+  a.total = a.Z + 57;
+  OMNI_REQUIRE(a.Z < (1ll << 31), "png_pack: image too large for one IDAT chunk");
+  const long long covered = 4 + a.Z;                      // chunk type + data
+  a.nseg = (int)((covered + CRC_SEG - 1) / CRC_SEG);
+  a.first_seg = covered - (long long)(a.nseg - 1) * CRC_SEG;
+  OMNI_REQUIRE(op->i[2] >= 2 * a.H + a.nseg, "png_pack: scratch holds %d words, needs %d", op->i[2], 2 * a.H + a.nseg);
+  OMNI_REQUIRE(op->i[3] == 0 || op->i[3] >= a.total, "png_pack: output holds %d bytes, needs %lld", op->i[3], a.total);
+  const long long quads = (a.U + 3) / 4;
+  hipLaunchKernelGGL(png_scatter_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(png_adler_rows_kernel, dim3(a.H), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_adler_fold_kernel, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_crc_seg_kernel, dim3((a.nseg + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(png_crc_fold_kernel, dim3(1), dim3(64), 0, s, a);
+  if (a.b64) {
+    const long long groups = (a.total + 2) / 3;
+    hipLaunchKernelGGL(base64_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const unsigned char*)a.png, a.b64, a.total);
+  }
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}

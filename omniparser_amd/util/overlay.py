@@ -119,6 +119,8 @@ def plan_overlay(xyxy: np.ndarray, labels: Sequence[str], image_size: Tuple[int,
 
 
 _FONT_CACHE = {}
+_MASK_CACHE = {}
+PRIM_FILL, PRIM_RING, PRIM_MASK = 0, 1, 2          # csrc/overlay_png.hip
 
 
 def _digit_font(scale: float):
@@ -133,10 +135,40 @@ def _digit_font(scale: float):
     return _FONT_CACHE[px]
 
 
-def render(scene: np.ndarray, cmds: Sequence[tuple]) -> np.ndarray:
-    """Raster the draw list onto a copy-free view of `scene` (uint8 [H,W,3], modified in place like cv2 does)."""
-    im = Image.fromarray(scene)
-    draw = ImageDraw.Draw(im)
+def text_mask(text: str, scale: float):
+    """8-bit coverage mask of `text` as Pillow's ImageDraw.text(..., anchor="ls") rasters it, and its offset from the text origin
+    (left end of the baseline): drawn once with ink 255 on a black canvas — Pillow blends out = round(in (255 - m) / 255 + ink m / 255),
+    which returns m itself there.  -> (uint8 [h,w], dx, dy); an empty mask for whitespace."""
+    key = (text, float(scale))
+    if key not in _MASK_CACHE:
+        font = _digit_font(scale)
+        px = getattr(font, "size", 12)
+        ox, oy = 2 * px, 3 * px
+        canvas = Image.new("L", (ox + px * (len(text) + 2), oy + 2 * px), 0)
+        draw = ImageDraw.Draw(canvas)
+        try:
+            draw.text((ox, oy), text, fill=255, font=font, anchor="ls")       # cv2 origin = left end of the baseline
+        except (ValueError, TypeError):
+            draw.text((ox, oy - 10), text, fill=255, font=font)
+        box = canvas.getbbox()
+        if box is None:
+            _MASK_CACHE[key] = (np.zeros((0, 0), dtype=np.uint8), 0, 0)
+        else:
+            _MASK_CACHE[key] = (np.ascontiguousarray(np.asarray(canvas.crop(box))), box[0] - ox, box[1] - oy)
+    return _MASK_CACHE[key]
+
+
+def raster_primitives(cmds: Sequence[tuple]):
+    """Draw list -> the primitive list both rasters execute IN ORDER (host: `render`; device: OMNI_OP_OVERLAY):
+    int32 [n,8] = {kind, x0, y0, x1, y1, r | g << 8 | b << 16, a, 0} + the concatenated coverage masks (uint8).
+      FILL  pixels x0..x1, y0..y1 (inclusive) take the colour;
+      RING  an outline of width a: the pixels of the rectangle that are NOT in its interior shrunk by a on every side — cv2 centres a
+            stroke of thickness t on the edge, hence the rectangle grown by t // 2 (what ImageDraw.rectangle(outline, width) draws
+            for every rectangle at least 2 a wide and high; smaller ones are simply filled);
+      MASK  x1, y1 exclusive, a = offset of its (y1-y0) x (x1-x0) mask: out = (t + (t >> 8)) >> 8, t = in (255 - m) + ink m + 128
+            (Pillow's BLEND8).
+    The colour tuple of a command is written to the frame's channels as given (the reference hands B,G,R tuples to an RGB frame)."""
+    prims, masks, off = [], [], 0
     for c in cmds:
         if c[0] == RECT:
             _, (x1, y1), (x2, y2), col, t = c
@@ -144,20 +176,69 @@ def render(scene: np.ndarray, cmds: Sequence[tuple]) -> np.ndarray:
                 x1, x2 = x2, x1
             if y2 < y1:
                 y1, y2 = y2, y1
+            ink = int(col[0]) | int(col[1]) << 8 | int(col[2]) << 16
             if t == FILLED:
-                draw.rectangle([x1, y1, x2, y2], fill=col)
-            else:                                                    # cv2 centres the stroke on the edge
+                prims.append((PRIM_FILL, x1, y1, x2, y2, ink, 0, 0))
+            else:
                 o = t // 2
-                draw.rectangle([x1 - o, y1 - o, x2 + o, y2 + o], outline=col, width=max(t, 1))
+                prims.append((PRIM_RING, x1 - o, y1 - o, x2 + o, y2 + o, ink, max(t, 1), 0))
         else:
             _, text, (x, y), col, scale, _t = c
-            font = _digit_font(scale)
-            try:
-                draw.text((x, y), text, fill=col, font=font, anchor="ls")     # cv2 origin = left end of the baseline
-            except (ValueError, TypeError):
-                draw.text((x, y - 10), text, fill=col, font=font)
-    scene[...] = np.asarray(im)
+            m, dx, dy = text_mask(text, scale)
+            if m.size == 0:
+                continue
+            ink = int(col[0]) | int(col[1]) << 8 | int(col[2]) << 16
+            prims.append((PRIM_MASK, x + dx, y + dy, x + dx + m.shape[1], y + dy + m.shape[0], ink, off, 0))
+            masks.append(m.reshape(-1))
+            off += m.size
+    P = np.asarray(prims, dtype=np.int32).reshape(-1, 8)
+    M = np.concatenate(masks) if masks else np.zeros(1, dtype=np.uint8)
+    return P, M
+
+
+def render(scene: np.ndarray, cmds: Sequence[tuple]) -> np.ndarray:
+    """Raster the draw list onto `scene` (uint8 [H,W,3], modified in place like cv2 does) on the host: the primitive semantics of
+    `raster_primitives`, executed with numpy.  The device raster (`render_device`) produces the same bytes."""
+    H, W = scene.shape[:2]
+    P, M = raster_primitives(cmds)
+    for kind, x0, y0, x1, y1, ink, a, _ in P.tolist():
+        col = np.array([ink & 255, (ink >> 8) & 255, (ink >> 16) & 255], dtype=np.uint8)
+        if kind == PRIM_MASK:
+            cx0, cy0, cx1, cy1 = max(x0, 0), max(y0, 0), min(x1, W), min(y1, H)
+            if cx0 >= cx1 or cy0 >= cy1:
+                continue
+            m = M[a:a + (y1 - y0) * (x1 - x0)].reshape(y1 - y0, x1 - x0)[cy0 - y0:cy1 - y0, cx0 - x0:cx1 - x0].astype(np.uint32)[..., None]
+            px = scene[cy0:cy1, cx0:cx1].astype(np.uint32)
+            t = px * (255 - m) + col.astype(np.uint32) * m + 128
+            scene[cy0:cy1, cx0:cx1] = np.where(m > 0, (t + (t >> 8)) >> 8, px).astype(np.uint8)
+            continue
+        cx0, cy0, cx1, cy1 = max(x0, 0), max(y0, 0), min(x1, W - 1), min(y1, H - 1)
+        if cx0 > cx1 or cy0 > cy1:
+            continue
+        if kind == PRIM_FILL or x0 + a > x1 - a or y0 + a > y1 - a:
+            scene[cy0:cy1 + 1, cx0:cx1 + 1] = col
+            continue
+        for (bx0, by0, bx1, by1) in ((x0, y0, x1, y0 + a - 1), (x0, y1 - a + 1, x1, y1), (x0, y0, x0 + a - 1, y1), (x1 - a + 1, y0, x1, y1)):
+            bx0, by0, bx1, by1 = max(bx0, 0), max(by0, 0), min(bx1, W - 1), min(by1, H - 1)
+            if bx0 <= bx1 and by0 <= by1:
+                scene[by0:by1 + 1, bx0:bx1 + 1] = col
     return scene
+
+
+def render_device(frame, cmds: Sequence[tuple], stream=None):
+    """The same raster on the MI355X (OMNI_OP_OVERLAY, csrc/overlay_png.hip): `frame` is a uint8 [H,W,3] device tensor, modified
+    in place; the primitive table and the label masks (a few KB) are uploaded per call."""
+    import torch
+    from .. import _lib as L
+    H, W = frame.shape[:2]
+    P, M = raster_primitives(cmds)
+    if P.shape[0] == 0:
+        return frame
+    assert frame.dtype == torch.uint8 and frame.is_contiguous() and frame.shape[2] == 3
+    pd = torch.from_numpy(P).to(frame.device)
+    md = torch.from_numpy(M).to(frame.device)
+    L.launch(L.make_op(L.OP_OVERLAY, L.F32, p=[frame.data_ptr(), pd.data_ptr(), md.data_ptr()], i={0: H, 1: W, 2: P.shape[0]}), stream)
+    return frame
 
 
 class BoxAnnotator:

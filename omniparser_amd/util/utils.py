@@ -19,6 +19,7 @@ import numpy as np
 import torch
 from PIL import Image
 
+from .. import _lib as L
 from ..florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS, Florence2Captioner
 from .yolov9 import YOLOv9Detector
 
@@ -384,6 +385,41 @@ def encode_png_b64(frame: np.ndarray) -> str:
     return base64.b64encode(buf.getvalue()).decode("ascii")
 
 
+def png_pack_device(frame: torch.Tensor, want_b64=True, stream=None):
+    """OMNI_OP_PNG_PACK: uint8 [H,W,3] device tensor -> (PNG file bytes, base64 ASCII) as device tensors (stored-deflate PNG:
+    include/omni_amd.h; layout restated in oracle/png_ref.py).  Five small launches, no host work."""
+    H, W = frame.shape[:2]
+    assert frame.dtype == torch.uint8 and frame.is_contiguous() and frame.shape[2] == 3
+    u = H * (3 * W + 1)
+    size = u + 5 * ((u + 65534) // 65535) + 63
+    nseg = (size - 53 + 4095) // 4096
+    png = torch.empty(size, dtype=torch.uint8, device=frame.device)
+    part = torch.empty(2 * H + nseg, dtype=torch.int32, device=frame.device)
+    b64 = torch.empty(4 * ((size + 2) // 3), dtype=torch.uint8, device=frame.device) if want_b64 else None
+    L.launch(L.make_op(L.OP_PNG_PACK, L.F32, p=[frame.data_ptr(), png.data_ptr(), part.data_ptr(), b64.data_ptr() if want_b64 else None],
+                       i={0: H, 1: W, 2: part.numel(), 3: size}), stream)
+    return png, b64
+
+
+def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, device, text_scale=0.4, text_padding=5, text_thickness=2,
+                           thickness=3):
+    """`annotate` + `encode_png_b64` with the raster, the PNG packing and the base64 on the device (OMNI_OVERLAY=device): same
+    layout (util/overlay.py::plan_overlay), same pixels as the host raster, stored-deflate PNG; the host uploads the frame and a
+    few KB of primitives and reads back ASCII.  -> (base64 str, label_coordinates)."""
+    from .overlay import BoxAnnotator, render_device
+    h, w, _ = image_np.shape
+    b = boxes * torch.Tensor([w, h, w, h])
+    cx, cy, bw, bh = b.unbind(-1)
+    xyxy = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh), -1).numpy()
+    xywh = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, bw, bh), -1).numpy()
+    ann = BoxAnnotator(text_scale=text_scale, text_padding=text_padding, text_thickness=text_thickness, thickness=thickness)
+    cmds = ann.plan(xyxy, [f"{i}" for i in range(b.shape[0])], (w, h))
+    frame = torch.from_numpy(np.array(image_np, order="C")).to(device)
+    render_device(frame, cmds)
+    _, b64 = png_pack_device(frame)
+    return b64.cpu().numpy().tobytes().decode("ascii"), {f"{phrase}": v for phrase, v in zip(phrases, xywh)}
+
+
 def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_TRESHOLD=0.01, output_coord_in_ratio=False,
                         ocr_bbox=None, text_scale=0.4, text_padding=5, draw_bbox_config=None, caption_model_processor=None,
                         ocr_text=[], use_local_semantics=True, iou_threshold=0.9, prompt=None, scale_img=False, imgsz=None,
@@ -429,8 +465,11 @@ def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_T
                          (filtered_boxes[:, 3] - filtered_boxes[:, 1]) * h), -1).numpy())} if len(filtered_boxes) else {}
     else:
         cfg = draw_bbox_config or {"text_scale": text_scale, "text_padding": text_padding}
-        frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)
-        encoded = encode_png_b64(frame)
+        if os.environ.get("OMNI_OVERLAY", "host") == "device":      # raster + PNG + base64 on the MI355X (csrc/overlay_png.hip)
+            encoded, label_coordinates = annotate_encode_device(image_np, boxes_cxcywh, phrases, model.device, **cfg)
+        else:
+            frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)
+            encoded = encode_png_b64(frame)
     if output_coord_in_ratio:
         label_coordinates = {k: [v[0] / w, v[1] / h, v[2] / w, v[3] / h] for k, v in label_coordinates.items()}
     return encoded, label_coordinates, elems

@@ -1,0 +1,77 @@
+"""The HIP kernels run FROM THEIR DEVICE SOURCES on the host emulation (tests/emu: csrc/*.hip compiled for the host, work-items as
+fibers, waves as collectives, MFMA / LDS-DMA / barriers emulated) through the same C ABI and the same checks as the `-m gpu` tests
+(tests/gpu_checks.py), at sizes a CPU finishes in seconds.  What this covers: every kernel's algorithm, indexing, barrier and
+`s_waitcnt` placement, LDS layouts, the launch geometry computed by the host side of the library.  What it cannot cover: anything
+only the hardware decides (timing, LDS capacity, hipGraph replay) — the `-m gpu` tests are the parity statement."""
+import pytest
+
+from omniparser_amd import _lib as L
+
+SMALL_CONV = [
+    # B, H, W, Cin, Cout, k, s, in_ld, in_off, out_ld, out_off, res, act
+    (1, 20, 24, 64, 64, 1, 1, 64, 0, 64, 0, False, L.ACT_SILU),
+    (2, 17, 23, 32, 96, 3, 1, 64, 32, 128, 32, True, L.ACT_SILU),
+    (1, 24, 24, 128, 256, 3, 2, 128, 0, 256, 0, False, L.ACT_SILU),
+    (1, 33, 31, 8, 40, 3, 2, 8, 0, 40, 0, False, L.ACT_NONE),          # generic (unaligned Cin) path
+    (1, 12, 12, 1024, 256, 1, 1, 1024, 0, 256, 0, False, L.ACT_GELU),  # small M, large K (split-K)
+    (1, 9, 9, 256, 1, 1, 1, 256, 0, 1, 0, False, L.ACT_NONE),          # Cout = 1 (class head)
+    (3, 12, 12, 64, 64, 3, 1, 192, 64, 64, 0, True, L.ACT_NONE),
+]
+SMALL_GEMM_DMA = [
+    # M, K, N, in_ld, in_off, out_ld, out_off, res, act, out_split
+    (300, 128, 128, 128, 0, 128, 0, False, L.ACT_NONE, False),
+    (333, 256, 384, 256, 0, 384, 0, True, L.ACT_NONE, False),
+    (260, 128, 512, 128, 0, 512, 0, False, L.ACT_GELU, True),
+    (513, 32, 256, 64, 32, 512, 256, False, L.ACT_NONE, False),
+    (5, 512, 256, 512, 0, 256, 0, False, L.ACT_NONE, False),
+]
+
+
+def test_mfma_fragment_layout(emu):
+    import gpu_checks as G
+    G.check_mfma_layout()
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_conv_igemm(emu, dtype):
+    import gpu_checks as G
+    r = G.check_conv(dtype, cases=SMALL_CONV)
+    assert r["cases"] >= 6
+
+
+def test_conv_igemm_exact_f32_path(emu, monkeypatch):
+    import gpu_checks as G
+    monkeypatch.setenv("OMNI_CONV_SPLIT", "0")
+    r = G.check_conv(L.F32, cases=SMALL_CONV)
+    assert r["cases"] >= 6 and r["worst_rel_err"] < 2e-5
+
+
+def test_gemm_dma_presplit_every_tile(emu):
+    import gpu_checks as G
+    r = G.check_gemm_dma(cases=SMALL_GEMM_DMA)
+    assert r["cases"] == 3 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_pool_resize_letterbox(emu, dtype):
+    import gpu_checks as G
+    G.check_pools(dtype)
+    G.check_letterbox(dtype, sizes=((320, 200, 160), (301, 199, 160), (160, 120, (120, 160))))
+
+
+@pytest.mark.parametrize("seed,nc,frac", [(0, 1, 0.08), (1, 3, 0.05), (2, 1, 0.6), (3, 2, 0.002)])
+def test_decode_nms_vs_oracle(emu, seed, nc, frac):
+    import gpu_checks as G
+    r = G.check_post(seed=seed, nc=nc, frac=frac)
+    assert r["nms_exact_on_gpu_candidates"] and (r["min_iou"] is None or r["min_iou"] >= 0.999)
+
+
+def test_nms_known_answers(emu):
+    import gpu_checks as G
+    G.check_nms_known_answers()
+
+
+@pytest.mark.parametrize("dtype", [L.F32, L.F16])
+def test_caption_kernels_vs_interpreter(emu, dtype):
+    import gpu_checks as G
+    G.check_caption_ops(dtype)

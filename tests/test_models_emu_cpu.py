@@ -1,0 +1,70 @@
+"""The product's DEVICE PATH — plan builders, blob importer, detector / captioner objects, ScreenParser — executed on the host
+emulation of its own kernels (tests/emu) and held to the `-m gpu` parity checks at sizes a CPU finishes in about a minute:
+quarter-width YOLOv9-E stand-in at a 320x320 network input, Florence-2-base-shaped captioner at 64x64 crops.  The checks are the
+ones the MI355X runs (tests/gpu_checks.py); what the hardware alone decides (timing, hipGraph replay, LDS capacity) stays with them."""
+import pytest
+import torch
+
+
+def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
+    """YOLOv9Detector.predict (import-verified blob -> plan -> letterbox / network / decode / NMS kernels) vs oracle.detector_ref on a
+    frame of tools/make_weights.py::EXACT_FRAMES: byte-exact input, heads within the fixed epsilon, identical candidates, NMS
+    bit-exact, final boxes one for one."""
+    import gpu_checks as G
+    from tools.make_weights import EXACT_FRAMES
+    out, det = G.check_detector(width=0.25, image_seeds=EXACT_FRAMES[(0.25, 320)][:1], imgsz=320, iw=640, ih=480)
+    assert det.import_error is not None and det.import_error < 1e-3           # load-time proof of the imported blob ran on the kernels
+    G.assert_detector_frame(out["images"][0], exact=True)
+    assert out["ops"] > 250
+
+
+def test_captioner_token_exact_r64(emu):
+    """Florence2Captioner.generate (DaViT tower, projector, BART encoder / decoder with KV cache, greedy loop: every captioner kernel)
+    vs transformers on the CPU: same ids, logit error below the smallest arg-max margin."""
+    import gpu_checks as G
+    out, _ = G.check_captioner(R=64, n=1)
+    assert out["ids_equal"], out
+    assert out["feat_rel_err"] < 1e-4 and out["enc_rel_err"] < 1e-4
+    assert out["max_logit_err"] < out["min_top1_top2_margin"], out
+
+
+def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
+    """ScreenParser.parse_batch with the detect -> caption hand-off on the device (OMNI_DEVICE_GLUE=1: eager detector plan, glue kernel,
+    crop rectangles that never visit the host, packed caption micro-batches) against the default host hand-off of the same frames:
+    identical element tables and crop rectangles; captions present on every icon without OCR text."""
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")                 # proven in the detector test above
+    det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
+    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    frames = [torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in (0, 2)]
+    ocr = [synthetic_ocr(0, 640, 480, 12), ([], [])]                                  # second frame without OCR
+    kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=4)
+    monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
+    sp = ScreenParser(det, cap, **kw)
+    assert sp.device_glue
+    elems, ids = sp.parse_batch(frames, ocr, return_ids=True)
+    crops = sp.last_crops
+    monkeypatch.setenv("OMNI_DEVICE_GLUE", "0")
+    sp0 = ScreenParser(det, cap, **kw)
+    assert not sp0.device_glue
+    boxes = sp0.detect(frames)
+    n_crops = 0
+    for f in range(2):
+        el, cr = sp0.glue(boxes[f], 640, 480, ocr[f][1], ocr[f][0])
+        assert cr == crops[f]
+        assert len(el) == len(elems[f])
+        k = 0
+        for a, b in zip(elems[f], el):
+            assert (a["type"], a["bbox"], a["source"], a["interactivity"]) == (b["type"], b["bbox"], b["source"], b["interactivity"])
+            if b["content"] is None:
+                assert isinstance(a["content"], str) and len(ids[f][k]) > 2      # captioned from the device-side rectangles
+                k += 1
+            else:
+                assert a["content"] == b["content"]
+        assert k == len(cr)
+        n_crops += k
+    assert n_crops >= 6          # more than one packed micro-batch of 4, spanning both frames

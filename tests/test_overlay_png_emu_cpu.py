@@ -1,0 +1,75 @@
+"""Overlay raster and PNG / base64 packing of csrc/overlay_png.hip, run from their device sources on the host emulation (tests/emu)
+and compared with (a) the host raster `overlay.render`, itself compared with Pillow's ImageDraw here, (b) oracle/png_ref.py (layout
+restatement on Python's zlib checksums), byte for byte, (c) Pillow's PNG reader.  The `-m gpu` twin: tests/test_gpu_h_overlay_png.py."""
+import base64
+import io
+
+import numpy as np
+import pytest
+import torch
+from PIL import Image, ImageDraw
+
+from omniparser_amd.util import overlay as OV
+
+
+def _scene(seed, W, H, K):
+    rng = np.random.default_rng(seed)
+    frame = rng.integers(0, 256, (H, W, 3), dtype=np.uint8)
+    x1 = rng.integers(-10, max(W - 20, 1), K); y1 = rng.integers(-10, max(H - 20, 1), K)
+    bw = rng.integers(1, 90, K); bh = rng.integers(1, 60, K)
+    bw[:3] = (1, 2, 5); bh[:3] = (1, 3, 2)                          # degenerate boxes: thinner than twice the stroke
+    xyxy = np.stack([x1, y1, x1 + bw, y1 + bh], 1).astype(np.float64)
+    cmds = OV.plan_overlay(xyxy, [str(i) for i in range(K)], (W, H), text_scale=0.4, text_padding=5)
+    return frame, cmds
+
+
+def test_host_raster_is_pillows_for_well_formed_primitives():
+    """`render` (numpy execution of the primitive list) against ImageDraw itself: filled tags and label text everywhere, outlines
+    wherever the rectangle is at least twice the stroke wide and high (Pillow's outline of smaller rectangles leaks outside them;
+    ours fills them)."""
+    frame, cmds = _scene(0, 320, 200, 40)
+    ours = OV.render(frame.copy(), cmds)
+    im = Image.fromarray(frame.copy())
+    draw = ImageDraw.Draw(im)
+    skipped = 0
+    for c in cmds:
+        if c[0] == OV.RECT:
+            _, (x1, y1), (x2, y2), col, t = c
+            if t == OV.FILLED:
+                draw.rectangle([x1, y1, x2, y2], fill=col)
+            else:
+                o = t // 2
+                if x2 - x1 + 2 * o + 1 < 2 * t or y2 - y1 + 2 * o + 1 < 2 * t:
+                    skipped += 1
+                    draw.rectangle([x1 - o, y1 - o, x2 + o, y2 + o], fill=col)
+                else:
+                    draw.rectangle([x1 - o, y1 - o, x2 + o, y2 + o], outline=col, width=t)
+        else:
+            _, text, (x, y), col, scale, _t = c
+            draw.text((x, y), text, fill=col, font=OV._digit_font(scale), anchor="ls")
+    assert skipped >= 2
+    assert np.array_equal(ours, np.asarray(im))
+
+
+@pytest.mark.parametrize("seed,W,H,K", [(1, 320, 200, 40), (2, 333, 97, 300), (3, 70, 30, 5)])
+def test_device_raster_equals_host_raster(emu, seed, W, H, K):
+    frame, cmds = _scene(seed, W, H, K)
+    want = OV.render(frame.copy(), cmds)
+    got = OV.render_device(torch.from_numpy(frame.copy()), cmds).numpy()
+    assert np.array_equal(got, want)
+    assert not np.array_equal(got, frame)
+
+
+@pytest.mark.parametrize("H,W", [(37, 53), (300, 200), (1, 1), (130, 1000)])
+def test_device_png_is_the_oracle_layout_and_decodes(emu, H, W):
+    """file bytes == oracle/png_ref.py (so the device CRC-32 / Adler-32 equal zlib's), base64 == base64.b64encode, and Pillow reads
+    the frame back.  (130 x 1000: six stored blocks, 96 CRC segments with a short first one.)"""
+    from oracle import png_ref as PR
+    from omniparser_amd.util.utils import png_pack_device
+    frame = np.random.default_rng(H * W).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    png, b64 = png_pack_device(torch.from_numpy(frame))
+    data = png.numpy().tobytes()
+    assert len(data) == PR.stored_png_size(H, W)
+    assert data == PR.stored_png(frame)
+    assert b64.numpy().tobytes() == base64.b64encode(data)
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)

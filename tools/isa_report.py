@@ -38,11 +38,12 @@ def loop_mix(body):
         m = re.search(r"s_c?branch\w*\s+(\.LBB\d+_\d+)", l)
         if m and m.group(1) in labels and labels[m.group(1)] < i:
             loops.append((labels[m.group(1)], i))
-    best, best_mfma = None, -1
-    for a, b in loops:                      # the loop with the most MFMAs (outermost span wins ties)
-        n = sum(1 for l in body[a:b + 1] if l.strip().startswith("v_mfma"))
-        if n > best_mfma or (n == best_mfma and best and (b - a) > (best[1] - best[0])):
-            best, best_mfma = (a, b), n
+    # the hot loop = an INNERMOST loop holding MFMAs (no other MFMA loop nested inside it); the one with the most MFMAs if several
+    def n_mfma(a, b):
+        return sum(1 for l in body[a:b + 1] if l.strip().startswith("v_mfma"))
+    with_mfma = [(a, b) for a, b in loops if n_mfma(a, b) > 0]
+    inner = [(a, b) for a, b in with_mfma if not any((c, d) != (a, b) and a <= c and d <= b for c, d in with_mfma)]
+    best = max(inner, key=lambda ab: n_mfma(*ab)) if inner else (max(loops, key=lambda ab: ab[1] - ab[0]) if loops else None)
     if best is None:
         return None
     c = Counter()
