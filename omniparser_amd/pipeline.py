@@ -31,7 +31,7 @@ class _GlueState:
     """Device side of the detect -> caption hand-off for one detector plan (batch B): fixed buffers + one small plan of B
     OMNI_OP_GLUE ops replayed right behind the detector graph on the detector's stream."""
 
-    def __init__(self, dp, det, iw, ih, thr):
+    def __init__(self, dp, det, iw, ih, thr, fused=False):
         dev, B, md = det.device, dp.batch, dp.out_boxes.shape[1]
         self.B, self.md = B, md
         with torch.cuda.stream(det.stream):
@@ -54,6 +54,17 @@ class _GlueState:
                for b in range(B)]
         self.plan = L.Plan(ops)        # run eagerly (B one-workgroup launches, ~5 us each), like the detector plan on this path:
         det.stream.synchronize()       # see detect_glue and profiles/r2_notes.md
+        # OMNI_DEVICE_GLUE=2 (untimed, next GPU session): detector ops AND hand-off ops in ONE plan, captured as ONE hipGraph — the
+        # stream then sees what the default path sees (uploads, graph launch, read-back) and no kernel launch between two replays,
+        # the arrangement that stalled
+        self.fused = None
+        if fused:
+            self.fused = L.Plan(list(dp.plan.ops) + ops)
+            if det.use_graph:
+                self.fused.run(det.stream)
+                det.stream.synchronize()
+                self.fused.capture(det.stream)
+                det.stream.synchronize()
 
 
 class ScreenParser:
@@ -64,7 +75,8 @@ class ScreenParser:
         self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
         # detect -> caption hand-off: host twin (`glue`, numpy) by default; OMNI_DEVICE_GLUE=1 = on the device (csrc/glue_ops.hip)
         import os
-        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") == "1"
+        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") in ("1", "2")
+        self.fused_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") == "2"
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
@@ -178,11 +190,11 @@ class ScreenParser:
         ih, iw = frames[0].shape[:2]
         det = self.det
         dp = det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
-        key = ("glue", float(self.iou_threshold))
+        key = ("glue", float(self.iou_threshold), self.fused_glue)
         gs = getattr(dp, "_glue", {}).get(key)
         if gs is None:
             with torch.cuda.device(det.device):
-                gs = _GlueState(dp, det, iw, ih, self.iou_threshold)
+                gs = _GlueState(dp, det, iw, ih, self.iou_threshold, fused=self.fused_glue)
             dp._glue = {**getattr(dp, "_glue", {}), key: gs}
         ocr_els = []
         gs.h_meta.zero_()
@@ -211,8 +223,11 @@ class ScreenParser:
             gs.meta.copy_(gs.h_meta)
             # the detector plan runs EAGERLY on this path: the second replay of its hipGraph never completed when the hand-off
             # kernels followed it on the same stream (ROCm 7.2, profiles/r2_notes.md); eager launches of the same ops are fine
-            dp.plan.run(det.stream)
-            gs.plan.run(det.stream)
+            if gs.fused is not None:
+                gs.fused.replay(det.stream)
+            else:
+                dp.plan.run(det.stream)
+                gs.plan.run(det.stream)
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
         return dp, gs, ocr_els, counts
 
