@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.ab_*`, `extra.annotate_tail`)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -217,6 +218,18 @@ def main():
         guarded("roofline", lambda: roofline(args, det, parser, dp_obj, crop_counts, B))
         if world == 1 and not args.no_extra:
             guarded("extra", lambda: extras(args, det, parser, frames, ocr, dev))
+        if world == 1 and not args.no_extra and not args.no_ab and args.mode == "e2e" and isinstance(out.get("extra"), dict):
+            # opt-in kernels that have never been timed, each in its OWN process with a hard limit (a fault or a stall there
+            # cannot take this line with it): the format-B producers, and the annotate / PNG tail on the device
+            out["extra"]["ab_format_b_producers"] = child_json(
+                [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                {"OMNI_ATTN_SPLIT_OUT": "1", "OMNI_FUSE_DWLN": "1"}, 150,
+                keep=("value", "ms_per_step", ("roofline", "non_gemm_share"), ("roofline", "gemm_ms_per_step"),
+                      ("roofline", "kernel_family_ms_per_step"), ("roofline", "crops_per_step")))
+            note("ab_format_b_producers done")
+            out["extra"]["annotate_tail"] = child_json([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
+                                                                                     "annotate_bench.py")], {}, 120)
+            note("annotate_tail done")
         if world == 1 and not args.no_cpu_baseline:
             guarded("cpu_baseline", lambda: cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0)))
         faulthandler.cancel_dump_traceback_later()
@@ -226,9 +239,41 @@ def main():
         dist.destroy_process_group()
 
 
+def child_json(cmd, env, limit_s, keep=None):
+    """run `cmd` with `env` added, at most `limit_s` seconds, and return the JSON object of its last stdout line (or what went wrong)."""
+    import subprocess
+    e = dict(os.environ, **env)
+    e.pop("OMNI_BENCH_WATCHDOG", None)
+    try:
+        r = subprocess.run(cmd, env=e, capture_output=True, text=True, timeout=limit_s)
+    except subprocess.TimeoutExpired:
+        return {"env": env, "error": f"no result within {limit_s} s"}
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    if r.returncode != 0 or not lines:
+        return {"env": env, "error": f"exit {r.returncode}: {r.stderr.strip()[-300:]}"}
+    try:
+        d = json.loads(lines[-1])
+    except ValueError as ex:
+        return {"env": env, "error": f"unparsable line: {ex}"}
+    if keep:
+        sel = {}
+        for k in keep:
+            if isinstance(k, tuple):
+                v = d
+                for part in k:
+                    v = v.get(part) if isinstance(v, dict) else None
+                sel[".".join(k)] = v
+            else:
+                sel[k] = d.get(k)
+        d = sel
+    d["env"] = env
+    return d
+
+
 KIND_NAMES = {1: "gemm (conv / linear)", 2: "avgpool", 3: "maxpool", 4: "resize_nearest", 5: "letterbox", 6: "detect_decode", 7: "nms",
               8: "dwconv3", 9: "layernorm", 10: "attention (window / mha)", 11: "channel_attention", 12: "proj_prep", 13: "assemble",
-              14: "embed_step", 15: "attn_decode", 16: "greedy_step", 17: "crop_resize", 18: "dwconv3+ln", 19: "split_convert"}
+              14: "embed_step", 15: "attn_decode", 16: "greedy_step", 17: "crop_resize", 18: "dwconv3+ln", 19: "split_convert", 20: "hand-off",
+              21: "overlay", 22: "png_pack"}
 
 
 def profile_plan(plan, stream, repeat=1):

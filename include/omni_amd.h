@@ -178,6 +178,16 @@ enum {
    *  p0 frame u8[H,W,3] p1 out PNG bytes p2 scratch u32[2 H + ceil((size - 53) / 4096)] p3 out base64 ASCII (4 ceil(size / 3)
    *  bytes) or NULL.  i0 H i1 W i2 scratch words i3 capacity of p1 in bytes (0 = not checked) */
   OMNI_OP_PNG_PACK = 22,
+  /* Same file as OMNI_OP_PNG_PACK with a COMPRESSED zlib stream (size known only on the device): scanlines Up-filtered (row 0:
+   * None), the filtered stream cut into 4096-byte units, each unit ONE fixed-Huffman deflate block of literals and run matches
+   * (distance 1 / 3) + an empty stored block (byte alignment), or one stored block when that is not smaller — one GPU thread per
+   * unit, then offsets, gather, Adler-32, CRC-32, base64 as above.  Worst case = the stored size with 4096-byte blocks.
+   *  p0 frame u8[H,W,3] p1 out PNG bytes (capacity i2) p2 scratch: filtered stream u8[H (3 W + 1)] p3 scratch: unit slots
+   *  u8[units * 4640] p4 out/scratch meta u32[i3]: {zlib stream bytes, FILE BYTES, base64 bytes, CRC segments, unit sizes..., unit
+   *  offsets...} p5 scratch u32[i4] (Adler / CRC partials) p6 out base64 ASCII (4 ceil(capacity / 3) bytes) or NULL
+   *  i0 H i1 W i2 capacity of p1 (>= H (3 W + 1) + 5 units + 63) i3 meta words (>= 4 + 2 units) i4 scratch words
+   *  (>= 2 H + ceil((capacity - 53) / 4096)) */
+  OMNI_OP_PNG_DEFLATE = 23,
   OMNI_OP__COUNT
 };
 

@@ -38,6 +38,7 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
     case OMNI_OP_GLUE: return omni_launch_glue(op, s);
     case OMNI_OP_OVERLAY: return omni_launch_overlay(op, s);
     case OMNI_OP_PNG_PACK: return omni_launch_png_pack(op, s);
+    case OMNI_OP_PNG_DEFLATE: return omni_launch_png_deflate(op, s);
     case OMNI_OP_AVGPOOL2: return omni_launch_avgpool2(op, s);
     case OMNI_OP_MAXPOOL: return omni_launch_maxpool(op, s);
     case OMNI_OP_RESIZE_NEAREST: return omni_launch_resize_nearest(op, s);

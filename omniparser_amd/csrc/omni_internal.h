@@ -100,3 +100,4 @@ int omni_launch_misc(const omni_op_t* op, hipStream_t s);
 int omni_launch_glue(const omni_op_t* op, hipStream_t s);
 int omni_launch_overlay(const omni_op_t* op, hipStream_t s);
 int omni_launch_png_pack(const omni_op_t* op, hipStream_t s);
+int omni_launch_png_deflate(const omni_op_t* op, hipStream_t s);

@@ -244,6 +244,226 @@ __global__ __launch_bounds__(256) void base64_kernel(const unsigned char* __rest
   o[3] = i + 2 < n ? enc(v & 63u) : (unsigned char)'=';
 }
 
+// ------------------------------------------------------------------------------------ PNG with a compressed stream
+// (layout and rationale: oracle/png_ref.py — Up-filtered scanlines cut into 4096-byte units, one fixed-Huffman deflate block of
+// literals + distance-1 / distance-3 run matches per unit, closed by an empty stored block so that units concatenate bytewise)
+constexpr int UNIT = 4096;
+constexpr int SLOT = 4640;               // >= UNIT * 9 / 8 + header / trailer bytes, 16-byte multiple
+enum { M_Z = 0, M_TOTAL = 1, M_B64 = 2, M_NSEG = 3, M_SIZES = 4 };
+
+struct DefArgs {
+  const unsigned char* img; unsigned char* png; unsigned char* filt; unsigned char* slots; unsigned* meta; unsigned* part; unsigned char* b64;
+  int H, W, nunits;
+  long long U;
+};
+
+// filtered scanline stream: row 0 filter 0 (None), other rows filter 2 (Up).  One thread per 4 stream bytes.
+__global__ __launch_bounds__(256) void png_filter_kernel(DefArgs a) {
+  const long long t = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const int RB = 3 * a.W + 1;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    const long long u = t * 4 + e;
+    if (u >= a.U) break;
+    const long long row = u / RB;
+    const int col = (int)(u - row * RB);
+    unsigned v;
+    if (col == 0) v = row ? 2u : 0u;
+    else {
+      const unsigned char* p = a.img + row * (long long)(3 * a.W) + col - 1;
+      v = row ? (unsigned)p[0] - (unsigned)p[-3 * a.W] : (unsigned)p[0];
+    }
+    a.filt[u] = (unsigned char)v;
+  }
+}
+
+struct BitWriter {
+  unsigned char* out;
+  unsigned long long acc;
+  int nb, pos;
+  __device__ __forceinline__ void put(unsigned v, int n) {        // LSB first
+    acc |= (unsigned long long)v << nb;
+    nb += n;
+    while (nb >= 8) { out[pos++] = (unsigned char)(acc & 255u); acc >>= 8; nb -= 8; }
+  }
+  __device__ __forceinline__ void put_code(unsigned code, int n) {  // Huffman codes are packed starting from their MSB
+    unsigned r = 0;
+    for (int k = 0; k < n; ++k) { r = (r << 1) | (code & 1u); code >>= 1; }
+    put(r, n);
+  }
+  __device__ __forceinline__ void lit_len(unsigned sym) {            // fixed code of RFC 1951 3.2.6
+    if (sym < 144u) put_code(0x30u + sym, 8);
+    else if (sym < 256u) put_code(0x190u + sym - 144u, 9);
+    else if (sym < 280u) put_code(sym - 256u, 7);
+    else put_code(0xC0u + sym - 280u, 8);
+  }
+  __device__ __forceinline__ void match(int len, int dist) {
+    if (len <= 10) lit_len(257u + (unsigned)(len - 3));
+    else if (len == 258) lit_len(285u);
+    else {
+      const unsigned m = (unsigned)(len - 3);
+      const int e = 31 - __builtin_clz(m) - 2;
+      const unsigned idx = (m >> e) - 4u;
+      lit_len(257u + 4u + 4u * (unsigned)e + idx);
+      put(m - ((idx + 4u) << e), e);
+    }
+    put_code(dist == 1 ? 0u : 2u, 5);
+  }
+};
+
+// one thread per unit: greedy run matching (distance 1 = byte runs, distance 3 = pixel runs; matches may reach back across the unit
+// start — the decoder's window holds those bytes), fixed-Huffman block + empty stored block; stored block if that is not smaller.
+__global__ __launch_bounds__(64) void png_deflate_units_kernel(DefArgs a) {
+  const int u = blockIdx.x * blockDim.x + threadIdx.x;
+  if (u >= a.nunits) return;
+  const long long start = (long long)u * UNIT;
+  const long long end = min(start + UNIT, a.U);
+  const bool final_unit = u == a.nunits - 1;
+  const unsigned char* f = a.filt;
+  BitWriter b;
+  b.out = a.slots + (long long)u * SLOT; b.acc = 0; b.nb = 0; b.pos = 0;
+  b.put(0u, 1); b.put(1u, 2);
+  long long i = start;
+  while (i < end) {
+    int l1 = 0, l3 = 0;
+    if (i >= 1) { const unsigned char p = f[i - 1]; while (i + l1 < end && l1 < 258 && f[i + l1] == p) ++l1; }
+    if (i >= 3) { while (i + l3 < end && l3 < 258 && f[i + l3] == f[i + l3 - 3]) ++l3; }
+    const int best = l3 > l1 ? l3 : l1;
+    if (best >= 3) { b.match(best, l3 > l1 ? 3 : 1); i += best; }
+    else { b.lit_len(f[i]); ++i; }
+  }
+  b.lit_len(256u);
+  b.put(final_unit ? 1u : 0u, 1); b.put(0u, 2);
+  if (b.nb) { b.out[b.pos++] = (unsigned char)(b.acc & 255u); b.acc = 0; b.nb = 0; }
+  b.out[b.pos++] = 0; b.out[b.pos++] = 0; b.out[b.pos++] = 0xff; b.out[b.pos++] = 0xff;
+  const int n = (int)(end - start);
+  if (b.pos >= n + 5) {
+    unsigned char* o = b.out;
+    o[0] = final_unit ? 1 : 0;
+    o[1] = (unsigned char)(n & 255); o[2] = (unsigned char)(n >> 8);
+    o[3] = (unsigned char)(~n & 255); o[4] = (unsigned char)((~n >> 8) & 255);
+    for (int k = 0; k < n; ++k) o[5 + k] = f[start + k];
+    b.pos = n + 5;
+  }
+  a.meta[M_SIZES + u] = (unsigned)b.pos;
+}
+
+// one thread: unit offsets (exclusive scan), stream / file sizes, constant header bytes
+__global__ void png_layout_kernel(DefArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned off = 0;
+  for (int u = 0; u < a.nunits; ++u) {
+    const unsigned sz = a.meta[M_SIZES + u];
+    a.meta[M_SIZES + a.nunits + u] = off;
+    off += sz;
+  }
+  const unsigned Z = 2u + off + 4u;
+  a.meta[M_Z] = Z;
+  a.meta[M_TOTAL] = Z + 57u;
+  a.meta[M_B64] = 4u * ((Z + 57u + 2u) / 3u);
+  a.meta[M_NSEG] = (4u + Z + CRC_SEG - 1u) / CRC_SEG;
+  const unsigned char sig[8] = {0x89, 'P', 'N', 'G', 0x0d, 0x0a, 0x1a, 0x0a};
+  for (int k = 0; k < 8; ++k) a.png[k] = sig[k];
+  unsigned char* ih = a.png + 8;
+  put_be32(ih, 13); ih[4] = 'I'; ih[5] = 'H'; ih[6] = 'D'; ih[7] = 'R';
+  put_be32(ih + 8, (unsigned)a.W); put_be32(ih + 12, (unsigned)a.H);
+  ih[16] = 8; ih[17] = 2; ih[18] = 0; ih[19] = 0; ih[20] = 0;
+  unsigned c = 0xffffffffu;
+  for (int k = 4; k < 21; ++k) c = crc_entry((c ^ ih[k]) & 255u) ^ (c >> 8);
+  put_be32(ih + 21, c ^ 0xffffffffu);
+  unsigned char* id = a.png + 33;
+  put_be32(id, Z); id[4] = 'I'; id[5] = 'D'; id[6] = 'A'; id[7] = 'T';
+  a.png[PNG_HEAD] = 0x78; a.png[PNG_HEAD + 1] = 0x01;
+  unsigned char* ie = a.png + PNG_HEAD + Z + 4;
+  const unsigned char iend[12] = {0, 0, 0, 0, 'I', 'E', 'N', 'D', 0xae, 0x42, 0x60, 0x82};
+  for (int k = 0; k < 12; ++k) ie[k] = iend[k];
+}
+
+// one wave per unit: slot -> its place in the stream
+__global__ __launch_bounds__(64) void png_gather_kernel(DefArgs a) {
+  const int u = blockIdx.x;
+  const unsigned sz = a.meta[M_SIZES + u], off = a.meta[M_SIZES + a.nunits + u];
+  const unsigned char* src = a.slots + (long long)u * SLOT;
+  unsigned char* dst = a.png + PNG_HEAD + 2 + off;
+  for (unsigned k = threadIdx.x; k < sz; k += 64) dst[k] = src[k];
+}
+
+// Adler-32 partials over the rows of the FILTERED stream (filter byte included), same form as png_adler_rows_kernel
+__global__ __launch_bounds__(64) void png_adler_filt_kernel(DefArgs a) {
+  const int row = blockIdx.x, lane = threadIdx.x;
+  const int RB = 3 * a.W + 1;
+  const unsigned char* src = a.filt + (long long)row * RB;
+  unsigned long long s1 = 0, s2 = 0;
+  for (int i = lane; i < RB; i += 64) {
+    const unsigned v = src[i];
+    s1 += v;
+    s2 += (unsigned long long)(RB - i) * v;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) { s1 += __shfl_xor(s1, o); s2 += __shfl_xor(s2, o); }
+  if (lane == 0) { a.part[2 * row] = (unsigned)(s1 % ADLER_MOD); a.part[2 * row + 1] = (unsigned)(s2 % ADLER_MOD); }
+}
+
+// the fold / CRC kernels of the stored variant, with the stream length read from the device
+__global__ void png_def_adler_fold_kernel(DefArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  const unsigned RB = (unsigned)(3 * a.W + 1);
+  unsigned long long A = 1, B = 0;
+  for (int r = 0; r < a.H; ++r) {
+    B = (B + (unsigned long long)(RB % ADLER_MOD) * A + a.part[2 * r + 1]) % ADLER_MOD;
+    A = (A + a.part[2 * r]) % ADLER_MOD;
+  }
+  put_be32(a.png + PNG_HEAD + a.meta[M_Z] - 4, (unsigned)((B << 16) | A));
+}
+
+__global__ __launch_bounds__(256) void png_def_crc_seg_kernel(DefArgs a) {
+  __shared__ unsigned tab[256];
+  tab[threadIdx.x] = crc_entry(threadIdx.x);
+  __syncthreads();
+  const int s = blockIdx.x * blockDim.x + threadIdx.x;
+  const int nseg = (int)a.meta[M_NSEG];
+  if (s >= nseg) return;
+  const long long covered = 4ll + a.meta[M_Z];
+  const long long first = covered - (long long)(nseg - 1) * CRC_SEG;
+  const unsigned char* base = a.png + 37;
+  const long long off = s == 0 ? 0 : first + (long long)(s - 1) * CRC_SEG;
+  const long long len = s == 0 ? first : CRC_SEG;
+  unsigned c = s == 0 ? 0xffffffffu : 0u;
+  for (long long i = 0; i < len; ++i) c = tab[(c ^ base[off + i]) & 255u] ^ (c >> 8);
+  a.part[2 * a.H + s] = c;
+}
+
+__global__ void png_def_crc_fold_kernel(DefArgs a) {
+  if (threadIdx.x || blockIdx.x) return;
+  unsigned xp = 1u << 30, op = 1u << 31;
+  for (unsigned n = 8u * CRC_SEG; n; n >>= 1) {
+    if (n & 1u) op = gf2_mul(xp, op);
+    xp = gf2_mul(xp, xp);
+  }
+  const int nseg = (int)a.meta[M_NSEG];
+  unsigned c = a.part[2 * a.H];
+  for (int s = 1; s < nseg; ++s) c = gf2_mul(op, c) ^ a.part[2 * a.H + s];
+  put_be32(a.png + PNG_HEAD + a.meta[M_Z], c ^ 0xffffffffu);
+}
+
+__global__ __launch_bounds__(256) void base64_dyn_kernel(const unsigned char* __restrict__ src, unsigned char* __restrict__ dst,
+                                                         const unsigned* __restrict__ meta) {
+  const long long n = meta[M_TOTAL];
+  const long long g = (long long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long long i = g * 3;
+  if (i >= n) return;
+  const unsigned b0 = src[i], b1 = i + 1 < n ? src[i + 1] : 0u, b2 = i + 2 < n ? src[i + 2] : 0u;
+  const unsigned v = (b0 << 16) | (b1 << 8) | b2;
+  auto enc = [](unsigned s) -> unsigned char {
+    return (unsigned char)(s < 26 ? 'A' + s : s < 52 ? 'a' + (s - 26) : s < 62 ? '0' + (s - 52) : s == 62 ? '+' : '/');
+  };
+  unsigned char* o = dst + g * 4;
+  o[0] = enc((v >> 18) & 63u);
+  o[1] = enc((v >> 12) & 63u);
+  o[2] = i + 1 < n ? enc((v >> 6) & 63u) : (unsigned char)'=';
+  o[3] = i + 2 < n ? enc(v & 63u) : (unsigned char)'=';
+}
+
 }  // namespace
 
 // OMNI_OP_OVERLAY (see include/omni_amd.h)
@@ -283,6 +503,40 @@ int omni_launch_png_pack(const omni_op_t* op, hipStream_t s) {
   if (a.b64) {
     const long long groups = (a.total + 2) / 3;
     hipLaunchKernelGGL(base64_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const unsigned char*)a.png, a.b64, a.total);
+  }
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+
+// OMNI_OP_PNG_DEFLATE (see include/omni_amd.h)
+int omni_launch_png_deflate(const omni_op_t* op, hipStream_t s) {
+  DefArgs a;
+  a.img = (const unsigned char*)op->p[0]; a.png = (unsigned char*)op->p[1]; a.filt = (unsigned char*)op->p[2];
+  a.slots = (unsigned char*)op->p[3]; a.meta = (unsigned*)op->p[4]; a.part = (unsigned*)op->p[5]; a.b64 = (unsigned char*)op->p[6];
+  a.H = op->i[0]; a.W = op->i[1];
+  OMNI_REQUIRE(a.img && a.png && a.filt && a.slots && a.meta && a.part && a.H > 0 && a.W > 0 && a.H <= 32768 && a.W <= 32768,
+               "png_deflate: bad arguments");
+  a.U = (long long)a.H * (3 * a.W + 1);
+  a.nunits = (int)((a.U + UNIT - 1) / UNIT);
+  const long long zmax = 2 + a.U + 5ll * a.nunits + 4;
+  OMNI_REQUIRE(zmax < (1ll << 31), "png_deflate: image too large for one IDAT chunk");
+  const int nseg_max = (int)((4 + zmax + CRC_SEG - 1) / CRC_SEG);
+  OMNI_REQUIRE(op->i[2] >= zmax + 57, "png_deflate: output holds %d bytes, worst case is %lld", op->i[2], zmax + 57);
+  OMNI_REQUIRE(op->i[3] >= M_SIZES + 2 * a.nunits, "png_deflate: meta holds %d words, needs %d", op->i[3], M_SIZES + 2 * a.nunits);
+  OMNI_REQUIRE(op->i[4] >= 2 * a.H + nseg_max, "png_deflate: scratch holds %d words, needs %d", op->i[4], 2 * a.H + nseg_max);
+  const long long quads = (a.U + 3) / 4;
+  hipLaunchKernelGGL(png_filter_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(png_deflate_units_kernel, dim3((a.nunits + 63) / 64), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_layout_kernel, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_gather_kernel, dim3(a.nunits), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_adler_filt_kernel, dim3(a.H), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_def_adler_fold_kernel, dim3(1), dim3(64), 0, s, a);
+  hipLaunchKernelGGL(png_def_crc_seg_kernel, dim3((nseg_max + 255) / 256), dim3(256), 0, s, a);
+  hipLaunchKernelGGL(png_def_crc_fold_kernel, dim3(1), dim3(64), 0, s, a);
+  if (a.b64) {
+    const long long groups = (zmax + 57 + 2) / 3;
+    hipLaunchKernelGGL(base64_dyn_kernel, dim3((unsigned)((groups + 255) / 256)), dim3(256), 0, s, (const unsigned char*)a.png, a.b64,
+                       (const unsigned*)a.meta);
   }
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;

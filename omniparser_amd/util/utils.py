@@ -401,6 +401,30 @@ def png_pack_device(frame: torch.Tensor, want_b64=True, stream=None):
     return png, b64
 
 
+def png_deflate_device(frame: torch.Tensor, want_b64=True, stream=None):
+    """OMNI_OP_PNG_DEFLATE: like png_pack_device with a compressed stream (Up filter + fixed-Huffman run-length deflate, one GPU
+    thread per 4096-byte unit; oracle/png_ref.py::deflate_png is the byte-exact restatement).  The size is decided on the device:
+    -> (PNG buffer, base64 buffer, meta) device tensors; meta[1] = file bytes, meta[2] = base64 bytes."""
+    H, W = frame.shape[:2]
+    assert frame.dtype == torch.uint8 and frame.is_contiguous() and frame.shape[2] == 3
+    dev = frame.device
+    u = H * (3 * W + 1)
+    units = (u + 4095) // 4096
+    cap = u + 5 * units + 63
+    nseg = (cap - 53 + 4095) // 4096
+    png = torch.empty(cap, dtype=torch.uint8, device=dev)
+    filt = torch.empty(u, dtype=torch.uint8, device=dev)
+    slots = torch.empty(units * 4640, dtype=torch.uint8, device=dev)
+    meta = torch.zeros(4 + 2 * units, dtype=torch.int32, device=dev)
+    part = torch.empty(2 * H + nseg, dtype=torch.int32, device=dev)
+    b64 = torch.empty(4 * ((cap + 2) // 3), dtype=torch.uint8, device=dev) if want_b64 else None
+    L.launch(L.make_op(L.OP_PNG_DEFLATE, L.F32,
+                       p=[frame.data_ptr(), png.data_ptr(), filt.data_ptr(), slots.data_ptr(), meta.data_ptr(), part.data_ptr(),
+                          b64.data_ptr() if want_b64 else None],
+                       i={0: H, 1: W, 2: cap, 3: meta.numel(), 4: part.numel()}), stream)
+    return png, b64, meta
+
+
 def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, device, text_scale=0.4, text_padding=5, text_thickness=2,
                            thickness=3):
     """`annotate` + `encode_png_b64` with the raster, the PNG packing and the base64 on the device (OMNI_OVERLAY=device): same
@@ -416,8 +440,14 @@ def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, d
     cmds = ann.plan(xyxy, [f"{i}" for i in range(b.shape[0])], (w, h))
     frame = torch.from_numpy(np.array(image_np, order="C")).to(device)
     render_device(frame, cmds)
-    _, b64 = png_pack_device(frame)
-    return b64.cpu().numpy().tobytes().decode("ascii"), {f"{phrase}": v for phrase, v in zip(phrases, xywh)}
+    if os.environ.get("OMNI_PNG_DEVICE", "deflate") == "stored":
+        _, b64 = png_pack_device(frame)
+        text = b64.cpu().numpy().tobytes()
+    else:
+        _, b64, meta = png_deflate_device(frame)
+        n = int(meta[2].item())                        # the one synchronising read: the base64 length decided on the device
+        text = b64[:n].cpu().numpy().tobytes()
+    return text.decode("ascii"), {f"{phrase}": v for phrase, v in zip(phrases, xywh)}
 
 
 def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_TRESHOLD=0.01, output_coord_in_ratio=False,

@@ -39,3 +39,121 @@ def stored_png_size(H: int, W: int) -> int:
 
 def stored_png_b64(frame: np.ndarray) -> str:
     return base64.b64encode(stored_png(frame)).decode("ascii")
+
+
+# ---------------------------------------------------------------------------------------------------------------------------------
+# OMNI_OP_PNG_DEFLATE: the same file with a COMPRESSED zlib stream, built so that every 4096-byte unit of the filtered scanline stream
+# can be encoded by one GPU thread without knowing its neighbours' output:
+#   * scanline filter: row 0 type 0 (None), every other row type 2 (Up: byte - byte above, mod 256) — flat regions become zeros;
+#   * the filtered stream (filter bytes included) is cut into units of UNIT bytes; each unit is ONE deflate block with the FIXED
+#     Huffman code (RFC 1951 3.2.6) holding literals and matches of distance 1 (byte runs) or 3 (pixel runs) found greedily
+#     (longer of the two, length >= 3; matches may reach back across the unit boundary — the window is the decoder's), then an
+#     EMPTY STORED block, which pads to a byte boundary (the "sync flush" marker 00 00 FF FF) so units concatenate bytewise;
+#     a unit whose fixed-Huffman form is not smaller than UNIT + 5 bytes is emitted as one stored block instead;
+#   * the last unit's trailing empty stored block carries BFINAL.
+UNIT = 4096
+_LEN_BASE = [3, 4, 5, 6, 7, 8, 9, 10, 11, 13, 15, 17, 19, 23, 27, 31, 35, 43, 51, 59, 67, 83, 99, 115, 131, 163, 195, 227, 258]
+_LEN_EXTRA = [0, 0, 0, 0, 0, 0, 0, 0, 1, 1, 1, 1, 2, 2, 2, 2, 3, 3, 3, 3, 4, 4, 4, 4, 5, 5, 5, 5, 0]
+
+
+def filtered_stream(frame: np.ndarray) -> np.ndarray:
+    H, W, _ = frame.shape
+    rows = frame.reshape(H, W * 3)
+    out = np.zeros((H, W * 3 + 1), dtype=np.uint8)
+    out[0, 1:] = rows[0]
+    if H > 1:
+        out[1:, 0] = 2
+        out[1:, 1:] = rows[1:] - rows[:-1]          # uint8 arithmetic wraps mod 256
+    return out.reshape(-1)
+
+
+class _Bits:
+    def __init__(self):
+        self.out = bytearray()
+        self.acc = 0
+        self.n = 0
+
+    def put(self, value, nbits):                    # LSB first
+        self.acc |= value << self.n
+        self.n += nbits
+        while self.n >= 8:
+            self.out.append(self.acc & 255)
+            self.acc >>= 8
+            self.n -= 8
+
+    def put_code(self, code, nbits):                # Huffman codes go in MSB first
+        rev = 0
+        for _ in range(nbits):
+            rev = (rev << 1) | (code & 1)
+            code >>= 1
+        self.put(rev, nbits)
+
+    def align(self):
+        if self.n:
+            self.out.append(self.acc & 255)
+            self.acc = 0
+            self.n = 0
+
+
+def _lit_len_code(bits, sym):
+    if sym < 144:
+        bits.put_code(0x30 + sym, 8)
+    elif sym < 256:
+        bits.put_code(0x190 + sym - 144, 9)
+    elif sym < 280:
+        bits.put_code(sym - 256, 7)
+    else:
+        bits.put_code(0xC0 + sym - 280, 8)
+
+
+def _match(bits, length, dist):
+    k = max(j for j in range(29) if _LEN_BASE[j] <= length)
+    _lit_len_code(bits, 257 + k)
+    if _LEN_EXTRA[k]:
+        bits.put(length - _LEN_BASE[k], _LEN_EXTRA[k])
+    bits.put_code(0 if dist == 1 else 2, 5)
+
+
+def deflate_unit(f: np.ndarray, start: int, end: int, final: bool) -> bytes:
+    """one unit [start, end) of the filtered stream `f` -> its bytes in the zlib stream."""
+    b = _Bits()
+    b.put(0, 1)
+    b.put(1, 2)                                     # BFINAL 0, BTYPE 01
+    i = start
+    while i < end:
+        best, bd = 0, 0
+        for dist in (1, 3):
+            if i >= dist:
+                l = 0
+                while i + l < end and l < 258 and f[i + l] == f[i + l - dist]:
+                    l += 1
+                if l > best:
+                    best, bd = l, dist
+        if best >= 3:
+            _match(b, best, bd)
+            i += best
+        else:
+            _lit_len_code(b, int(f[i]))
+            i += 1
+    _lit_len_code(b, 256)
+    b.put(1 if final else 0, 1)
+    b.put(0, 2)                                     # empty stored block
+    b.align()
+    data = bytes(b.out) + b"\x00\x00\xff\xff"
+    n = end - start
+    if len(data) >= n + 5:
+        data = struct.pack("<BHH", 1 if final else 0, n, n ^ 0xFFFF) + f[start:end].tobytes()
+    return data
+
+
+def deflate_png(frame: np.ndarray) -> bytes:
+    H, W, C = frame.shape
+    assert C == 3 and frame.dtype == np.uint8
+    f = filtered_stream(frame)
+    n = f.size
+    z = bytearray(b"\x78\x01")
+    for s in range(0, n, UNIT):
+        z += deflate_unit(f, s, min(s + UNIT, n), s + UNIT >= n)
+    z += struct.pack(">I", zlib.adler32(f.tobytes()) & 0xFFFFFFFF)
+    ihdr = struct.pack(">IIBBBBB", W, H, 8, 2, 0, 0, 0)
+    return b"\x89PNG\r\n\x1a\n" + _chunk(b"IHDR", ihdr) + _chunk(b"IDAT", bytes(z)) + _chunk(b"IEND", b"")

@@ -41,6 +41,32 @@ def test_png_pack_is_the_oracle_layout_and_decodes(H, W):
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
 
 
+@pytest.mark.parametrize("kind", ["screenshot", "noise", "flat"])
+def test_png_deflate_is_the_oracle_stream_and_decodes(kind):
+    """OMNI_OP_PNG_DEFLATE at 1920x1080: byte-identical to oracle/png_ref.py::deflate_png (CPU restatement of the same encoder, Python
+    zlib checksums), inflated by zlib to the filtered scanlines, read back by Pillow."""
+    import zlib
+    from oracle import png_ref as PR
+    from omniparser_amd.synth import synthetic_screenshot
+    from omniparser_amd.util.utils import png_deflate_device
+    H, W = (1080, 1920) if kind == "screenshot" else (270, 480)
+    if kind == "screenshot":
+        frame = synthetic_screenshot(2, W, H)
+    elif kind == "noise":
+        frame = np.random.default_rng(1).integers(0, 256, (H, W, 3), dtype=np.uint8)
+    else:
+        frame = np.full((H, W, 3), 200, dtype=np.uint8)
+    png, b64, meta = png_deflate_device(torch.from_numpy(frame).cuda())
+    torch.cuda.synchronize()
+    m = meta.cpu()
+    data = png[: int(m[1])].cpu().numpy().tobytes()
+    assert zlib.decompress(data[41:41 + int(m[0])]) == PR.filtered_stream(frame).tobytes()
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
+    assert b64[: int(m[2])].cpu().numpy().tobytes() == base64.b64encode(data)
+    if kind != "screenshot":                                 # the pure-Python encoder needs ~1 s per 100 KB
+        assert data == PR.deflate_png(frame)
+
+
 def test_get_som_labeled_img_with_device_overlay(monkeypatch):
     """ref:util/utils.py:417-496 through the product with OMNI_OVERLAY=device vs the default host raster + Pillow PNG: same elements,
     same label coordinates, and the two PNGs decode to the same annotated frame."""

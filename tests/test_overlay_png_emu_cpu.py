@@ -73,3 +73,37 @@ def test_device_png_is_the_oracle_layout_and_decodes(emu, H, W):
     assert data == PR.stored_png(frame)
     assert b64.numpy().tobytes() == base64.b64encode(data)
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
+
+
+def _frames():
+    from omniparser_amd.synth import synthetic_screenshot
+    rng = np.random.default_rng(5)
+    yield "noise", rng.integers(0, 256, (37, 53, 3), dtype=np.uint8)                  # incompressible: stored fallback in every unit
+    yield "flat", np.full((40, 300, 3), 77, dtype=np.uint8)                            # maximal runs (258-byte matches)
+    yield "screenshot", synthetic_screenshot(1, 480, 270)
+    yield "pixel runs", np.tile(rng.integers(0, 256, (1, 1, 3), dtype=np.uint8), (5, 3000, 1))   # distance-3 matches across units
+    yield "one pixel", rng.integers(0, 256, (1, 1, 3), dtype=np.uint8)
+    f = rng.integers(0, 256, (64, 200, 3), dtype=np.uint8); f[::2] = f[1::2]            # every run length 3 .. 258 somewhere
+    for k, l in enumerate(range(3, 259)):
+        f[8 + k % 48, :, :].reshape(-1)[(k // 48) * 90:(k // 48) * 90 + l] = (k * 7) & 255
+    yield "all match lengths", f
+
+
+@pytest.mark.parametrize("name,frame", list(_frames()), ids=[n for n, _ in _frames()])
+def test_device_deflate_png_is_the_oracle_stream_and_decodes(emu, name, frame):
+    """OMNI_OP_PNG_DEFLATE: file bytes == oracle/png_ref.py::deflate_png (same filter, same greedy matcher, same fixed-Huffman bits,
+    zlib's checksums), zlib inflates the stream to the filtered scanlines, Pillow reads the frame back, base64 matches."""
+    import zlib
+    from oracle import png_ref as PR
+    from omniparser_amd.util.utils import png_deflate_device
+    png, b64, meta = png_deflate_device(torch.from_numpy(np.ascontiguousarray(frame)))
+    total, nb64 = int(meta[1]), int(meta[2])
+    data = png[:total].numpy().tobytes()
+    want = PR.deflate_png(frame)
+    assert total == len(want) and data == want
+    z = data[41:41 + int(meta[0])]
+    assert zlib.decompress(z) == PR.filtered_stream(frame).tobytes()
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
+    assert b64[:nb64].numpy().tobytes() == base64.b64encode(data)
+    if name in ("flat", "pixel runs"):
+        assert total < frame.size // 20
