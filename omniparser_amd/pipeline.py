@@ -80,6 +80,7 @@ class ScreenParser:
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
+        self.max_new_tokens = 20          # ref:util/utils.py:125 generate(max_new_tokens=20)
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
@@ -261,11 +262,12 @@ class ScreenParser:
 
     # ---- stage 3: caption all crops of all frames in packed micro-batches
     @torch.inference_mode()
-    def caption(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=20, crops_dev: Optional[torch.Tensor] = None):
+    def caption(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=None, crops_dev: Optional[torch.Tensor] = None):
         """crops_per_frame: host rectangles per frame, or — with `crops_dev` (int32 [frames, max_det, 4] on the device, rows in
         caption order) — just the number of crops per frame: the rectangles then never visit the host."""
         cap = self.cap
         R = cap.resolution
+        max_new_tokens = max_new_tokens or self.max_new_tokens
         if crops_dev is not None:
             flat = [(fi, k) for fi, n in enumerate(crops_per_frame) for k in range(int(n))]
         else:

@@ -12,7 +12,7 @@ CSRC = ROOT / "omniparser_amd" / "csrc"
 OUT = HERE / "libomni_emu.so"
 OBJ = HERE / "_obj"
 CLANG = os.environ.get("OMNI_EMU_CXX", "/opt/rocm/lib/llvm/bin/clang++")
-FLAGS = ["-x", "c++", "-std=c++20", "-O1", "-mf16c", "-pthread", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas", "-Wno-unused-value",
+FLAGS = ["-x", "c++", "-std=c++20", "-O2", "-mavx2", "-mf16c", "-pthread", "-fPIC", "-ffp-contract=off", "-Wno-unknown-pragmas", "-Wno-unused-value",
          "-Wno-psabi", f"-I{HERE / 'fakehip'}"]
 
 

@@ -146,6 +146,21 @@ inline auto collective(const T& v, F&& f) {
   return f([&w, q](int l) { T t; std::memcpy(&t, w.buf[q][l & 63], sizeof(T)); return t; });
 }
 
+// same, but `f` gets lane -> const T* into the wave's buffer (valid until this lane's next collective): no copies
+template <class T, class F>
+inline auto collective_ptr(const T& v, F&& f) {
+  static_assert(sizeof(T) <= SLOT && alignof(T) <= 64, "wave scratch");
+  Fiber* me = cur;
+  Wave& w = blk->waves[me->wave];
+  const unsigned seq = me->coll++;
+  const int q = seq & 1;
+  if (w.tag[q] != seq) { w.tag[q] = seq; w.count[q] = 0; }
+  std::memcpy(w.buf[q][me->lane], &v, sizeof(T));
+  ++w.count[q];
+  while (w.tag[q] == seq && w.count[q] < w.alive) yield();
+  return f([&w, q](int l) { return reinterpret_cast<const T*>(w.buf[q][l & 63]); });
+}
+
 [[noreturn]] inline void fiber_exit() {
   Block& b = *blk;
   Fiber* me = cur;
@@ -318,18 +333,24 @@ inline emu_hv2 emu_cvt_pkrtz(float a, float b) {
 typedef float emu_f32x4 __attribute__((ext_vector_type(4)));
 typedef float emu_f32x16 __attribute__((ext_vector_type(16)));
 typedef _Float16 emu_f16x8 __attribute__((ext_vector_type(8)));
-struct emu_AB16 { emu_f16x8 a, b; };
+struct alignas(64) emu_ABf { float a[8], b[8]; };         // a lane's A / B fragment, widened once
+inline emu_ABf emu_widen(emu_f16x8 a, emu_f16x8 b) {
+  emu_ABf m;
+  for (int i = 0; i < 8; ++i) { m.a[i] = (float)a[i]; m.b[i] = (float)b[i]; }
+  return m;
+}
 inline emu_f32x16 emu_mfma_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, int, int, int) {
   const int l = emu::cur->lane;
-  return emu::collective(emu_AB16{a, b}, [&](auto get) {
-    emu_AB16 fr[64];
-    for (int q = 0; q < 64; ++q) fr[q] = get(q);
+  return emu::collective_ptr(emu_widen(a, b), [&](auto at) {
     emu_f32x16 d = c;
     const int col = l & 31;
+    const emu_ABf *b0 = at(col), *b1 = at(col + 32);
     for (int r = 0; r < 16; ++r) {
       const int row = (r & 3) + 8 * (r >> 2) + 4 * (l >> 5);
+      const emu_ABf *a0 = at(row), *a1 = at(row + 32);
       double s = c[r];                          // products exact, one rounding per instruction (the hardware sums a k block wide)
-      for (int k = 0; k < 16; ++k) s += (double)((float)fr[row + 32 * (k >> 3)].a[k & 7] * (float)fr[col + 32 * (k >> 3)].b[k & 7]);
+      for (int k = 0; k < 8; ++k) s += (double)(a0->a[k] * b0->b[k]);
+      for (int k = 0; k < 8; ++k) s += (double)(a1->a[k] * b1->b[k]);
       d[r] = (float)s;
     }
     return d;
@@ -337,15 +358,16 @@ inline emu_f32x16 emu_mfma_32x32x16_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x16 c, 
 }
 inline emu_f32x4 emu_mfma_16x16x32_f16(emu_f16x8 a, emu_f16x8 b, emu_f32x4 c, int, int, int) {
   const int l = emu::cur->lane;
-  return emu::collective(emu_AB16{a, b}, [&](auto get) {
-    emu_AB16 fr[64];
-    for (int q = 0; q < 64; ++q) fr[q] = get(q);
+  return emu::collective_ptr(emu_widen(a, b), [&](auto at) {
     emu_f32x4 d = c;
     const int col = l & 15;
     for (int r = 0; r < 4; ++r) {
       const int row = 4 * (l >> 4) + r;
       double s = c[r];
-      for (int k = 0; k < 32; ++k) s += (double)((float)fr[row + 16 * (k >> 3)].a[k & 7] * (float)fr[col + 16 * (k >> 3)].b[k & 7]);
+      for (int kb = 0; kb < 4; ++kb) {
+        const emu_ABf *ar = at(row + 16 * kb), *bc = at(col + 16 * kb);
+        for (int k = 0; k < 8; ++k) s += (double)(ar->a[k] * bc->b[k]);
+      }
       d[r] = (float)s;
     }
     return d;

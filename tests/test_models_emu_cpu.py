@@ -20,12 +20,22 @@ def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
 
 def test_captioner_token_exact_r64(emu):
     """Florence2Captioner.generate (DaViT tower, projector, BART encoder / decoder with KV cache, greedy loop: every captioner kernel)
-    vs transformers on the CPU: same ids, logit error below the smallest arg-max margin."""
+    vs transformers on the CPU: image features, encoder output, greedy ids.  Three decode steps: a single-row lm_head (768 x 51289,
+    padded to a 128-row tile) costs the emulation 15 G multiply-adds per step; the 21-token loops run on the MI355X
+    (tests/test_gpu_b_caption_model.py) and in the plan interpreter (tests/test_caption_cpu.py)."""
+    import caption_checks as CC
     import gpu_checks as G
-    out, _ = G.check_captioner(R=64, n=1)
-    assert out["ids_equal"], out
-    assert out["feat_rel_err"] < 1e-4 and out["enc_rel_err"] < 1e-4
-    assert out["max_logit_err"] < out["min_top1_top2_margin"], out
+    from omniparser_amd.florence import Florence2Captioner
+    from tools.make_weights import build_random_captioner, ensure_caption_checkpoint
+    max_new = 3
+    pix = torch.randn(1, 3, 64, 64, generator=torch.Generator().manual_seed(75))
+    feats, enc, ids = CC.hf_reference(build_random_captioner(0), pix, max_new)
+    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    got = cap.generate(pixel_values=pix, max_new_tokens=max_new)
+    cp = cap.plans(cap.bucket(1), 64, max_new)
+    assert G.rel_err(cp.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
+    assert G.rel_err(cp.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
+    assert got.shape == ids.shape and torch.equal(got, ids), (got, ids)
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
@@ -45,6 +55,7 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
     kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=4)
     monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
     sp = ScreenParser(det, cap, **kw)
+    sp.max_new_tokens = 1                                          # the decode loop is covered by the captioner test
     assert sp.device_glue
     elems, ids = sp.parse_batch(frames, ocr, return_ids=True)
     crops = sp.last_crops
@@ -61,7 +72,7 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
         for a, b in zip(elems[f], el):
             assert (a["type"], a["bbox"], a["source"], a["interactivity"]) == (b["type"], b["bbox"], b["source"], b["interactivity"])
             if b["content"] is None:
-                assert isinstance(a["content"], str) and len(ids[f][k]) > 2      # captioned from the device-side rectangles
+                assert isinstance(a["content"], str) and len(ids[f][k]) >= 1     # captioned from the device-side rectangles
                 k += 1
             else:
                 assert a["content"] == b["content"]

@@ -16,7 +16,7 @@ echo "=== 1. default bench line"
 ( OMNI_BENCH_WATCHDOG=120 timeout 420 python bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "exit $?" >> "$OUT/bench.err" )
 grep -v "^  File\|^Thread" "$OUT/bench.err" | tail -6 | cut -c1-300
 echo "=== 2. GPU suite"
-for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/test_gpu_c_detector.py tests/test_gpu_d_pipeline.py tests/test_gpu_f_device_handoff.py; do
+for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/test_gpu_c_detector.py tests/test_gpu_d_pipeline.py tests/test_gpu_g_service.py tests/test_gpu_h_overlay_png.py tests/test_gpu_f_device_handoff.py; do
   n=$(basename "$f" .py)
   ( timeout 600 python -m pytest "$f" -q -p no:cacheprovider --durations=5 > "$OUT/$n.log" 2>&1; echo "exit $?" >> "$OUT/$n.log" )
   echo "--- $n"; grep -v "Warning\|warnings.warn\|^$\|_create_method\|^tests/test_gpu" "$OUT/$n.log" | tail -12 | cut -c1-1200
@@ -42,9 +42,14 @@ for ctr in FETCH_SIZE WRITE_SIZE; do
   ( timeout 300 rocprofv3 --pmc $ctr --kernel-trace --output-format csv -d "$OUT/pmc_$ctr" -- python bench.py --steps 1 --warmup 0 --no-cpu-baseline --no-extra > /dev/null 2> "$OUT/pmc_$ctr.err"; echo "pmc $ctr exit $?" )
   python tools/pmc_summary.py "$OUT/pmc_$ctr" > "$OUT/pmc_$ctr.json" 2>> "$OUT/pmc_$ctr.err"
 done
+echo "=== 4b. annotate / PNG tail: host vs device (tools/annotate_bench.py)"
+( timeout 120 python tools/annotate_bench.py > "$OUT/annotate_tail.json" 2> "$OUT/annotate_tail.err"; echo "annotate exit $?"; cat "$OUT/annotate_tail.json" | cut -c1-900 )
 echo "=== 5. device hand-off (eager detector plan) A/B — last: the graph variant of this path stalled in round 2"
 ( OMNI_DEVICE_GLUE=1 OMNI_BENCH_WATCHDOG=40 timeout 90 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_device_glue.json" 2> "$OUT/ab_device_glue.err"; echo "device glue -> exit $?" )
 tail -c 600 "$OUT/ab_device_glue.json"; echo
+echo "=== 6. device hand-off inside the detector graph (OMNI_DEVICE_GLUE=2: one graph, no launch between replays) — the very last GPU work of the call"
+( OMNI_DEVICE_GLUE=2 OMNI_BENCH_WATCHDOG=40 timeout 90 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_device_glue2.json" 2> "$OUT/ab_device_glue2.err"; echo "device glue 2 -> exit $?" )
+tail -c 600 "$OUT/ab_device_glue2.json"; echo
 find "$OUT" -name "*_kernel_stats.csv" | head -3
 find "$OUT" -name "*.csv" -size +8M -delete
 find "$OUT" -name "*.db" -delete
