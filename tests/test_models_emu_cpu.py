@@ -5,6 +5,8 @@ ones the MI355X runs (tests/gpu_checks.py); what the hardware alone decides (tim
 import pytest
 import torch
 
+from omniparser_amd import _lib as L
+
 
 def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
     """YOLOv9Detector.predict (import-verified blob -> plan -> letterbox / network / decode / NMS kernels) vs oracle.detector_ref on a
@@ -18,7 +20,7 @@ def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
     assert out["ops"] > 250
 
 
-def test_captioner_token_exact_r64(emu):
+def test_captioner_token_exact_r64(emu, monkeypatch):
     """Florence2Captioner.generate (DaViT tower, projector, BART encoder / decoder with KV cache, greedy loop: every captioner kernel)
     vs transformers on the CPU: image features, encoder output, greedy ids.  Three decode steps: a single-row lm_head (768 x 51289,
     padded to a 128-row tile) costs the emulation 15 G multiply-adds per step; the 21-token loops run on the MI355X
@@ -36,6 +38,20 @@ def test_captioner_token_exact_r64(emu):
     assert G.rel_err(cp.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
     assert G.rel_err(cp.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
     assert got.shape == ids.shape and torch.equal(got, ids), (got, ids)
+    # the opt-in format-B producers (attention / channel attention / fused dwconv + LayerNorm write the split operand of the next
+    # GEMM directly: OMNI_ATTN_SPLIT_OUT, OMNI_FUSE_DWLN — untimed on the MI355X so far): same features, encode pass only
+    monkeypatch.setenv("OMNI_ATTN_SPLIT_OUT", "1")
+    monkeypatch.setenv("OMNI_FUSE_DWLN", "1")
+    cap2 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cp2 = cap2.plans(1, 64, max_new)
+    assert any(op.kind == L.OP_DWCONV3_LN for op in cp2.encode_plan.ops) and not any(op.kind == L.OP_DWCONV3_LN for op in cp.encode_plan.ops)
+    assert sum(op.kind == L.OP_SPLIT_CONVERT for op in cp2.encode_plan.ops) < sum(op.kind == L.OP_SPLIT_CONVERT for op in cp.encode_plan.ops)
+    with torch.inference_mode():
+        cp2.reset()
+        cp2.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
+        cp2.encode_plan.run(cap2.stream)
+    assert G.rel_err(cp2.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
+    assert G.rel_err(cp2.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
@@ -52,7 +68,7 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
     cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     frames = [torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in (0, 2)]
     ocr = [synthetic_ocr(0, 640, 480, 12), ([], [])]                                  # second frame without OCR
-    kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=4)
+    kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)
     monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
     sp = ScreenParser(det, cap, **kw)
     sp.max_new_tokens = 1                                          # the decode loop is covered by the captioner test
@@ -78,4 +94,4 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
                 assert a["content"] == b["content"]
         assert k == len(cr)
         n_crops += k
-    assert n_crops >= 6          # more than one packed micro-batch of 4, spanning both frames
+    assert n_crops >= 6          # one packed micro-batch spanning both frames (the seams between micro-batches: tests/test_gpu_d_pipeline.py)
