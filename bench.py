@@ -230,6 +230,13 @@ def main():
             out["extra"]["annotate_tail"] = child_json([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
                                                                                      "annotate_bench.py")], {}, 120)
             note("annotate_tail done")
+            # BASELINE configs[3] stand-in on this one GPU: mixed-resolution eval stream (tools/stream_bench.py), 64x64 crops
+            out["extra"]["stream_mixed_resolution_r64"] = child_json(
+                [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stream_bench.py"), "--items", "48",
+                 "--caption-res", "64"], {}, 150,
+                keep=("metric", "value", "unit", "items", "seconds", "caption_res", "device_batch", "rank0_batches", "mean_elements",
+                      "resolution_counts", "data"))
+            note("stream_mixed_resolution_r64 done")
         if world == 1 and not args.no_cpu_baseline:
             guarded("cpu_baseline", lambda: cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0)))
         faulthandler.cancel_dump_traceback_later()
