@@ -46,7 +46,7 @@ def parse_args():
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
-    ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.ab_*`, `extra.annotate_tail`)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.ab_opt_in_kernels`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -220,13 +220,14 @@ def main():
             guarded("extra", lambda: extras(args, det, parser, frames, ocr, dev))
         if world == 1 and not args.no_extra and not args.no_ab and args.mode == "e2e" and isinstance(out.get("extra"), dict):
             # opt-in kernels that have never been timed, each in its OWN process with a hard limit (a fault or a stall there
-            # cannot take this line with it): the format-B producers, and the annotate / PNG tail on the device
-            out["extra"]["ab_format_b_producers"] = child_json(
+            # cannot take this line with it): the format-B producers + the row-coalesced decode attention (compare
+            # roofline.kernel_family_ms_per_step family by family with the line's own), and the annotate / PNG tail on the device
+            out["extra"]["ab_opt_in_kernels"] = child_json(
                 [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
-                {"OMNI_ATTN_SPLIT_OUT": "1", "OMNI_FUSE_DWLN": "1"}, 150,
+                {"OMNI_ATTN_SPLIT_OUT": "1", "OMNI_FUSE_DWLN": "1", "OMNI_DECODE_ATTN": "2"}, 150,
                 keep=("value", "ms_per_step", ("roofline", "non_gemm_share"), ("roofline", "gemm_ms_per_step"),
                       ("roofline", "kernel_family_ms_per_step"), ("roofline", "crops_per_step")))
-            note("ab_format_b_producers done")
+            note("ab_opt_in_kernels done")
             out["extra"]["annotate_tail"] = child_json([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
                                                                                      "annotate_bench.py")], {}, 120)
             note("annotate_tail done")

@@ -1040,6 +1040,57 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(DecArgs a) {
   stf((T*)a.o + (long long)b * a.ldo + h * 64 + lane, acc / sum);
 }
 
+// Row-coalesced variant (OMNI_DECODE_ATTN=2, f32 plans; untimed so far): one wave per (b, group of 4 heads).  A lane owns one
+// float4 of the group's 256 channels, so every K / V row is read as ONE contiguous 1 KiB access per wave (the kernel above gives
+// each lane its own row: 64 rows per load instruction); the 16 lanes of a head reduce their partial dot products by shuffles.
+// Same arithmetic up to the summation order of the 64-term dot product.
+__global__ __launch_bounds__(64) void attn_decode_rows_kernel(DecArgs a) {
+  OMNI_DYN_LDS(float, sp);                    // [4][nk_pad] scores -> probabilities of the group's heads
+  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
+  const int hl = lane >> 4;                   // head within the group
+  const int C = a.ldc;
+  const int ch = g * 256 + lane * 4;          // first of this lane's 4 channels
+  float* Kc = (float*)a.kc + (long long)b * a.cap * C + ch;
+  float* Vc = (float*)a.vc + (long long)b * a.cap * C + ch;
+  int nk;
+  if (a.nk_fixed > 0) {
+    nk = a.nk_fixed;
+  } else {
+    const int st = *a.step;
+    nk = st + 1;
+    *reinterpret_cast<f32x4*>(Kc + (long long)st * C) = *reinterpret_cast<const f32x4*>((const float*)a.knew + (long long)b * a.ldn + a.koff + ch);
+    *reinterpret_cast<f32x4*>(Vc + (long long)st * C) = *reinterpret_cast<const f32x4*>((const float*)a.vnew + (long long)b * a.ldn + a.voff + ch);
+    __syncthreads();
+  }
+  const int nkp = (a.nk_fixed > 0 ? a.nk_fixed : a.cap) + 1;        // row pitch of sp
+  float* mine = sp + hl * nkp;
+  const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)a.q + (long long)b * a.ldq + a.qoff + ch);
+  float mx = -INFINITY;
+  for (int k = 0; k < nk; ++k) {
+    const f32x4 kv = *reinterpret_cast<const f32x4*>(Kc + (long long)k * C);
+    float s = (q[0] * kv[0] + q[1] * kv[1]) + (q[2] * kv[2] + q[3] * kv[3]);
+#pragma unroll
+    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);             // the 16 lanes of a head
+    s *= a.scale;
+    if ((lane & 15) == 0) mine[k] = s;
+    mx = fmaxf(mx, s);
+  }
+  __syncthreads();
+  float sum = 0.f;
+  for (int k = lane & 15; k < nk; k += 16) { const float e = expf(mine[k] - mx); mine[k] = e; sum += e; }
+#pragma unroll
+  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  __syncthreads();
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+  for (int k = 0; k < nk; ++k) {
+    const float pk = mine[k];
+    const f32x4 v = *reinterpret_cast<const f32x4*>(Vc + (long long)k * C);
+    acc[0] += pk * v[0]; acc[1] += pk * v[1]; acc[2] += pk * v[2]; acc[3] += pk * v[3];
+  }
+  f32x4 o4 = {acc[0] / sum, acc[1] / sum, acc[2] / sum, acc[3] / sum};
+  *reinterpret_cast<f32x4*>((float*)a.o + (long long)b * a.ldo + ch) = o4;
+}
+
 // ------------------------------------------------------------------------------------ greedy_step
 struct GreedyArgs {
   const void* logits; const float* bias; int* ids; int* finished; const int* step;
@@ -1359,6 +1410,14 @@ static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.q && a.kc && a.vc && a.o && B > 0 && a.heads > 0 && a.C == a.heads * 64, "attn_decode: bad arguments (head_dim 64)");
   OMNI_REQUIRE(a.nk_fixed > 0 || (a.knew && a.vnew && a.step), "attn_decode: self-attention needs new k/v and the step counter");
   int nk_max = a.nk_fixed > 0 ? a.nk_fixed : a.cap;
+  const char* dv = getenv("OMNI_DECODE_ATTN");
+  const int variant = dv ? atoi(dv) : 1;
+  if (variant == 2 && op->dtype == OMNI_F32 && a.heads % 4 == 0 && a.ldc % 4 == 0 && a.ldq % 4 == 0 && a.qoff % 4 == 0 && a.ldo % 4 == 0 &&
+      (a.nk_fixed > 0 || (a.ldn % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0))) {
+    hipLaunchKernelGGL(attn_decode_rows_kernel, dim3(a.heads / 4, B), dim3(64), (size_t)4 * (nk_max + 1) * 4, s, a);
+    OMNI_HIP_CHECK(hipGetLastError());
+    return OMNI_OK;
+  }
   dim3 grid(a.heads, B);
   size_t sh = (size_t)nk_max * 4;
   int rc = by_dtype(op->dtype, "attn_decode",
