@@ -46,6 +46,7 @@ def parse_args():
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
+    ap.add_argument("--pipeline", action="store_true", help="time the K steps through ScreenParser.parse_stream (steps overlap) instead of K parse_batch calls")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.ab_opt_in_kernels`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
@@ -137,6 +138,9 @@ def main():
                         r[2 + 5 * OD.MAX_DET:2 + 6 * OD.MAX_DET] = dp.out_cls[j]
             return
         elems, ids = parser.parse_batch([frames[f] for f in idx], [ocr[f] for f in idx], return_ids=True)
+        pack(step_id, li, elems, ids)
+
+    def pack(step_id, li, elems, ids):
         crop_counts.append(sum(parser.stats["crops"]))
         if li is not None:
             for j in range(B):
@@ -161,8 +165,19 @@ def main():
     sync_all()
     crop_counts.clear()
     t0 = time.perf_counter()
-    for li, item in enumerate(my_items):
-        step(item, li)
+    if args.pipeline and args.mode == "e2e":
+        # the same K steps as a software pipeline over batches (ScreenParser.parse_stream): detector + hand-off of step i+1 overlap
+        # the captions of step i, the caption work of step i+1 is queued before step i is read back
+        def batches():
+            for item in my_items:
+                idx = [(item * B + j) % 8 for j in range(B)]
+                yield [frames[f] for f in idx], [ocr[f] for f in idx]
+        with torch.inference_mode():
+            for li, (elems, ids) in enumerate(parser.parse_stream(batches(), return_ids=True)):
+                pack(my_items[li], li, elems, ids)
+    else:
+        for li, item in enumerate(my_items):
+            step(item, li)
     with torch.cuda.stream(det.stream):
         allr = OD.gather_records(recs, n_items, rank, world)
     sync_all()
@@ -202,6 +217,7 @@ def main():
     if args.mode == "e2e":
         out["config"]["mean_crops_per_screenshot"] = round(sum(crop_counts) / max(len(crop_counts), 1) / B, 2)
         out["config"]["caption_micro_batch"] = 128
+        out["config"]["steps_pipelined"] = bool(args.pipeline)
 
     if rank == 0:
         # the timed result above is final: nothing below may keep the JSON line from being printed
@@ -223,9 +239,9 @@ def main():
             # cannot take this line with it): the format-B producers + the row-coalesced decode attention (compare
             # roofline.kernel_family_ms_per_step family by family with the line's own), and the annotate / PNG tail on the device
             out["extra"]["ab_opt_in_kernels"] = child_json(
-                [sys.executable, os.path.abspath(__file__), "--steps", "2", "--warmup", "1", "--no-extra", "--no-cpu-baseline"],
+                [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--pipeline"],
                 {"OMNI_ATTN_SPLIT_OUT": "1", "OMNI_FUSE_DWLN": "1", "OMNI_DECODE_ATTN": "2"}, 150,
-                keep=("value", "ms_per_step", ("roofline", "non_gemm_share"), ("roofline", "gemm_ms_per_step"),
+                keep=("value", "ms_per_step", "steps", ("config", "steps_pipelined"), ("roofline", "non_gemm_share"), ("roofline", "gemm_ms_per_step"),
                       ("roofline", "kernel_family_ms_per_step"), ("roofline", "crops_per_step")))
             note("ab_opt_in_kernels done")
             out["extra"]["annotate_tail"] = child_json([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
@@ -469,7 +485,7 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
     from tools.make_weights import build_random_captioner
     cap = build_random_captioner(0)
     R = args.caption_res
-    n = 8
+    n = 4
     rng = np.random.default_rng(0)
     img = synthetic_screenshot(0)
     boxes = [(int(x), int(y), int(x) + 60, int(y) + 48) for x, y in zip(rng.integers(0, 1800, n), rng.integers(0, 1000, n))]

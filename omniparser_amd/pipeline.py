@@ -265,6 +265,12 @@ class ScreenParser:
     def caption(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=None, crops_dev: Optional[torch.Tensor] = None):
         """crops_per_frame: host rectangles per frame, or — with `crops_dev` (int32 [frames, max_det, 4] on the device, rows in
         caption order) — just the number of crops per frame: the rectangles then never visit the host."""
+        return self.caption_finish(self.caption_launch(frames, crops_per_frame, max_new_tokens, crops_dev))
+
+    @torch.inference_mode()
+    def caption_launch(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=None, crops_dev: Optional[torch.Tensor] = None):
+        """queue the crop / encode / decode work of every micro-batch on the captioner's stream; nothing is read back.  The handle
+        keeps the frames alive until `caption_finish`."""
         cap = self.cap
         R = cap.resolution
         max_new_tokens = max_new_tokens or self.max_new_tokens
@@ -308,6 +314,12 @@ class ScreenParser:
                     L.launch(op, cap.stream)
                     o = e
                 ids_all.append(cap._run(cp, n, max_new_tokens, defer=True))   # keep the GPU fed: no sync between micro-batches
+        return (list(frames), flat, ids_all)
+
+    @torch.inference_mode()
+    def caption_finish(self, handle):
+        frames, flat, ids_all = handle
+        cap = self.cap
         ids_all = [cap._finish_ids(t.cpu().long()) for t in ids_all]     # single read-back point
         out = [[] for _ in frames]
         k = 0
@@ -326,6 +338,62 @@ class ScreenParser:
         ih, iw = frames[0].shape[:2]
         with self.det._lock, self.cap._lock:
             return self._parse_batch_locked(frames, ocr, return_ids, iw, ih, pad_to)
+
+    def parse_stream(self, batches, return_ids=False, pad_to: Optional[int] = None):
+        """Generator over an iterable of (frames, ocr) batches -> what `parse_batch` returns for each, in order, as a software
+        pipeline: the detector pass and the host hand-off of batch i+1 run on a helper thread (their stream is the detector's)
+        while the captions of batch i occupy the GPU, and the caption work of batch i+1 is queued BEFORE the read-back of batch i
+        blocks — the GPU never waits for the host between batches.  Same kernels, same order per batch, same results as
+        `parse_batch`.  (Host hand-off only: with OMNI_DEVICE_GLUE the crop table of a batch lives in per-plan device buffers.)"""
+        from concurrent.futures import ThreadPoolExecutor
+        if self.device_glue:
+            for frames, ocr in batches:
+                yield self.parse_batch(frames, ocr, return_ids=return_ids, pad_to=pad_to)
+            return
+
+        def stage_a(frames, ocr):
+            with torch.inference_mode(), self.det._lock:
+                ih, iw = frames[0].shape[:2]
+                det_boxes = self.detect(frames, pad_to)
+                elems_all, crops_all = [], []
+                for fi, xy in enumerate(det_boxes):
+                    texts, boxes = ocr[fi] if ocr is not None else ([], [])
+                    el, cr = self.glue(xy, iw, ih, boxes, texts)
+                    elems_all.append(el); crops_all.append(cr)
+                return frames, elems_all, crops_all, [len(b) for b in det_boxes]
+
+        def finish(pending):
+            handle, elems_all, crops_all, nbox = pending
+            with torch.inference_mode(), self.cap._lock:
+                caps = self.caption_finish(handle)
+            ids_out = []
+            for el, cl in zip(elems_all, caps):
+                q = list(cl)
+                for e in el:
+                    if e["content"] is None and q:
+                        e["content"] = q.pop(0)[0]
+                ids_out.append([r for _, r in cl])
+            self.stats = {"crops": [len(c) for c in crops_all], "boxes": nbox}
+            self.last_crops = crops_all
+            return (elems_all, ids_out) if return_ids else elems_all
+
+        it = iter(batches)
+        first = next(it, None)
+        if first is None:
+            return
+        with ThreadPoolExecutor(1) as helper:
+            fut = helper.submit(stage_a, *first)
+            pending = None
+            while fut is not None:
+                frames, elems_all, crops_all, nbox = fut.result()
+                nxt = next(it, None)
+                fut = helper.submit(stage_a, *nxt) if nxt is not None else None
+                with torch.inference_mode(), self.cap._lock:
+                    handle = self.caption_launch(frames, crops_all)
+                if pending is not None:
+                    yield finish(pending)
+                pending = (handle, elems_all, crops_all, nbox)
+            yield finish(pending)
 
     def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih, pad_to=None):
         tiled = self.tile_large and (iw > 1952 or ih > 1112)

@@ -95,3 +95,43 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
         assert k == len(cr)
         n_crops += k
     assert n_crops >= 6          # one packed micro-batch spanning both frames (the seams between micro-batches: tests/test_gpu_d_pipeline.py)
+
+
+def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):
+    """ScreenParser.parse_stream (detector + hand-off of batch i+1 on a helper thread while batch i is captioned; caption work of
+    batch i+1 queued before the read-back of batch i) returns what parse_batch returns, batch by batch, in order.  Real detector,
+    hand-off and crop kernels on the emulation (two threads launching concurrently); the encode / decode plans are replaced by a
+    fingerprint of each crop's pixel tensor, which pins crop -> caption slot -> element across the pipeline's hand-overs."""
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
+    monkeypatch.setenv("OMNI_DEVICE_GLUE", "0")
+    det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
+    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+
+    def fingerprint(cp, n, max_new, defer=False):
+        x = cp.x_in.t[:n, :, :, :3].double()
+        key = (x.sum((1, 2, 3)) * 977.0 + x[:, ::7, ::5].sum((1, 2, 3)) * 131.0).abs()
+        return torch.stack([torch.full((n,), 0, dtype=torch.long), 100 + (key.long() % 40000), torch.full((n,), 2, dtype=torch.long)], 1).int()
+    monkeypatch.setattr(cap, "_run", fingerprint)
+    sp = ScreenParser(det, cap, box_threshold=0.5, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)
+    batches = [([torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in seeds], [synthetic_ocr(s, 640, 480, 10) for s in seeds])
+               for seeds in ((0, 1), (2,), (3, 0))]
+    want, crops_want = [], []
+    for f, o in batches:
+        want.append(sp.parse_batch(f, o, return_ids=True, pad_to=2))
+        crops_want.append(sp.last_crops)
+    got = []
+    crops_got = []
+    for res in sp.parse_stream(iter(batches), return_ids=True, pad_to=2):
+        got.append(res)
+        crops_got.append(sp.last_crops)
+    assert len(got) == 3 and crops_got == crops_want
+    for (el_w, ids_w), (el_g, ids_g) in zip(want, got):
+        assert el_g == el_w
+        assert [[r.tolist() for r in f] for f in ids_g] == [[r.tolist() for r in f] for f in ids_w]
+    assert sum(len(c) for b in crops_want for c in b) >= 12
+    assert len({tuple(r.tolist()) for _, ids in want for f in ids for r in f}) >= 10        # the fingerprints tell crops apart
