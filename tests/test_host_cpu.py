@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_enums_mirror_the_header():
     hdr = (ROOT / "include" / "omni_amd.h").read_text()
     ops = dict(re.findall(r"\b(OMNI_OP_[A-Z0-9_]+) = (\d+),", hdr))
-    assert len(ops) == 20 and sorted(map(int, ops.values())) == list(range(1, 21))
+    assert len(ops) == 23 and sorted(map(int, ops.values())) == list(range(1, 24))
     for name, val in ops.items():
         assert getattr(L, name[len("OMNI_"):]) == int(val), name
     assert (L.F32, L.F16, L.ACT_NONE, L.ACT_SILU, L.ACT_GELU) == (0, 1, 0, 1, 2)
@@ -222,3 +222,19 @@ def test_library_binds_to_one_hip_runtime():
     assert out.returncode == 0, out.stderr[-2000:]
     libs = eval(out.stdout.strip().splitlines()[-1])
     assert len(libs) == 1 and "torch" in libs[0], libs
+
+
+def test_bench_child_process_helper_reports_instead_of_raising():
+    """bench.py runs never-timed code paths in child processes with a hard limit (`extra.ab_opt_in_kernels`, `extra.annotate_tail`,
+    `extra.stream_*`): whatever happens there ends up as data in the line, never as an exception or a stall of the line itself."""
+    import importlib.util
+    import sys
+    spec = importlib.util.spec_from_file_location("bench_under_test", ROOT / "bench.py")
+    b = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(b)
+    ok = b.child_json([sys.executable, "-c", "print('noise'); print('{\"value\": 2, \"roofline\": {\"non_gemm_share\": 0.3}}')"], {"X": "1"}, 20,
+                      keep=("value", ("roofline", "non_gemm_share"), ("roofline", "absent")))
+    assert ok == {"value": 2, "roofline.non_gemm_share": 0.3, "roofline.absent": None, "env": {"X": "1"}}
+    assert "no result within" in b.child_json([sys.executable, "-c", "import time; time.sleep(30)"], {}, 1)["error"]
+    assert b.child_json([sys.executable, "-c", "import sys; sys.stderr.write('boom'); sys.exit(3)"], {}, 20)["error"].startswith("exit 3")
+    assert "error" in b.child_json([sys.executable, "-c", "print('{not json')"], {}, 20)
