@@ -1,6 +1,6 @@
 """`-m gpu`: the tail of get_som_labeled_img on the device (csrc/overlay_png.hip, opt-in OMNI_OVERLAY=device) — set-of-marks raster,
 stored-deflate PNG with device-side Adler-32 / CRC-32, base64 — against the host raster, the byte-layout oracle (oracle/png_ref.py)
-and Pillow's PNG reader.  Last file of the suite: new in round 2 after the last GPU minute (validated on the host emulation,
+and Pillow's PNG reader.  New in round 2 after the last GPU minute (validated on the host emulation,
 tests/test_overlay_png_emu_cpu.py)."""
 import base64
 import io

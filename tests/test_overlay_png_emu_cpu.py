@@ -1,6 +1,6 @@
 """Overlay raster and PNG / base64 packing of csrc/overlay_png.hip, run from their device sources on the host emulation (tests/emu)
 and compared with (a) the host raster `overlay.render`, itself compared with Pillow's ImageDraw here, (b) oracle/png_ref.py (layout
-restatement on Python's zlib checksums), byte for byte, (c) Pillow's PNG reader.  The `-m gpu` twin: tests/test_gpu_h_overlay_png.py."""
+restatement on Python's zlib checksums), byte for byte, (c) Pillow's PNG reader.  The `-m gpu` twin: tests/test_gpu_f_overlay_png.py."""
 import base64
 import io
 

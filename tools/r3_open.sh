@@ -16,7 +16,7 @@ echo "=== 1. default bench line"
 ( OMNI_BENCH_WATCHDOG=120 timeout 420 python bench.py --steps 5 --warmup 2 > "$OUT/bench.json" 2> "$OUT/bench.err"; echo "exit $?" >> "$OUT/bench.err" )
 grep -v "^  File\|^Thread" "$OUT/bench.err" | tail -6 | cut -c1-300
 echo "=== 2. GPU suite"
-for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/test_gpu_c_detector.py tests/test_gpu_d_pipeline.py tests/test_gpu_g_service.py tests/test_gpu_h_overlay_png.py tests/test_gpu_f_device_handoff.py; do
+for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/test_gpu_c_detector.py tests/test_gpu_d_pipeline.py tests/test_gpu_f_overlay_png.py tests/test_gpu_g_device_handoff.py tests/test_gpu_h_service.py; do
   n=$(basename "$f" .py)
   ( timeout 600 python -m pytest "$f" -q -p no:cacheprovider --durations=5 > "$OUT/$n.log" 2>&1; echo "exit $?" >> "$OUT/$n.log" )
   echo "--- $n"; grep -v "Warning\|warnings.warn\|^$\|_create_method\|^tests/test_gpu" "$OUT/$n.log" | tail -12 | cut -c1-1200
