@@ -1,5 +1,5 @@
 """`-m gpu`: the opt-in device-side detect -> caption hand-off (OMNI_DEVICE_GLUE=1, csrc/glue_ops.hip) — the kernel against the fixtures
-recorded from the reference's own functions and against the host twin, then through `ScreenParser.parse_batch`.  Last file of the
+recorded from the reference's own functions and against the host twin, then through `ScreenParser.parse_batch`.  Late in the
 suite: the path is experimental (profiles/r2_notes.md)."""
 import pytest
 
