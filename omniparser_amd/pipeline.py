@@ -6,6 +6,7 @@ frame (the reference's list semantics, util/utils.py) -> the crops of ALL frames
 caption micro-batches (ref batch_size=128) -> on-device greedy decode.  Results equal a per-frame
 `get_som_labeled_img(...)[2]` call (same functions underneath); only the packing differs.
 """
+import os
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -226,6 +227,11 @@ class ScreenParser:
             # kernels followed it on the same stream (ROCm 7.2, profiles/r2_notes.md); eager launches of the same ops are fine
             if gs.fused is not None:
                 gs.fused.replay(det.stream)
+            elif os.environ.get("OMNI_DEVICE_GLUE_GRAPH", "0") == "1":
+                # experiment for the next GPU session: the arrangement that stalled (detector graph replay, then eager hand-off
+                # kernels), to be tried with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (ROCm's pre-recorded AQL packets for graph kernel nodes)
+                dp.launch(det)
+                gs.plan.run(det.stream)
             else:
                 dp.plan.run(det.stream)
                 gs.plan.run(det.stream)

@@ -50,6 +50,9 @@ tail -c 600 "$OUT/ab_device_glue.json"; echo
 echo "=== 6. device hand-off inside the detector graph (OMNI_DEVICE_GLUE=2: one graph, no launch between replays) — the very last GPU work of the call"
 ( OMNI_DEVICE_GLUE=2 OMNI_BENCH_WATCHDOG=40 timeout 90 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_device_glue2.json" 2> "$OUT/ab_device_glue2.err"; echo "device glue 2 -> exit $?" )
 tail -c 600 "$OUT/ab_device_glue2.json"; echo
+echo "=== 7. the stalling arrangement with ROCm's graph packet capture off (detector graph + eager hand-off kernels) — may stall: 60 s limit"
+( OMNI_DEVICE_GLUE=1 OMNI_DEVICE_GLUE_GRAPH=1 DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 OMNI_BENCH_WATCHDOG=30 timeout 60 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_device_glue_nocapture.json" 2> "$OUT/ab_device_glue_nocapture.err"; echo "device glue, graph, packet capture off -> exit $?" )
+tail -c 300 "$OUT/ab_device_glue_nocapture.json"; echo
 find "$OUT" -name "*_kernel_stats.csv" | head -3
 find "$OUT" -name "*.csv" -size +8M -delete
 find "$OUT" -name "*.db" -delete
