@@ -105,10 +105,18 @@ struct Block {
 inline thread_local Block* blk = nullptr;
 inline thread_local Fiber* cur = nullptr;
 
+// OMNI_EMU_ORDER=reverse runs the work-items of a workgroup in descending order between synchronisation points (default: ascending):
+// a missing barrier between "write my slot" and "read a neighbour's slot" shows under at least one of the two orders
+inline bool reverse_order() {
+  static const bool r = [] { const char* e = std::getenv("OMNI_EMU_ORDER"); return e && e[0] == 'r'; }();
+  return r;
+}
+inline int next_index(int i, int n) { return reverse_order() ? (i == 0 ? n - 1 : i - 1) : (i + 1 == n ? 0 : i + 1); }
+
 inline void yield() {
   Block& b = *blk;
   int nxt = cur->idx;
-  do { nxt = nxt + 1 == b.n ? 0 : nxt + 1; } while (!b.fibers[nxt].alive);
+  do { nxt = next_index(nxt, b.n); } while (!b.fibers[nxt].alive);
   if (nxt == cur->idx) return;
   Fiber* from = cur;
   cur = &b.fibers[nxt];
@@ -174,7 +182,7 @@ inline auto collective_ptr(const T& v, F&& f) {
     emu_switch(&dummy, b.sched_sp);
   } else {
     int nxt = me->idx;
-    do { nxt = nxt + 1 == b.n ? 0 : nxt + 1; } while (!b.fibers[nxt].alive);
+    do { nxt = next_index(nxt, b.n); } while (!b.fibers[nxt].alive);
     cur = &b.fibers[nxt];
     void* dummy;
     emu_switch(&dummy, cur->sp);
@@ -226,7 +234,7 @@ struct Worker {                               // one host thread: stacks for the
       f.sp = top - 8;
     }
     blk = &b;
-    cur = &b.fibers[0];
+    cur = &b.fibers[reverse_order() ? n - 1 : 0];
     emu_switch(&b.sched_sp, cur->sp);         // returns when the last work-item has exited
     blk = nullptr; cur = nullptr;
   }

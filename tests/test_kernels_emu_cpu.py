@@ -120,3 +120,21 @@ def test_presplit_gemm_accuracy_versus_activation_scale(emu):
         assert err < max(2e-6, 4 * 2.0 ** (-24 - e)), (e, err)       # representation limit: 2^-24 absolute per element
     assert seen[0][0] < 1e-6 and seen[-12][0] > seen[0][0]
     print(seen)
+
+
+def test_kernel_checks_also_pass_in_reverse_work_item_order():
+    """The emulation runs the work-items of a workgroup in ascending order between synchronisation points; OMNI_EMU_ORDER=reverse runs
+    them in descending order.  A missing __syncthreads / s_waitcnt between "write my slot" and "read a neighbour's" corrupts the
+    result under at least one of the two orders — so the kernel checks above (and the hand-off / overlay / PNG ones) must pass under
+    both.  (Own process: the order is read once per process.)"""
+    import os
+    import subprocess
+    import sys
+    from pathlib import Path
+    here = Path(__file__).resolve().parent
+    env = dict(os.environ, OMNI_EMU_ORDER="reverse")
+    r = subprocess.run([sys.executable, "-m", "pytest", "-x", "-q", "-p", "no:cacheprovider", "-k", "not reverse_work_item_order",
+                        str(here / "test_kernels_emu_cpu.py"), str(here / "test_glue_emu_cpu.py"), str(here / "test_overlay_png_emu_cpu.py")],
+                       env=env, capture_output=True, text=True, cwd=str(here.parent))
+    assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
+    assert " passed" in r.stdout and "failed" not in r.stdout
