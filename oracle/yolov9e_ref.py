@@ -277,8 +277,17 @@ def max_class_logits(model, x):
     return torch.cat(res)
 
 
+def calibrated_keys(state_dict):
+    """state_dict entries that the calibration of build_random_detector computes (everything else is the seeded initialisation):
+    BatchNorm running statistics and the last convolution of every class-head branch."""
+    import re
+    return [k for k in state_dict if k.endswith(("running_mean", "running_var", "num_batches_tracked")) or
+            re.fullmatch(r"head\.cv3\.\d+\.2\.(weight|bias)", k)]
+
+
 def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, margin_frames=(), calib_half=False, box_gain=1.0,
-                          bn_gain=0.25, bn_shift=0.5, calib_noisy=2, calib_random=1, calib_noise_std=0.1, calib_native=8):
+                          bn_gain=0.25, bn_shift=0.5, calib_noisy=2, calib_random=1, calib_noise_std=0.1, calib_native=8,
+                          calibration=None):
     """Seeded random YOLOv9-E that is WELL CONDITIONED, so that box-for-box parity can be asserted on every frame:
 
       * BatchNorm gains are small (gamma ~ 0.25) and shifts sizeable (beta ~ 0.5 randn): every Conv+BN+SiLU then works
@@ -319,6 +328,24 @@ def build_random_detector(seed=0, nc=1, width=1.0, pass_rate=0.15, conf=0.05, ma
             bins = torch.arange(16, dtype=torch.float32)
             seq[-1].bias.copy_((-(bins - 1.5) ** 2 / 1.5).repeat(4))
             seq[-1].weight.mul_(box_gain)
+        if calibration is not None:
+            # `calibration` = the tensors a previous run of the passes below produced (tools/standin_calibration/*.pt, a few MB):
+            # the same blob, bit for bit, on every box and in seconds — the calibration itself costs ~45 full CPU forward passes and
+            # its BatchNorm statistics depend on the host's reduction order in the last bits
+            model.eval()
+            for m in model.modules():
+                if isinstance(m, nn.BatchNorm2d):
+                    m.momentum = 0.03
+            sd = model.state_dict()
+            want = set(calibrated_keys(sd))
+            have = {k for k in calibration if k not in ("margin", "pass_rate")}
+            assert have == want, (sorted(want - have)[:5], sorted(have - want)[:5])
+            for k in want:
+                assert sd[k].shape == calibration[k].shape and sd[k].dtype == calibration[k].dtype, k
+                sd[k].copy_(calibration[k])
+            model.margin = float(calibration["margin"])
+            model.pass_rate = float(calibration["pass_rate"])
+            return model
         x = _calibration_input()
         xc = _calibration_input(noisy=calib_noisy, random_frames=calib_random, noise_std=calib_noise_std, native=calib_native) \
             if (calib_noisy or calib_random or calib_native) else x

@@ -52,9 +52,30 @@ def parity_inputs(width):
     return xs
 
 
+CALIB_DIR = ROOT / "tools" / "standin_calibration"
+
+
+def calibration_path(seed=0, nc=1, width=1.0):
+    return CALIB_DIR / f"v4_s{seed}_nc{nc}_w{width:g}.pt"
+
+
 def make_blob(path, seed=0, nc=1, width=1.0):
-    from oracle.yolov9e_ref import build_random_detector
-    model = build_random_detector(seed=seed, nc=nc, width=width, margin_frames=parity_inputs(width))
+    """Seeded initialisation + calibration.  The calibration results (BatchNorm statistics, class-head scale / threshold placement:
+    a few MB) are committed under tools/standin_calibration/, so a fresh box builds the SAME blob bit for bit in seconds instead of
+    re-running ~45 full-width CPU forward passes whose statistics differ in the last bits from host to host; without the file the
+    calibration runs and writes it."""
+    from oracle.yolov9e_ref import build_random_detector, calibrated_keys
+    cpath = calibration_path(seed, nc, width)
+    if cpath.exists() and os.environ.get("OMNI_RECALIBRATE", "0") != "1":
+        model = build_random_detector(seed=seed, nc=nc, width=width, calibration=torch.load(str(cpath), map_location="cpu"))
+    else:
+        model = build_random_detector(seed=seed, nc=nc, width=width, margin_frames=parity_inputs(width))
+        sd = model.state_dict()
+        calib = {k: sd[k].clone() for k in calibrated_keys(sd)}
+        calib["margin"] = torch.tensor(model.margin, dtype=torch.float64)
+        calib["pass_rate"] = torch.tensor(model.pass_rate, dtype=torch.float64)
+        cpath.parent.mkdir(parents=True, exist_ok=True)
+        torch.save(calib, str(cpath))
     path = Path(path)
     path.parent.mkdir(parents=True, exist_ok=True)
     with torch.no_grad():
