@@ -162,3 +162,22 @@ def test_foreign_architecture_fails_with_a_readable_message(tmp_path):
             return [self.c(x)] * 6
     with pytest.raises(BlobImportError, match="convolution units"):
         import_state_dict(_trace(Tiny(), tmp_path, "tiny.pt"))
+
+
+def test_standin_blob_is_rebuilt_bit_for_bit_from_committed_calibration(tmp_path):
+    """tools/make_weights.py: seeded initialisation + the committed calibration constants (tools/standin_calibration/*.pt) give the
+    same TorchScript blob state on every box — the frame lists of the parity tests (EXACT_FRAMES / WELL_FRAMES) were scanned on exactly
+    these weights.  The constants hold what the calibration computes and nothing else."""
+    import torch
+    from oracle.yolov9e_ref import YOLOv9E, calibrated_keys
+    from tools import make_weights as MW
+    for seed, nc, width in ((0, 1, 0.25), (0, 1, 0.5), (0, 1, 1.0), (1, 2, 0.25)):
+        assert MW.calibration_path(seed, nc, width).exists(), (seed, nc, width)
+    calib = torch.load(str(MW.calibration_path(0, 1, 0.25)), map_location="cpu")
+    want = set(calibrated_keys(YOLOv9E(nc=1, width=0.25).state_dict()))
+    assert set(calib) == want | {"margin", "pass_rate"} and len(want) == 900
+    out = tmp_path / "model.pt"
+    MW.make_blob(out, seed=0, nc=1, width=0.25)
+    a = torch.jit.load(str(out), map_location="cpu").state_dict()
+    b = torch.jit.load(str(MW.ensure_blob(seed=0, nc=1, width=0.25)), map_location="cpu").state_dict()
+    assert set(a) == set(b) and all(torch.equal(a[k], b[k]) for k in a)
