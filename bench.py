@@ -217,6 +217,8 @@ def main():
     if args.mode == "e2e":
         out["config"]["mean_crops_per_screenshot"] = round(sum(crop_counts) / max(len(crop_counts), 1) / B, 2)
         out["config"]["caption_micro_batch"] = 128
+        from omniparser_amd.florence import _BUCKETS
+        out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
 
     if rank == 0:
@@ -235,6 +237,13 @@ def main():
         if world == 1 and not args.no_extra:
             guarded("extra", lambda: extras(args, det, parser, frames, ocr, dev))
         if world == 1 and not args.no_extra and not args.no_ab and args.mode == "e2e" and isinstance(out.get("extra"), dict):
+            # this process is done with the GPU: give its activation pools back before the children build their own plans
+            try:
+                import gc
+                parser.cap._plans.clear(); det._plans.clear()
+                gc.collect(); torch.cuda.empty_cache()
+            except Exception:      # noqa: BLE001
+                pass
             # opt-in kernels that have never been timed, each in its OWN process with a hard limit (a fault or a stall there
             # cannot take this line with it): the format-B producers + the row-coalesced decode attention (compare
             # roofline.kernel_family_ms_per_step family by family with the line's own), and the annotate / PNG tail on the device

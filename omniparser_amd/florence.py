@@ -21,7 +21,7 @@ from . import _lib as L
 from .planner import PlanBuilder, View, torch_dtype
 
 PROMPT_IDS = [0, 2264, 473, 5, 2274, 6190, 116, 2]   # <s>What does the image describe?</s>  
-_BUCKETS = tuple(sorted({min(max(int(x), 1), 128) for x in os.environ.get("OMNI_CAPTION_BUCKETS", "8,16,32,64,128").split(",")} | {128}))
+_BUCKETS = tuple(sorted({min(max(int(x), 1), 128) for x in os.environ.get("OMNI_CAPTION_BUCKETS", "8,16,32,64,96,128").split(",")} | {128}))
 CLIP_MEAN = (0.485, 0.456, 0.406)
 CLIP_STD = (0.229, 0.224, 0.225)
 
@@ -466,8 +466,10 @@ class Florence2Captioner:
 
     @staticmethod
     def bucket(n: int) -> int:
-        """plan capacity for a micro-batch of n crops (rows beyond n are computed and ignored).  OMNI_CAPTION_BUCKETS adds sizes
-        (e.g. "8,16,32,64,96,128": a 93-crop tail then costs 96 rows instead of 128); every size is one more resident plan."""
+        """plan capacity for a micro-batch of n crops (rows beyond n are computed and ignored): powers of two plus 96 — the bench
+        step's 349 crops are 128 + 128 + 93, and a 96-row plan for that tail computes 8 % fewer rows per step than a third 128-row
+        one.  Every capacity is one more resident plan (60 GB of activations at 128 rows, 768x768 crops; at most OMNI_MAX_CAPTION_PLANS
+        stay resident), which is why the ladder is not finer; OMNI_CAPTION_BUCKETS overrides it."""
         for b in _BUCKETS:
             if n <= b:
                 return b
