@@ -557,9 +557,9 @@ def assert_detector_frame(rec, head_tol=HEAD_TOL, exact=False):
       5. on such a frame whose oracle NMS takes no decision on a tie: the final boxes match the oracle's one to one (IoU >= 0.999,
          same class, scores within 1e-5).  Greedy NMS is discontinuous: a suppression whose IoU lies within 1e-5 of the threshold
          (`near_ties`), or that is taken by a box whose score is within 4e-6 of its victim's (`score_ties`), comes out the other way
-         under a 1e-6 change of the candidates in ANY implementation, and on a lattice of equal boxes (flat GUI regions) one such
-         flip can move on to the neighbours — there 1-4 are the parity statement and the final boxes may differ by one exchanged box
-         per tie; on a frame that does not meet the fixed epsilon only the box count is compared.
+         under a 1e-6 change of the candidates in ANY implementation, and one such flip moves on to the neighbours (the oracle's own
+         final list changes by up to 10 boxes when its candidates are perturbed that much) — there 1-4 are the parity statement;
+         on a frame that does not meet the fixed epsilon only the box count is compared.
     exact=True: the caller picked the frame from the tie-free, well-conditioned list (tools/make_weights.py::EXACT_FRAMES, scanned on
     the CPU oracle), so 4 and 5 MUST apply — the test fails if they were skipped."""
     assert rec["input_mismatch"] == 0, rec
@@ -582,13 +582,26 @@ def assert_detector_frame(rec, head_tol=HEAD_TOL, exact=False):
         assert rec["n_ref"] == rec["n_gpu"] and rec["unmatched_boxes"] == 0 and rec["matched_is_bijection"], rec
         assert rec["matched_min_iou"] >= 0.999 and rec["matched_cls_equal"] and rec["matched_max_score_diff"] <= 1e-5, rec
     elif well:
-        # each tie may exchange one box for another (one oracle box and one device box left without a twin); perturbing the oracle's
-        # own candidates by the GPU-vs-oracle differences exchanges 0.1-0.4 boxes per tie (profiles/r2_parity_frame_scan.md)
-        ties = rec["near_ties"] + rec["score_ties"]
-        assert abs(rec["n_ref"] - rec["n_gpu"]) <= ties and rec["unmatched_boxes"] <= 2 * ties, rec
+        # The oracle decides a tie by the last bit of a score / an IoU, and greedy NMS passes a flipped decision on: perturbing the
+        # oracle's OWN candidates by the GPU-vs-oracle differences (1e-6 in the scores, 2e-4 px) changes its own final boxes on the
+        # bench frames with one or two ties by 0 (55-100 % of the trials), 4 or 10 boxes (tools/scan_parity_frames.py,
+        # profiles/r2_parity_frame_scan.md).  What parity means here is therefore 3 + 4 — identical candidates, and the reference's
+        # NMS applied to them reproduced bit for bit — both asserted above; against the oracle's own final list only what a tie cannot
+        # change is asserted: the count within the ill-conditioned bound, matched boxes with equal classes and scores.
+        assert abs(rec["n_ref"] - rec["n_gpu"]) <= max(3, 0.15 * rec["n_ref"]), rec
         assert rec["matched_cls_equal"] and rec["matched_max_score_diff"] <= 1e-5, rec
     else:
         assert abs(rec["n_ref"] - rec["n_gpu"]) <= max(3, 0.15 * rec["n_ref"]), rec
+
+
+def device_candidates(dp, bi):
+    """candidate records of frame `bi` of a detector plan (atomic compaction order) -> boxes, scores, classes, anchors in anchor
+    order = the order of the reference's boolean mask."""
+    n_c = int(dp.count[bi].item())
+    raw = dp.cand[bi].cpu()
+    recf = raw.view(torch.float32).view(-1, 8)[:n_c]; reci = raw.view(torch.int32).view(-1, 8)[:n_c]
+    order = torch.argsort(reci[:, 6])
+    return recf[order, 0:4].clone(), recf[order, 4].clone(), reci[order, 5].long(), reci[order, 6].long()
 
 
 def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, precision="f32", conf=0.05, iou=0.1,
@@ -642,10 +655,7 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
                "near_ties": int(dbg["near_ties"]), "score_ties": int(dbg["score_ties"])}
         # candidate level (decode + threshold): the device's records sorted by anchor index vs the oracle's masked anchors
         n_c = rec["cand_gpu"]
-        raw = dp.cand[0].cpu()
-        recf = raw.view(torch.float32).view(-1, 8)[:n_c]; reci = raw.view(torch.int32).view(-1, 8)[:n_c]
-        order = torch.argsort(reci[:, 6])
-        g_boxes, g_scores, g_cls, g_anchor = recf[order, 0:4].clone(), recf[order, 4].clone(), reci[order, 5].long(), reci[order, 6].long()
+        g_boxes, g_scores, g_cls, g_anchor = device_candidates(dp, 0)
         r_boxes, r_scores, r_cls = dbg["cand"]
         r_anchor = torch.nonzero(dbg["valid"]).flatten()
         same = n_c == len(r_anchor) and torch.equal(g_anchor, r_anchor)
@@ -1029,12 +1039,10 @@ def compare_frame_elements(f, elems_g, crops_g, el_r, cr_r, dbg, listed_exact, o
         out["crop_coords_off_by_one"] += off
         if off > 2 or left:
             problems.append(f"frame {f}: {off} crop coordinates off by one, {len(left)} device crops without a twin")
-    elif listed_exact:
-        # well-conditioned frame, but the oracle's NMS decides on ties: each may exchange one box for another
-        ties = int(dbg["near_ties"]) + int(dbg["score_ties"])
-        if missing > 2 * ties or abs(len(el_r) - len(elems_g)) > ties:
-            problems.append(f"frame {f}: {missing} oracle elements unmatched, {len(elems_g)} vs {len(el_r)} elements with {ties} NMS ties")
     elif abs(len(el_r) - len(elems_g)) > max(3, 0.15 * len(el_r)):
+        # the oracle's NMS decides on ties on this frame (its own element list changes by 3-4 elements in a third of the trials when
+        # its candidates are perturbed by 1e-6), or the frame is not on the well-conditioned list: against the ORACLE's list only the
+        # count is compared; the exact statement for such frames is `expected_from_device_candidates` in check_bench_path
         problems.append(f"frame {f}: {len(elems_g)} vs {len(el_r)} elements (ties {dbg['near_ties']}+{dbg['score_ties']})")
     out["matched_fraction"].append(round(1.0 - missing / max(len(el_r), 1), 4))
 
@@ -1074,12 +1082,38 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     detector_problems = []
     from tools.make_weights import WELL_FRAMES
     exact_frames = set(WELL_FRAMES.get((width, 640), ()))     # well-conditioned frames: exact when tie-free, one exchange per tie otherwise
+    dp = det.get_plan(IW, IH, 640, 0.05, 0.1, 300, batch=n_frames)          # still holds this batch's candidate records
+    out.update(cand_max_score_diff=0.0, cand_max_box_diff_px=0.0)
     for f in range(n_frames):
         rb, rs, rc, dbg = D.predict(cpu_model, Image.fromarray(imgs[f]), conf=0.05, imgsz=640, iou=0.1, max_det=300, return_debug=True)
         el_r, cr_r = sp.glue(rb, IW, IH, ocr[f][1], ocr[f][0])
         crops_r.append(cr_r)
         out["near_ties"].append(int(dbg["near_ties"]))
         out["elements"].append(len(el_r))
+        # (i) EVERY frame, ties or not: the same anchors pass the threshold with the same class, scores within 1e-5, boxes within
+        #     2e-3 px; and the frame's elements / crop rectangles ARE the reference's post-processing (restated batched_nms + clamp,
+        #     then the fixture-pinned hand-off) of the device's own candidates — exactly
+        g_boxes, g_scores, g_cls, g_anchor = device_candidates(dp, f)
+        r_boxes, r_scores, r_cls = dbg["cand"]
+        r_anchor = torch.nonzero(dbg["valid"]).flatten()
+        if f in exact_frames:
+            if len(g_anchor) != len(r_anchor) or not torch.equal(g_anchor, r_anchor) or not torch.equal(g_cls, r_cls):
+                detector_problems.append(f"frame {f}: candidate sets differ ({len(g_anchor)} vs {len(r_anchor)} anchors)")
+            else:
+                ds, db = (g_scores - r_scores).abs().max().item(), (g_boxes - r_boxes).abs().max().item()
+                out["cand_max_score_diff"] = max(out["cand_max_score_diff"], ds); out["cand_max_box_diff_px"] = max(out["cand_max_box_diff_px"], db)
+                if ds > 1e-5 or db > 2e-3:
+                    detector_problems.append(f"frame {f}: candidates differ by {ds:.2e} in the scores, {db:.2e} px in the boxes")
+        xb, xs, xc = _oracle_nms_clamp(g_boxes, g_scores, g_cls, 0.1, 300, IW, IH)
+        el_x, cr_x = sp.glue(xb, IW, IH, ocr[f][1], ocr[f][0])
+        same = len(el_x) == len(elems[f]) and all(
+            (a["type"], a["bbox"], a["source"], a["interactivity"]) == (b["type"], b["bbox"], b["source"], b["interactivity"]) and
+            (b["content"] is None or a["content"] == b["content"]) for a, b in zip(elems[f], el_x))
+        if not same or [list(c) for c in crops_g[f]] != [list(c) for c in cr_x]:
+            detector_problems.append(f"frame {f}: elements / crop rectangles are not the reference post-processing of the device's own "
+                                     f"candidates ({len(elems[f])} vs {len(el_x)} elements, {len(crops_g[f])} vs {len(cr_x)} crops)")
+        out.setdefault("expected_from_device_candidates", []).append(bool(same))
+        # (ii) against the ORACLE's own list: element for element where its NMS takes no decision on a tie
         compare_frame_elements(f, elems[f], crops_g[f], el_r, cr_r, dbg, f in exact_frames, out, detector_problems)
     if out["exact_frames"] < min(min_exact, n_frames):
         detector_problems.append(f"only {out['exact_frames']} frames compared element for element")

@@ -102,9 +102,11 @@ class RehearsalParser:
         from omniparser_amd.florence import CLIP_MEAN, CLIP_STD
         elems_all, crops_all, ids_out = [], [], []
         imgs = [f.cpu().numpy() for f in frames]
+        cands, counts = [], []
         for fi, img in enumerate(imgs):
             ih, iw = img.shape[:2]
             xy = self.det.predict(Image.fromarray(img), conf=self.conf, imgsz=self.imgsz, iou=self.nms_iou)[0].boxes.xyxy
+            cands.append(self.det.plan.cand[0]); counts.append(self.det.plan.count[0])
             texts, boxes = ocr[fi]
             el, cr = self.glue(xy, iw, ih, boxes, texts)
             rows = self.cap.oc.caption_crops(img, cr, max_new_tokens=20, batch_size=64) if cr else []
@@ -117,4 +119,5 @@ class RehearsalParser:
             x[j, :, :, :3] = torch.from_numpy(PR.caption_pixel_values(imgs[f], crops_all[f][k], R, CLIP_MEAN, CLIP_STD))
         self.cap.x_in[B] = x
         self.last_crops = crops_all
+        self.det.plan = types.SimpleNamespace(cand=torch.stack(cands), count=torch.stack(counts))      # the batch plan's candidate records
         return (elems_all, ids_out) if return_ids else elems_all

@@ -87,13 +87,20 @@ def test_rules_on_ill_conditioned_or_tied_frames(frame):
     # ...but 8x the noise is the limit
     with pytest.raises(AssertionError):
         G.assert_detector_frame(_rec(dbg, rb, rs, rc, rb, rs, rc, head_err=9e-3, noise=noise))
-    # a tie in the oracle's NMS: one box exchanged per tie, candidates still have to be identical
+    # a tie in the oracle's NMS: its own final list changes by up to 10 boxes under a 1e-6 perturbation of its candidates, so against
+    # that list only the count is bounded — identical candidates and the bit-exact NMS on them remain mandatory
     tied = dict(dbg); tied["score_ties"] = 1
     gb = rb.clone(); gb[10] += 3.0
     G.assert_detector_frame(_rec(tied, rb, rs, rc, gb, rs, rc))
     gb[11:14] += 3.0
+    G.assert_detector_frame(_rec(tied, rb, rs, rc, gb, rs, rc))
     with pytest.raises(AssertionError):
-        G.assert_detector_frame(_rec(tied, rb, rs, rc, gb, rs, rc))
+        G.assert_detector_frame(_rec(tied, rb, rs, rc, gb, rs, rc), exact=True)          # a listed frame must be tie-free
+    rec = _rec(tied, rb, rs, rc, gb, rs, rc); rec["nms_exact_on_gpu_candidates"] = False
+    with pytest.raises(AssertionError):
+        G.assert_detector_frame(rec)
+    with pytest.raises(AssertionError):
+        G.assert_detector_frame(_rec(tied, rb, rs, rc, rb[: len(rb) // 2], rs[: len(rb) // 2], rc[: len(rb) // 2]))
     rec = _rec(tied, rb, rs, rc, rb, rs, rc); rec["cand_max_score_diff"] = 1e-3
     with pytest.raises(AssertionError):
         G.assert_detector_frame(rec)
@@ -136,11 +143,13 @@ def test_bench_path_element_rules(frame):
     assert run(bad, cr_r)[1]
     crops = [list(c) for c in cr_r]; crops[3][0] += 2
     assert run(el_r, crops)[1]
-    # a listed frame whose oracle NMS decides on a tie: one exchanged element per tie, not more
+    # a listed frame whose oracle NMS decides on a tie: against the oracle's list only the count is bounded (the exact statement for
+    # such frames — elements == reference post-processing of the device's own candidates — lives in check_bench_path)
     tied = dict(dbg); tied["near_ties"] = 1
     out, problems = run(el_r[:-1], cr_r[:-1], d=tied)
     assert not problems and out["exact_frames"] == 0
-    assert run(el_r[:-4], cr_r, d=tied)[1]
+    assert not run(el_r[:-3], cr_r, d=tied)[1]
+    assert run(el_r[: len(el_r) // 2], cr_r, d=tied)[1]
     # outside the list (oracle ill conditioned there) only the element count is compared
     out, problems = run(el_r[:-2], cr_r[:-2], d=tied, listed=False)
     assert not problems and out["exact_frames"] == 0
