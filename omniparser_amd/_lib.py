@@ -40,7 +40,6 @@ class OmniError(RuntimeError):
 
 
 _lib = None
-EMULATION = False        # True only after bind_emulation(): the test suite's host build of the SAME device sources (tests/emu)
 
 
 def lib():
@@ -57,8 +56,9 @@ def lib():
 
 
 def bind(path):
-    """dlopen a library that implements include/omni_amd.h and declare its prototypes (libomni_amd.so; the test suite also binds the
-    host emulation tests/emu/libomni_emu.so, built from the same sources, to run the kernels without a GPU)."""
+    """dlopen a library that implements include/omni_amd.h and declare its prototypes.  The product binds libomni_amd.so (`lib()`);
+    the test suite also binds tests/emu/libomni_emu.so — the same device sources compiled for the host — by patching this module
+    from tests/emu/emu_runtime.py; nothing in the product does."""
     L = ctypes.CDLL(str(path))
     missing = [s for s in EXPORTS if not hasattr(L, s)]
     if missing:
@@ -94,27 +94,10 @@ def bind(path):
     return L
 
 
-def bind_emulation(path):
-    """TEST SUITE ONLY: route this process's C-ABI calls to tests/emu/libomni_emu.so — csrc/*.hip compiled for the host against an
-    emulation of the HIP / gfx950 constructs they use (work-items as fibers, waves as collectives, MFMA, LDS-DMA).  Pointers handed
-    to it are host pointers; Detector / captioner objects then accept device "cpu".  Returns the previous binding."""
-    global _lib, EMULATION
-    prev = (_lib, EMULATION)
-    _lib, EMULATION = bind(path), True
-    return prev
-
-
-def unbind_emulation(prev):
-    global _lib, EMULATION
-    _lib, EMULATION = prev
-
-
 def require_device(device, what):
-    """The product runs on the MI355X only: anything but a cuda device raises — unless the test suite has bound the host emulation."""
+    """The product runs on the MI355X only: anything but an available cuda device raises (no CPU fallback)."""
     import torch
     device = torch.device(device or ("cuda" if torch.cuda.is_available() else "cpu"))
-    if EMULATION:
-        return torch.device("cpu")
     if device.type == "cuda" and not torch.cuda.is_available():
         raise RuntimeError(f"CUDA device requested but unavailable: {device}")   # ref:util/yolov9.py:40-41
     if device.type != "cuda":

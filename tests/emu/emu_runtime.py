@@ -1,7 +1,7 @@
 """TEST INFRASTRUCTURE: run the product's device path on the host emulation of its own kernels (tests/emu/libomni_emu.so).
 
-`emulated_device()` binds the emulation library behind omniparser_amd._lib (so every omni_op_launch / plan call of the product
-lands in the host build of csrc/*.hip), makes the torch.cuda entry points the product's host code touches inert (streams are
+`emulated_device()` swaps the library bound behind omniparser_amd._lib for the emulation library (so every omni_op_launch / plan call
+of the product lands in the host build of csrc/*.hip) and its device gate for one that answers "cpu", makes the torch.cuda entry points the product's host code touches inert (streams are
 markers, synchronisation is a no-op: the emulation executes every launch synchronously) and switches plans to eager replay
 (hipGraph capture is a property of the HIP runtime, not of the kernels).  Tensors live in host memory; their `data_ptr()` is what
 the kernels dereference.  Nothing in the product imports this module."""
@@ -61,7 +61,10 @@ def emulated_device(env=None):
     import torch
     import build_emu
     from omniparser_amd import _lib as L
-    prev = L.bind_emulation(build_emu.build())
+    # the product has no emulation switch: the test suite swaps the bound library and the device gate of omniparser_amd._lib
+    prev = (L._lib, L.require_device)
+    L._lib = L.bind(build_emu.build())
+    L.require_device = lambda device, what: torch.device("cpu")
     saved = {k: getattr(torch.cuda, k) for k in ("is_available", "current_device", "synchronize", "Stream", "Event", "stream", "device",
                                                  "current_stream", "device_count")}
     torch.cuda.is_available = lambda: True
@@ -92,4 +95,4 @@ def emulated_device(env=None):
                 os.environ[k] = v
         for k, v in saved.items():
             setattr(torch.cuda, k, v)
-        L.unbind_emulation(prev)
+        L._lib, L.require_device = prev
