@@ -238,3 +238,19 @@ def test_bench_child_process_helper_reports_instead_of_raising():
     assert "no result within" in b.child_json([sys.executable, "-c", "import time; time.sleep(30)"], {}, 1)["error"]
     assert b.child_json([sys.executable, "-c", "import sys; sys.stderr.write('boom'); sys.exit(3)"], {}, 20)["error"].startswith("exit 3")
     assert "error" in b.child_json([sys.executable, "-c", "print('{not json')"], {}, 20)
+
+
+def test_product_objects_refuse_to_run_without_the_gpu():
+    """No CPU fallback: on a box without a GPU the detector / captioner constructors raise (before touching any weights), whatever
+    device string they are given; the emulation the test suite uses is bound from tests/emu/emu_runtime.py, not by the product."""
+    import torch
+    if torch.cuda.is_available():
+        pytest.skip("needs a box without a GPU")
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    for dev in (None, "cpu", "cuda"):
+        with pytest.raises(RuntimeError, match="no CPU fallback|unavailable"):
+            YOLOv9Detector(model_path="/nonexistent/model.pt", device=dev)
+        with pytest.raises(RuntimeError, match="no CPU fallback|unavailable"):
+            Florence2Captioner("/nonexistent", dev)
+    assert not hasattr(L, "bind_emulation") and not hasattr(L, "EMULATION")
