@@ -69,13 +69,18 @@ class ParseService:
             groups += [idx[k:k + max_group] for k in range(0, len(idx), max_group)]
         return sorted(groups, key=lambda g: g[0])
 
-    def _render(self, rgb: np.ndarray, elems: List[dict]) -> str:
+    def _render(self, rgb: np.ndarray, elems: List[dict], frame_dev=None) -> str:
         import torch
         from .util import utils as U
         if os.environ.get("OMNI_SKIP_ANNOTATE", "0") == "1":
             return ""
         h, w = rgb.shape[:2]
         boxes = torch.tensor([e["bbox"] for e in elems], dtype=torch.float32).reshape(-1, 4)
+        if frame_dev is not None and os.environ.get("OMNI_OVERLAY", "host") == "device":
+            # raster + PNG + base64 on the device, on the copy of the screenshot this request already uploaded (csrc/overlay_png.hip)
+            with torch.inference_mode():
+                return U.annotate_encode_device(rgb, U._box_convert_xyxy_to_cxcywh(boxes), list(range(len(elems))), frame_dev.device,
+                                                frame_dev=frame_dev, **overlay_style((w, h)))[0]
         frame, _ = U.annotate(rgb, U._box_convert_xyxy_to_cxcywh(boxes), None, list(range(len(elems))), **overlay_style((w, h)))
         return U.encode_png_b64(frame)
 
@@ -97,7 +102,10 @@ class ParseService:
             sp = self.screen_parser()
             frames = [torch.from_numpy(np.array(images[i], order="C")).to(sp.det.device) for i in group]
             elems = sp.parse_batch(frames, [ocrs[i] if ocrs[i] is not None else ([], []) for i in group])
-            pngs = list(self.pool.map(lambda a: self._render(*a), [(images[i], el) for i, el in zip(group, elems)]))
+            if os.environ.get("OMNI_OVERLAY", "host") == "device":
+                pngs = [self._render(images[i], el, fr) for i, el, fr in zip(group, elems, frames)]       # one stream: sequential
+            else:
+                pngs = list(self.pool.map(lambda a: self._render(*a), [(images[i], el) for i, el in zip(group, elems)]))
             dt = time.time() - t0
             for i, el, png in zip(group, elems, pngs):
                 results[i] = {"som_image_base64": png, "parsed_content_list": el, "latency": dt}

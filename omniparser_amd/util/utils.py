@@ -426,19 +426,21 @@ def png_deflate_device(frame: torch.Tensor, want_b64=True, stream=None):
 
 
 def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, device, text_scale=0.4, text_padding=5, text_thickness=2,
-                           thickness=3):
+                           thickness=3, frame_dev: Optional[torch.Tensor] = None):
     """`annotate` + `encode_png_b64` with the raster, the PNG packing and the base64 on the device (OMNI_OVERLAY=device): same
     layout (util/overlay.py::plan_overlay), same pixels as the host raster, stored-deflate PNG; the host uploads the frame and a
     few KB of primitives and reads back ASCII.  -> (base64 str, label_coordinates)."""
     from .overlay import BoxAnnotator, render_device
-    h, w, _ = image_np.shape
+    h, w = (image_np.shape if image_np is not None else frame_dev.shape)[:2]
     b = boxes * torch.Tensor([w, h, w, h])
     cx, cy, bw, bh = b.unbind(-1)
     xyxy = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, cx + 0.5 * bw, cy + 0.5 * bh), -1).numpy()
     xywh = torch.stack((cx - 0.5 * bw, cy - 0.5 * bh, bw, bh), -1).numpy()
     ann = BoxAnnotator(text_scale=text_scale, text_padding=text_padding, text_thickness=text_thickness, thickness=thickness)
     cmds = ann.plan(xyxy, [f"{i}" for i in range(b.shape[0])], (w, h))
-    frame = torch.from_numpy(np.array(image_np, order="C")).to(device)
+    # `frame_dev`: the caller's own uint8 [H,W,3] device copy of the screenshot (the batch route uploads one per request): drawn on
+    # in place, no second upload
+    frame = frame_dev if frame_dev is not None else torch.from_numpy(np.array(image_np, order="C")).to(device)
     render_device(frame, cmds)
     if os.environ.get("OMNI_PNG_DEVICE", "deflate") == "stored":
         _, b64 = png_pack_device(frame)

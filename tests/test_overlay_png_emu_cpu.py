@@ -107,3 +107,21 @@ def test_device_deflate_png_is_the_oracle_stream_and_decodes(emu, name, frame):
     assert b64[:nb64].numpy().tobytes() == base64.b64encode(data)
     if name in ("flat", "pixel runs"):
         assert total < frame.size // 20
+
+
+def test_batch_route_renders_on_the_request_s_device_frame(emu, monkeypatch):
+    """server.ParseService._render with OMNI_OVERLAY=device draws on the device copy of the screenshot that the batch route uploaded
+    (no second upload) and returns a PNG that decodes to what the host raster + Pillow PNG of the same elements decodes to."""
+    from omniparser_amd.server import ParseService
+    rng = np.random.default_rng(9)
+    rgb = rng.integers(0, 256, (120, 200, 3), dtype=np.uint8)
+    elems = [{"bbox": [0.1, 0.2, 0.4, 0.5]}, {"bbox": [0.5, 0.1, 0.95, 0.9]}, {"bbox": [0.0, 0.0, 0.02, 0.03]}]
+    svc = ParseService.__new__(ParseService)
+    monkeypatch.setenv("OMNI_OVERLAY", "host")
+    host = svc._render(rgb, elems)
+    monkeypatch.setenv("OMNI_OVERLAY", "device")
+    frame = torch.from_numpy(rgb.copy())
+    dev = svc._render(rgb, elems, frame)
+    a, b = (np.asarray(Image.open(io.BytesIO(base64.b64decode(x))).convert("RGB")) for x in (host, dev))
+    assert a.shape == (120, 200, 3) and np.array_equal(a, b) and not np.array_equal(a, rgb)
+    assert np.array_equal(frame.numpy(), a)                      # drawn in place on the request's frame
