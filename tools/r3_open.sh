@@ -21,11 +21,12 @@ for f in tests/test_gpu_a_kernels.py tests/test_gpu_b_caption_model.py tests/tes
   ( timeout 600 python -m pytest "$f" -q -p no:cacheprovider --durations=5 > "$OUT/$n.log" 2>&1; echo "exit $?" >> "$OUT/$n.log" )
   echo "--- $n"; grep -v "Warning\|warnings.warn\|^$\|_create_method\|^tests/test_gpu" "$OUT/$n.log" | tail -12 | cut -c1-1200
 done
-echo "=== 3. opt-in format-B producers"
+echo "=== 3. opt-in kernels, the power-of-two caption plan ladder (default now has a 96-row plan), pipelined steps"
 ( OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1 timeout 240 python -m pytest tests/test_gpu_b_caption_model.py -q -p no:cacheprovider -k "r64 or r768" 2>&1 | tail -3 | cut -c1-400 )
-for v in "OMNI_ATTN_SPLIT_OUT=1" "OMNI_FUSE_DWLN=1" "OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1" "OMNI_CAPTION_BUCKETS=8,16,32,64,96,128"; do
+for v in "OMNI_ATTN_SPLIT_OUT=1" "OMNI_FUSE_DWLN=1" "OMNI_ATTN_SPLIT_OUT=1 OMNI_FUSE_DWLN=1" "OMNI_DECODE_ATTN=2" "OMNI_CAPTION_BUCKETS=8,16,32,64,128" "OMNI_BENCH_FLAGS=--pipeline"; do
   tag=$(echo "$v" | tr ' =' '__')
-  ( env $v OMNI_BENCH_WATCHDOG=60 timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra > "$OUT/ab_$tag.json" 2> "$OUT/ab_$tag.err"; echo "$v -> exit $?" )
+  extra_flags=""; case "$v" in OMNI_BENCH_FLAGS=*) extra_flags="${v#OMNI_BENCH_FLAGS=}";; esac
+  ( env $v OMNI_BENCH_WATCHDOG=60 timeout 120 python bench.py --steps 3 --warmup 1 --no-cpu-baseline --no-extra $extra_flags > "$OUT/ab_$tag.json" 2> "$OUT/ab_$tag.err"; echo "$v -> exit $?" )
   python - "$OUT/ab_$tag.json" <<'PY'
 import json, sys
 try:
