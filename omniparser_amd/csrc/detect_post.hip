@@ -269,6 +269,8 @@ __global__ __launch_bounds__(64) void reduce_kernel(NmsArgs a, int max_words) {
   if (lane == 0) *a.out_count = kept_total < a.max_det ? kept_total : a.max_det;
 }
 
+__global__ void zero_count_kernel(int* count) { if (threadIdx.x == 0) *count = 0; }
+
 }  // namespace
 
 int omni_launch_detect_decode(const omni_op_t* op, hipStream_t s) {
@@ -291,7 +293,10 @@ int omni_launch_detect_decode(const omni_op_t* op, hipStream_t s) {
   a.cand = (Cand*)op->p[6]; a.count = (int*)op->p[7];
   OMNI_REQUIRE(a.cand && a.count && a.cap > 0, "detect_decode: null output");
   OMNI_REQUIRE(a.scale > 0.0f, "detect_decode: bad scale");
-  OMNI_HIP_CHECK(hipMemsetAsync(a.count, 0, sizeof(int), s));
+  // the candidate counter is reset by a KERNEL, not by hipMemsetAsync: a captured plan then consists of kernel nodes only (a memset
+  // node in the middle of the detector graph was the one non-kernel node of the graph whose second replay stalled in round 2,
+  // profiles/r2_notes.md)
+  hipLaunchKernelGGL(zero_count_kernel, dim3(1), dim3(64), 0, s, a.count);
   dim3 grid((tot + 255) / 256);
   if (op->dtype == OMNI_F32) hipLaunchKernelGGL(decode_kernel<float>, grid, dim3(256), 0, s, a);
   else if (op->dtype == OMNI_F16) hipLaunchKernelGGL(decode_kernel<half_t>, grid, dim3(256), 0, s, a);

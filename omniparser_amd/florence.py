@@ -112,6 +112,10 @@ class _CaptionPlans:
         # inputs written pre-split by their producers.  OMNI_GEMM_DMA=0 keeps every layer on the register-staged kernels.
         use_dma = dt == L.F32 and pb.split and os.environ.get("OMNI_GEMM_DMA", "1") != "0"
         self.use_dma = use_dma
+        # format B is decided per producer / consumer GROUP, not per layer: a DaViT stage (or the encoder) uses it only when EVERY
+        # linear layer fed by its LayerNorm / GELU / attention outputs takes the LDS-DMA GEMM (N % 128 == 0, K % 32 == 0), i.e. when
+        # the width is a multiple of 128 — true for all Florence-2 widths (128..1024, 768); narrower stand-ins stay on f32 tensors
+        grp = {"dma": use_dma}
 
         def packed(key, make, dma=False):
             ck = (key, dt, "dma") if dma else (key, dt)
@@ -139,7 +143,8 @@ class _CaptionPlans:
                 b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
                 return wt, b
             n_out, k_in = out.C, x.C
-            dma = use_dma and n_out % 128 == 0 and k_in % 32 == 0 and x.ld % 16 == 0 and x.coff % 16 == 0
+            dma = grp["dma"] and n_out % 128 == 0 and k_in % 32 == 0 and x.ld % 16 == 0 and x.coff % 16 == 0
+            assert dma or x.fmt != "split", f"{keys}: split input for a layer that cannot take the LDS-DMA GEMM"
             wp, bp = packed("|".join(keys), make, dma=dma)
             if dma and x.fmt != "split":
                 pb.split_convert(x)
@@ -153,7 +158,7 @@ class _CaptionPlans:
             split=<other View>: f32 into `out` AND format B into that view (post-LN rows that are also a residual)."""
             rows = x.B * x.H * x.W
             omode, y2 = 0, None
-            if use_dma and split is not None and x.C % 16 == 0:
+            if grp["dma"] and split is not None and x.C % 16 == 0:
                 omode, y2 = (1, None) if split is out else (2, split)
             pb.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[x.ptr, add.data_ptr() if add is not None else None,
                                                       f32(key + ".weight").data_ptr(), f32(key + ".bias").data_ptr(), out.ptr,
@@ -193,8 +198,8 @@ class _CaptionPlans:
             pb.add_op(L.make_op(L.OP_DWCONV3_LN, dt,
                                 p=[x.ptr, wp.data_ptr(), bp.data_ptr(), hout.ptr, y1.ptr,
                                    f32(norm_key + ".weight").data_ptr(), f32(norm_key + ".bias").data_ptr()],
-                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 6: 1 if (use_dma and x.C % 16 == 0) else 0}, f={0: 1e-5}))
-            hout.fmt = "split" if (use_dma and x.C % 16 == 0) else "f32"
+                                i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 6: 1 if grp["dma"] else 0}, f={0: 1e-5}))
+            hout.fmt = "split" if grp["dma"] else "f32"
             return hout
 
         # ---------------- input + vision tower
@@ -202,8 +207,10 @@ class _CaptionPlans:
         x = self.x_in
         vt = "model.vision_tower."
         self.chan_ws = None
+        self.stage_out = []          # output of every DaViT stage (stays valid after the encode plan: each stage owns its buffers)
         for s in range(4):
             C = w.embed_dim[s]
+            grp["dma"] = use_dma and C % 128 == 0
             k, st, pd = w.patch[s]
             Ho = (x.H + 2 * pd - k) // st + 1
             conv_key = f"{vt}convs.{s}.conv"
@@ -244,21 +251,23 @@ class _CaptionPlans:
                             L.OP_ATTN_ROWS, dt,
                             p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr, qb.data_ptr() + 4 * C, qb.data_ptr() + 8 * C],
                             i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
-                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if attn_split else 0},
+                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if (attn_split and grp["dma"]) else 0},
                             f={0: (C // w.heads[s]) ** -0.5}))
-                        att.fmt = "split" if attn_split else "f32"
+                        att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "window_attn.proj", att, B_, res=B_)
                     else:
                         linear(pre + "channel_attn.qkv", hbuf, qkv)
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
-                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if attn_split else 0}))
-                        att.fmt = "split" if attn_split else "f32"
+                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if (attn_split and grp["dma"]) else 0}))
+                        att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
                     linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU, out_split=True)
                     linear(pre + "ffn.fc2", ffn, A_, res=A_)
             x = A_
+            self.stage_out.append(A_)
         self.vision_out = x
+        grp["dma"] = use_dma
         # ---------------- projector
         mp = "model.multi_modal_projector."
         h = x.H
@@ -301,9 +310,10 @@ class _CaptionPlans:
         encpos = wc[ck]
         pb.keep.append(encpos)
         xa = pb.alloc(B, S, 1, D)
-        xs = pb.alloc(B, S, 1, D) if use_dma else None       # format-B twin of xa (xa itself stays f32: it is the residual)
+        dma_enc = grp["dma"] = use_dma and D % 128 == 0     # every encoder linear (K = D or 4D, N multiple of D) then takes the DMA GEMM
+        xs = pb.alloc(B, S, 1, D) if dma_enc else None        # format-B twin of xa (xa itself stays f32: it is the residual)
         layernorm(lm + "encoder.layernorm_embedding", enc, xa, add=encpos, period=S, split=xs)
-        xin = xs if use_dma else xa
+        xin = xs if dma_enc else xa
         qkv = pb.alloc(B, S, 1, 3 * D)
         att = pb.alloc(B, S, 1, D)
         tmp = pb.alloc(B, S, 1, D)
@@ -314,8 +324,8 @@ class _CaptionPlans:
             linear(None, xin, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
             pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
                                 i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
-                                   12: 0, 15: 64, 16: 1 if attn_split else 0}, f={0: 64 ** -0.5}))
-            att.fmt = "split" if attn_split else "f32"
+                                   12: 0, 15: 64, 16: 1 if (attn_split and dma_enc) else 0}, f={0: 64 ** -0.5}))
+            att.fmt = "split" if (attn_split and dma_enc) else "f32"
             linear(pre + "self_attn.out_proj", att, tmp, res=xa)
             layernorm(pre + "self_attn_layer_norm", tmp, xa, split=xs)
             linear(pre + "fc1", xin, ffn, act=L.ACT_GELU, out_split=True)

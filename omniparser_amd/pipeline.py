@@ -326,7 +326,11 @@ class ScreenParser:
     def caption_finish(self, handle):
         frames, flat, ids_all = handle
         cap = self.cap
-        ids_all = [cap._finish_ids(t.cpu().long()) for t in ids_all]     # single read-back point
+        # single read-back point.  The snapshots were produced on cap.stream (a non-blocking stream: the default stream does
+        # not order against it), so the copies are issued ON that stream — stream order alone makes them see the finished ids
+        with torch.cuda.stream(cap.stream):
+            ids_all = [t.cpu() for t in ids_all]
+        ids_all = [cap._finish_ids(t.long()) for t in ids_all]
         out = [[] for _ in frames]
         k = 0
         for ids in ids_all:

@@ -894,6 +894,153 @@ def check_captioner(R=64, n=5, seed=0, precision="f32", max_new=20):
     return out, cap
 
 
+# ------------------------------------------------------------------------------------------ real crops, plan capacities
+def real_crop_boxes(seed, n, iw=1920, ih=1080):
+    """n crop rectangles on synthetic_screenshot(seed): the icon-sized squares the generator drew (a detector-free stand-in for
+    the hand-off's crop list: same sizes, same content classes — flat panel, icon with glyph, text strip edges)."""
+    rng = np.random.default_rng(77 + seed)
+    out = []
+    for _ in range(n):
+        s = int(rng.integers(18, 96)); t = int(rng.integers(18, 96))
+        x0, y0 = int(rng.integers(0, iw - s)), int(rng.integers(0, ih - t))
+        out.append([x0, y0, x0 + s, y0 + t])
+    return out
+
+
+def _fill_rows(cap, cp, frame_dev, boxes, rows):
+    """device crop pre-processing (OMNI_OP_CROP_RESIZE) of boxes[i] into row rows[i] of the plan's input tensor."""
+    from omniparser_amd.florence import CLIP_MEAN, CLIP_STD
+    R = cp.R
+    H, W = frame_dev.shape[:2]
+    if cap._lut is None:
+        cap._lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32)).to(cap.device)
+        if R != 64:
+            b, k = L.resample_coeffs(64, R, 1)
+            cap._bic = (torch.from_numpy(b).to(cap.device), torch.from_numpy(k).to(cap.device), k.shape[1])
+    esz = 4 if cap.dtype == L.F32 else 2
+    keep = []
+    with torch.cuda.stream(cap.stream):
+        for bx_, r in zip(boxes, rows):
+            bx = torch.tensor([bx_], dtype=torch.int32).to(cap.device)
+            c64 = torch.empty((1, 64, 64, 3), dtype=torch.uint8, device=cap.device)
+            tmp = torch.empty((1, 64, R, 3), dtype=torch.uint8, device=cap.device) if R != 64 else None
+            bb, kk, ks = cap._bic if R != 64 else (None, None, 0)
+            op = L.make_op(L.OP_CROP_RESIZE, cap.dtype,
+                           p=[frame_dev.data_ptr(), bx.data_ptr(), c64.data_ptr(), tmp.data_ptr() if tmp is not None else None,
+                              cp.x_in.ptr + r * R * R * cp.x_in.ld * esz, bb.data_ptr() if bb is not None else None,
+                              kk.data_ptr() if kk is not None else None, cap._lut.data_ptr()],
+                           i={0: 1, 1: H, 2: W, 3: R, 4: ks, 13: cp.x_in.ld},
+                           f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
+            L.launch(op, cap.stream)
+            keep += [bx, c64, tmp]
+        cap.stream.synchronize()
+
+
+def _run_rows(cap, cp, rows, max_new, graph=True):
+    """encode + max_new decode steps of a plan; snapshots of the listed rows: input, every DaViT stage, image features, encoder
+    output, step-0 logits, ids."""
+    run = (lambda p: p.replay(cap.stream)) if (graph and cap.use_graph) else (lambda p: p.run(cap.stream))
+    idx = torch.tensor(rows, device=cap.device)
+    snap = {}
+    with torch.inference_mode(), torch.cuda.stream(cap.stream):
+        cp.reset()
+        run(cp.encode_plan)
+        snap["x_in"] = cp.x_in.t[idx][..., :3].float().cpu()
+        for s, v in enumerate(cp.stage_out):
+            snap[f"stage{s}"] = v.t[idx].float().cpu()
+        snap["img_feat"] = cp.img_feat.t[idx][:, :, 0, :].float().cpu()
+        snap["enc_out"] = cp.enc_out.t[idx][:, :, 0, :].float().cpu()
+        for t in range(max_new):
+            run(cp.step_plan)
+            if t == 1:        # step 0 is the forced BOS; step 1 is the first free arg-max
+                snap["logits1"] = cp.logits.t[idx][:, 0, 0, :].float().cpu()
+        cap.stream.synchronize()
+        snap["ids"] = cp.ids[idx].cpu().long()
+    return snap
+
+
+def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, standin=None):
+    """The SAME real crops through a `small`-row plan (n / small passes) and through ONE `large`-row plan (the checked crops at both
+    ends of the batch, every other row filled with other real crops): every intermediate tensor of a crop must not depend on the
+    plan capacity or on its row.  GPU vs GPU, no CPU oracle: seconds, and it bisects by construction (first divergent tensor)."""
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.synth import synthetic_screenshot
+    from tools.make_weights import CAPTION_STANDIN, ensure_caption_checkpoint
+    cap = Florence2Captioner(ensure_caption_checkpoint(0, standin or CAPTION_STANDIN), "cuda", precision="f32", resolution=R)
+    frame = torch.from_numpy(synthetic_screenshot(seed, 1920, 1080)).to(DEV)
+    boxes = real_crop_boxes(seed, large)
+    half = n // 2
+    rows_large = list(range(half)) + list(range(large - (n - half), large))      # both ends of the large batch
+    cpl = cap.plans(large, R, max_new)
+    _fill_rows(cap, cpl, frame, boxes, list(range(large)))
+    big = _run_rows(cap, cpl, rows_large, max_new)
+    checked = [boxes[r] for r in rows_large]
+    del cpl
+    cps = cap.plans(small, R, max_new)
+    parts = []
+    for s0 in range(0, n, small):
+        chunk = checked[s0:s0 + small]
+        _fill_rows(cap, cps, frame, chunk, list(range(len(chunk))))
+        parts.append(_run_rows(cap, cps, list(range(len(chunk))), max_new))
+    sm = {k: torch.cat([p_[k] for p_ in parts], 0) for k in parts[0]}
+    out = {"R": R, "n": n, "capacities": [small, large], "rows_large": rows_large}
+    first = None
+    for k in ("x_in", "stage0", "stage1", "stage2", "stage3", "img_feat", "enc_out", "logits1"):
+        a, b = sm[k], big[k]
+        d = (a - b).abs().max().item()
+        out[k] = {"max_abs": d, "rel": d / max(b.abs().max().item(), 1e-30), "bitwise": bool(torch.equal(a, b))}
+        if first is None and not torch.equal(a, b):
+            first = k
+    out["first_divergent"] = first
+    out["ids_equal"] = bool(torch.equal(sm["ids"], big["ids"]))
+    out["ids_rows_differ"] = int((sm["ids"] != big["ids"]).any(1).sum())
+    return out, cap
+
+
+def check_captioner_real_crops(R=768, n=4, seed=0, max_new=20, capacity=None, standin=None):
+    """Florence2Captioner on REAL caption inputs (device crop pre-processing of synthetic-screenshot rectangles: 64x64 bilinear,
+    bicubic to RxR — smooth, spatially coherent images, unlike randn) vs transformers on the CPU fed by the ORACLE's crop
+    pre-processing: pixel tensors bitwise, features / encoder output / logits, token-exact ids, arg-max margins."""
+    from oracle import preprocess_ref as PR
+    from omniparser_amd.florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS, Florence2Captioner
+    from omniparser_amd.synth import synthetic_screenshot
+    from tools.make_weights import CAPTION_STANDIN, build_random_captioner, ensure_caption_checkpoint, standin_scale
+    import caption_checks as CC
+    d = ensure_caption_checkpoint(0, standin or CAPTION_STANDIN)
+    model = build_random_captioner(0, chan_qk_scale=standin_scale(standin))
+    img = synthetic_screenshot(seed, 1920, 1080)
+    boxes = real_crop_boxes(seed, n)
+    pv = np.stack([PR.caption_pixel_values(img, b, R, CLIP_MEAN, CLIP_STD) for b in boxes])
+    pix = torch.from_numpy(pv).permute(0, 3, 1, 2).contiguous()
+    feats, enc, ids = CC.hf_reference(model, pix, max_new)
+    cap = Florence2Captioner(d, "cuda", precision="f32", resolution=R)
+    B = capacity or cap.bucket(n)
+    cp = cap.plans(B, R, max_new)
+    rows = list(range(B - n, B))                       # the LAST rows of the plan
+    _fill_rows(cap, cp, torch.from_numpy(img).to(DEV), boxes, rows)
+    got = _run_rows(cap, cp, rows, max_new)
+    cfg = model.config
+    n_img = (R // 32) ** 2 + 1
+    with torch.inference_mode():
+        ref = model.generate(input_ids=torch.tensor([[cfg.image_token_id] * n_img + PROMPT_IDS] * n), pixel_values=pix,
+                             max_new_tokens=max_new, num_beams=1, do_sample=False, output_logits=True, return_dict_in_generate=True)
+    lg1 = ref.logits[1].float()
+    top2 = lg1.topk(2, dim=1).values
+    T = ids.shape[1]
+    out = {"R": R, "n": n, "capacity": B, "x_in_bitwise": bool(torch.equal(got["x_in"], torch.from_numpy(pv))),
+           "feat_rel_err": rel_err(got["img_feat"], feats), "enc_rel_err": rel_err(got["enc_out"], enc),
+           "logit1_max_err": (got["logits1"][:, : lg1.shape[1]] - lg1).abs().max().item(),
+           "logit1_min_margin": (top2[:, 0] - top2[:, 1]).min().item(),
+           "ids_equal": bool(torch.equal(_pad_to(got["ids"], T, cap.w.pad)[:, :T], ids))}
+    return out, cap
+
+
+def _pad_to(ids, T, pad):
+    if ids.shape[1] >= T:
+        return ids
+    return torch.cat([ids, torch.full((ids.shape[0], T - ids.shape[1]), pad, dtype=ids.dtype)], 1)
+
+
 # ------------------------------------------------------------------------------------------ end to end
 class _OracleCaptioner:
     """CPU reference of the caption stage: oracle crop pre-processing + transformers Florence-2."""

@@ -60,3 +60,29 @@ def test_omniparser_facade_parse_roundtrip():
         assert e["type"] in ("text", "icon") and len(e["bbox"]) == 4 and isinstance(e["content"], str)
         assert all(0.0 <= v <= 1.0 for v in e["bbox"])
     assert any(e["source"] == "box_yolo_content_yolo" for e in elems) and any(e["type"] == "text" for e in elems)
+
+
+def test_plan_capacity_invariance_r768():
+    """The same 16 real crops through an 8-row plan and through the 128-row plan bench.py uses (60 GB of activations, tensors
+    beyond 2^31 elements, 18 k-tile GEMM launches): every stage output, the encoder output, the first free logits and the ids of
+    a crop must not depend on the plan capacity or on the crop's row."""
+    import gpu_checks as G
+    out, _ = G.check_plan_capacity(R=768, n=16, small=8, large=128)
+    print(out)
+    assert out["x_in"]["bitwise"], out
+    assert out["ids_equal"], out
+    for k in ("stage0", "stage1", "stage2", "stage3", "img_feat", "enc_out"):
+        assert out[k]["rel"] <= 1e-5, (k, out)
+    assert out["logits1"]["max_abs"] <= 1e-4, out
+
+
+def test_captioner_real_crops_token_exact_r768():
+    """randn-free twin of test_captioner_token_exact_r768: up-sampled screenshot crops (what the reference feeds Florence-2) in the
+    last rows of a 128-row plan vs transformers on the CPU."""
+    import gpu_checks as G
+    out, _ = G.check_captioner_real_crops(R=768, n=4, capacity=128)
+    print(out)
+    assert out["x_in_bitwise"], out
+    assert out["ids_equal"], out
+    assert out["feat_rel_err"] < 3e-4 and out["enc_rel_err"] < 3e-4, out
+    assert out["logit1_max_err"] < 0.1 * out["logit1_min_margin"], out
