@@ -399,6 +399,127 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(DwLnArgs a) {
   }
 }
 
+// Strip version of the fusion (f32 plans, C = 128 / 256 / 512 — DaViT stages 0-2, 97 % of the bytes of this op): the kernel above
+// re-reads the 3x3 neighbourhood of every pixel through L2 (one wave per pixel, nine row loads per output row), which is why it
+// lost to the two separate kernels in round 2 (142 ms vs 101 ms per step).  Here a thread owns NV 16-byte channel vectors of ONE
+// image column and slides down a strip of SR output rows with a rolling 3-row window in registers: every input row is loaded once
+// per strip (+2 halo rows per strip), the three horizontal taps are three loads of which two hit L1 (the neighbours' vectors),
+// the conv result never leaves registers before the LayerNorm statistics (LPP lanes per pixel: shuffles only), and both outputs
+// (x1 in f32 for the residual path, LN(x1) in format B or f32 for the GEMM) are written once.  HBM traffic: (1 + 2/SR) reads +
+// 2 writes per element instead of ~2.5 + 1 (dwconv3_strip_kernel with DW_ROWS = 4, measured) + 1 + 1 (layernorm).
+// Blocks are numbered so that horizontally adjacent blocks of a strip run on the SAME XCD (bid & 7 = XCD): their shared halo
+// columns then hit that XCD's L2.  Per-element arithmetic (tap order, (acc + bias) + centre, two-pass statistics) is the unfused
+// kernels': y1 is bit-identical to dwconv3_kernel, h equals layernorm_f32v4_kernel up to the summation order of the statistics.
+template <int NV, int LPP, bool OSPLIT>
+__global__ __launch_bounds__(256) void dwln_strip_kernel(DwLnArgs a, int SR, int pxb, int strips, unsigned nblocks) {
+  constexpr int PPB = 256 / LPP;                                  // pixels (columns) per block
+  const unsigned per = (gridDim.x + 7u) >> 3;
+  const unsigned L = (blockIdx.x & 7u) * per + (blockIdx.x >> 3);   // logical block: contiguous ranges per XCD
+  if (L >= nblocks) return;
+  const int pw = (int)(L % (unsigned)pxb);
+  const unsigned t = L / (unsigned)pxb;
+  const int strip = (int)(t % (unsigned)strips);
+  const int b = (int)(t / (unsigned)strips);
+  const int tid = threadIdx.x;
+  const int w = pw * PPB + tid / LPP, l = tid % LPP;
+  if (w >= a.W) return;                                           // whole LPP-lane groups leave together
+  const int h0 = strip * SR, h1 = min(h0 + SR, a.H);
+  const float* __restrict__ X = (const float*)a.x + (long long)b * a.H * a.W * a.C;
+  float* __restrict__ Y1 = (float*)a.y1 + (long long)b * a.H * a.W * a.C;
+  unsigned char* __restrict__ Hh = (unsigned char*)a.h + (long long)b * a.H * a.W * a.C * 4;
+  const float* __restrict__ Wt = (const float*)a.w;
+  f32x4 wt[9][NV], cb[NV], lg[NV], lb[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int c = (l + i * LPP) * 4;
+#pragma unroll
+    for (int k = 0; k < 9; ++k) wt[k][i] = *reinterpret_cast<const f32x4*>(Wt + k * a.C + c);
+    cb[i] = *reinterpret_cast<const f32x4*>(a.bias + c);
+    lg[i] = *reinterpret_cast<const f32x4*>(a.g + c);
+    lb[i] = *reinterpret_cast<const f32x4*>(a.b + c);
+  }
+  const bool wl = w > 0, wr = w + 1 < a.W;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  auto load_row = [&](int h, f32x4 (&dst)[3][NV]) {
+    const bool hok = h >= 0 && h < a.H;
+    const float* __restrict__ row = X + ((long long)(hok ? h : 0) * a.W + w) * a.C;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (l + i * LPP) * 4;
+      dst[0][i] = (hok && wl) ? *reinterpret_cast<const f32x4*>(row - a.C + c) : z4;
+      dst[1][i] = hok ? *reinterpret_cast<const f32x4*>(row + c) : z4;
+      dst[2][i] = (hok && wr) ? *reinterpret_cast<const f32x4*>(row + a.C + c) : z4;
+    }
+  };
+  f32x4 r0[3][NV], r1[3][NV], r2[3][NV], nx[3][NV];
+  load_row(h0 - 1, r0);
+  load_row(h0, r1);
+  load_row(h0 + 1, r2);
+  const float invC = 1.0f / (float)a.C;
+  for (int h = h0; h < h1; ++h) {
+    if (h + 1 < h1) load_row(h + 2, nx);                          // in flight under this row's arithmetic and stores
+    f32x4 y[NV];
+    float s = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      f32x4 acc = z4;
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc += wt[0 + q][i] * r0[q][i];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc += wt[3 + q][i] * r1[q][i];
+#pragma unroll
+      for (int q = 0; q < 3; ++q) acc += wt[6 + q][i] * r2[q][i];
+      y[i] = (acc + cb[i]) + r1[1][i];
+      s += (y[i][0] + y[i][1]) + (y[i][2] + y[i][3]);
+    }
+    const long long pix = (long long)h * a.W + w;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) *reinterpret_cast<f32x4*>(Y1 + pix * a.C + (l + i * LPP) * 4) = y[i];
+    const float mean = group_sum<LPP>(s) * invC;
+    float q2 = 0.0f;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const f32x4 d = y[i] - mean;
+      q2 += (d[0] * d[0] + d[1] * d[1]) + (d[2] * d[2] + d[3] * d[3]);
+    }
+    const float rstd = 1.0f / sqrtf(group_sum<LPP>(q2) * invC + a.eps);
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      const int c = (l + i * LPP) * 4;
+      float o[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = (y[i][e] - mean) * rstd * lg[i][e] + lb[i][e];
+      if constexpr (OSPLIT) {
+        uint2 hi, lo;
+        omni_split4(o, hi, lo);
+        unsigned char* p = Hh + pix * a.C * 4 + omni_split_off(c);
+        *reinterpret_cast<uint2*>(p) = hi;
+        *reinterpret_cast<uint2*>(p + 32) = lo;
+      } else {
+        *reinterpret_cast<f32x4*>(Hh + (pix * a.C + c) * 4) = f32x4{o[0], o[1], o[2], o[3]};
+      }
+    }
+#pragma unroll
+    for (int q = 0; q < 3; ++q)
+#pragma unroll
+      for (int i = 0; i < NV; ++i) { r0[q][i] = r1[q][i]; r1[q][i] = r2[q][i]; r2[q][i] = nx[q][i]; }
+  }
+}
+
+template <int NV, int LPP>
+void launch_dwln_strip(const DwLnArgs& a, hipStream_t s) {
+  constexpr int PPB = 256 / LPP;
+  const int pxb = (a.W + PPB - 1) / PPB;
+  // strip length: long strips re-read fewer halo rows (2 / SR); short ones keep >= ~1024 blocks in flight on small batches
+  int SR = 16;
+  while (SR > 4 && (long long)a.B * ((a.H + SR - 1) / SR) * pxb < 1024) SR >>= 1;
+  const int strips = (a.H + SR - 1) / SR;
+  const long long nb = (long long)a.B * strips * pxb;
+  const unsigned grid = (unsigned)(((nb + 7) / 8) * 8);
+  if (a.osplit) hipLaunchKernelGGL((dwln_strip_kernel<NV, LPP, true>), dim3(grid), dim3(256), 0, s, a, SR, pxb, strips, (unsigned)nb);
+  else hipLaunchKernelGGL((dwln_strip_kernel<NV, LPP, false>), dim3(grid), dim3(256), 0, s, a, SR, pxb, strips, (unsigned)nb);
+}
+
 // ------------------------------------------------------------------------------------ attn_rows
 struct AttnArgs {
   const void* q; const void* k; const void* v; void* o; const float* kbias; const float* vbias;
@@ -684,6 +805,178 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
   }
 }
 
+// Round-3 rewrite of the f32 window kernel for LATENCY: the kernel above walks global memory in dependent phases (seven staging
+// iterations with a load -> convert -> LDS-write chain each, then per query tile a Q load right in front of its first MFMA), with
+// three 3-wave blocks per CU nothing hid those round trips and it ran at 2.0 TB/s (profiles/r2_pmc_*: 25 % of HBM).  Same
+// arithmetic, same LDS image, same MFMA sequence per query tile — bit-identical output — but every global load of the block is
+// issued before the first use: the wave's three Q tiles first, then K (six 16-byte loads per thread) and V (four or eight);
+// V is transposed in registers per (4 keys x 4 channels) item so V^T goes to LDS as 8-byte writes instead of 2-byte ones.
+__global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
+  constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
+  unsigned char* Kh = lds;
+  unsigned char* Kl = lds + NKP * KROW;
+  unsigned char* Vh = lds + 2 * NKP * KROW;
+  unsigned char* Vl = Vh + D * VROW;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Qp = (const float*)a.q; const float* Kp = (const float*)a.k; const float* Vp = (const float*)a.v;
+  // window origin (uniform): token row of window-local index i = base + (i / 12) * W + i % 12 unless it falls outside the image
+  const int wpi = a.wy * a.wx;
+  const int b = g / wpi, wrem = g - b * wpi;
+  const int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
+  const int r0 = wyi * 12, c0 = wxi * 12;
+  auto row_of = [&](int i) -> long long {
+    const int r = r0 + i / 12, c = c0 + i % 12;
+    return (r >= a.H || c >= a.W) ? -1ll : ((long long)b * a.H + r) * a.W + c;
+  };
+  const int qc = lane & 15, grp = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- 1. all global loads of the block
+  f32x4 qraw[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const long long qrow = row_of((wave + 3 * t) * 16 + qc);
+    const float* qp = Qp + (qrow >= 0 ? qrow : 0) * a.ldq + a.qoff + h * D + grp * 8;
+    qraw[t][0] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp) : z4;
+    qraw[t][1] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp + 4) : z4;
+  }
+  f32x4 kraw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {                       // item e = (key, 4-channel group): 144 * 8 = 6 * 192
+    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
+    const long long row = row_of(key);
+    if (row >= 0) kraw[j] = *reinterpret_cast<const f32x4*>(Kp + row * a.ldk + a.koff + h * D + d0);
+    else kraw[j] = a.kbias ? f32x4{a.kbias[h * D + d0], a.kbias[h * D + d0 + 1], a.kbias[h * D + d0 + 2], a.kbias[h * D + d0 + 3]} : z4;
+  }
+  f32x4 vraw[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                       // item e = (key quad, 4-channel group): 36 * 8 = 288 = 192 + 96
+    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
+    if (e < 288) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = row_of(kq * 4 + u);
+        if (row >= 0) vraw[j][u] = *reinterpret_cast<const f32x4*>(Vp + row * a.ldv + a.voff + h * D + d0);
+        else vraw[j][u] = a.vbias ? f32x4{a.vbias[h * D + d0], a.vbias[h * D + d0 + 1], a.vbias[h * D + d0 + 2], a.vbias[h * D + d0 + 3]} : z4;
+      }
+    }
+  }
+  // ---- 2. LDS image: K rows (hi | lo), V^T rows (hi | lo), keys 144..159 zero
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
+    half_t kh[4], kl[4];
+#pragma unroll
+    for (int u = 0; u < 4; ++u) split1(kraw[j][u], kh[u], kl[u]);
+    *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = h16x4{kh[0], kh[1], kh[2], kh[3]};
+    *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = h16x4{kl[0], kl[1], kl[2], kl[3]};
+  }
+  if (tid < 128) {                                    // padding keys 144..159: 16 keys x 8 channel groups
+    const int key = 144 + (tid >> 3), d0 = (tid & 7) * 4;
+    const h16x4 zh = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
+    *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = zh;
+    *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = zh;
+  } else {                                            // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
+    const int r = tid - 128;                          // 0..63: (hi | lo, d)
+    unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(p) = z;
+    *reinterpret_cast<u32x4*>(p + 16) = z;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
+    if (e < 288) {
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
+        half_t vh[4], vl[4];
+#pragma unroll
+        for (int u = 0; u < 4; ++u) split1(vraw[j][u][dd], vh[u], vl[u]);
+        *reinterpret_cast<h16x4*>(Vh + (d0 + dd) * VROW + kq * 8) = h16x4{vh[0], vh[1], vh[2], vh[3]};
+        *reinterpret_cast<h16x4*>(Vl + (d0 + dd) * VROW + kq * 8) = h16x4{vl[0], vl[1], vl[2], vl[3]};
+      }
+    }
+  }
+  __syncthreads();
+
+  const float inv2048 = 1.0f / 2048.0f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int qt = wave + 3 * t;
+    h16x8 qh, ql;
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      half_t hh, ll;
+      split1(qraw[t][u >> 2][u & 3], hh, ll);
+      qh[u] = hh; ql[u] = ll;
+    }
+    float sc[40];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
+      h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+      h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
+      f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        int key = kt * 16 + grp * 4 + r;
+        float sv = (accM[r] + accC[r] * inv2048) * a.scale;
+        sv = key < 144 ? sv : -INFINITY;
+        sc[kt * 4 + r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 40; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    f32x4 oM[2], oC[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      h16x8 ph, pl;
+#pragma unroll
+      for (int u = 0; u < 8; ++u) {
+        half_t hh, ll;
+        split1(sc[(2 * j + (u >> 2)) * 4 + (u & 3)], hh, ll);
+        ph[u] = hh; pl[u] = ll;
+      }
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
+        h16x4 a0 = *reinterpret_cast<const h16x4*>(vr), a1 = *reinterpret_cast<const h16x4*>(vr + 32);
+        h16x4 b0 = *reinterpret_cast<const h16x4*>(vr + D * VROW), b1 = *reinterpret_cast<const h16x4*>(vr + D * VROW + 32);
+        h16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
+        h16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ql_ = grp * 4 + r;
+      const float rs = __shfl(sum, ql_);
+      const long long orow = row_of(qt * 16 + ql_);
+      if (orow >= 0) {
+        const float inv = 1.0f / rs;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          store_out<float>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, (oM[dt][r] + oC[dt][r] * inv2048) * inv, a.osplit);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ plain MHA on MFMA (BART encoder)
 // softmax(q k^T * scale) v for head_dim 64 and any key count (hf:models/bart/modeling_bart.py:143-257), flash-style:
 // keys are walked in blocks of 32 with an online softmax; both contractions use split-f16 MFMA exactly as in
@@ -940,6 +1233,125 @@ __global__ __launch_bounds__(256) void chan_apply_kernel(ChanArgs a) {
   }
 }
 
+// Round-3 channel attention for f32 plans (three kernels; the pair above stays for f16 plans and as the A/B reference).
+//   scores   S_partial[i][j] = sum_{n in chunk} q[n][i] k[n][j] on v_mfma_f32_32x32x2_f32 (exact f32 products, f32 accumulation):
+//            the MFMA's operand layout IS the memory layout — lane (i = lane & 31, t = lane >> 5) supplies q[n0 + t][i], so
+//            both operands go from global memory straight into the matrix core, one dword per lane per step, with no LDS and no
+//            VALU work.  The VALU kernel above read 20 B of LDS per 4 FMAs and was LDS-bound at 2.9 TB/s (profiles/r2_pmc_*).
+//            Four waves per (chunk, group, image) take a quarter of the chunk each and are summed in wave order through LDS.
+//   softmax  A = softmax_j(scale * sum_chunks S_partial) once per (image, group) — the apply kernel above recomputed it in every
+//            256-token block (36 x 4 KB of partials per block in stage 0); A overwrites the group's chunk-0 slot of the workspace.
+//   apply    out[n][i] = sum_j A[i][j] v[n][j], one token per thread: v as eight 16-byte loads (was 32 dword loads, each
+//            touching 64 cache lines per wave), A rows 16-byte aligned in LDS.  Same fma chain per output as before.
+__global__ __launch_bounds__(256) void chan_scores_mfma_kernel(ChanArgs a) {
+  __shared__ float red[4][1024];
+  const int chunk = blockIdx.x, g = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int n0c = chunk * a.chunk_tokens;
+  const int n1 = n0c + a.chunk_tokens < a.N ? n0c + a.chunk_tokens : a.N;
+  const int per = a.chunk_tokens / 4;                              // tokens per wave (chunk_tokens % 8 == 0)
+  const int nw0 = n0c + wave * per, nw1 = min(nw0 + per, n1);
+  const float* __restrict__ base = (const float*)a.qkv + (long long)b * a.N * 3 * a.C + g * 32 + (lane & 31);
+  const long long ld = 3ll * a.C;
+  f32x16 acc;
+#pragma unroll
+  for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
+  const int tsel = lane >> 5;
+  int n = nw0;
+  for (; n + 32 <= nw1; n += 32) {                                 // 16 MFMA steps (32 tokens) per trip: 32 loads in flight
+    const float* r = base + (long long)(n + tsel) * ld;
+    float qv[16], kv[16];
+#pragma unroll
+    for (int u = 0; u < 16; ++u) { qv[u] = r[2 * u * ld]; kv[u] = r[2 * u * ld + a.C]; }
+#pragma unroll
+    for (int u = 0; u < 16; ++u) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv[u], kv[u], acc, 0, 0, 0);
+  }
+  for (; n < nw1; n += 2) {                                        // ragged tail (small token counts)
+    const int tok = n + tsel;
+    const bool ok = tok < nw1;
+    const float* r = base + (long long)(ok ? tok : nw0) * ld;
+    const float qv = ok ? r[0] : 0.0f, kv = ok ? r[a.C] : 0.0f;
+    acc = __builtin_amdgcn_mfma_f32_32x32x2f32(qv, kv, acc, 0, 0, 0);
+  }
+  // D layout: col j = lane & 31, row i = (e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)
+#pragma unroll
+  for (int e = 0; e < 16; ++e) red[wave][((e & 3) + 8 * (e >> 2) + 4 * (lane >> 5)) * 32 + (lane & 31)] = acc[e];
+  __syncthreads();
+  float* out = a.ws + (((long long)b * a.G + g) * a.chunks + chunk) * 1024;
+  for (int e = threadIdx.x; e < 1024; e += 256) out[e] = ((red[0][e] + red[1][e]) + red[2][e]) + red[3][e];
+}
+
+__global__ __launch_bounds__(256) void chan_softmax_kernel(ChanArgs a) {
+  __shared__ float sa[32][33];
+  const int g = blockIdx.x, b = blockIdx.y;
+  float* p0 = a.ws + ((long long)b * a.G + g) * a.chunks * 1024;
+  const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
+  {
+    const float* p = p0 + i * 32 + j0;
+    float s[4] = {0.f, 0.f, 0.f, 0.f};
+    for (int c = 0; c < a.chunks; ++c)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) s[e] += p[(long long)c * 1024 + e];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) sa[i][j0 + e] = s[e] * a.scale;
+  }
+  __syncthreads();
+  if (threadIdx.x < 32) {
+    const int r = threadIdx.x;
+    float mx = -INFINITY;
+    for (int j = 0; j < 32; ++j) mx = fmaxf(mx, sa[r][j]);
+    float sum = 0.f;
+    for (int j = 0; j < 32; ++j) { float e = expf(sa[r][j] - mx); sa[r][j] = e; sum += e; }
+    const float inv = 1.0f / sum;
+    for (int j = 0; j < 32; ++j) sa[r][j] *= inv;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int e = 0; e < 4; ++e) p0[i * 32 + j0 + e] = sa[i][j0 + e];     // A over the chunk-0 partial of this (image, group)
+}
+
+__global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
+  __shared__ __attribute__((aligned(16))) float sa[32][36];
+  const int g = blockIdx.y, b = blockIdx.z;
+  {
+    const float* A = a.ws + ((long long)b * a.G + g) * a.chunks * 1024;
+    const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
+    *reinterpret_cast<f32x4*>(&sa[i][j0]) = *reinterpret_cast<const f32x4*>(A + i * 32 + j0);
+  }
+  __syncthreads();
+  const int n = blockIdx.x * 256 + threadIdx.x;
+  if (n >= a.N) return;
+  const float* vrow = (const float*)a.qkv + ((long long)b * a.N + n) * 3 * a.C + 2 * a.C + g * 32;
+  float v[32];
+#pragma unroll
+  for (int q = 0; q < 8; ++q) {
+    const f32x4 t = *reinterpret_cast<const f32x4*>(vrow + q * 4);
+    v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
+  }
+  float* orow = (float*)a.o + ((long long)b * a.N + n) * a.C + g * 32;
+  unsigned char* srow = (unsigned char*)a.o + (((long long)b * a.N + n) * a.C) * 4;
+#pragma unroll 2
+  for (int i4 = 0; i4 < 32; i4 += 4) {
+    float s4[4];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float s = 0.f;
+#pragma unroll
+      for (int j = 0; j < 32; ++j) s = fmaf(sa[i4 + e][j], v[j], s);
+      s4[e] = s;
+    }
+    if (a.osplit) {
+      uint2 hi, lo;
+      omni_split4(s4, hi, lo);
+      unsigned char* p = srow + omni_split_off(g * 32 + i4);
+      *reinterpret_cast<uint2*>(p) = hi;
+      *reinterpret_cast<uint2*>(p + 32) = lo;
+    } else {
+      *reinterpret_cast<f32x4*>(orow + i4) = f32x4{s4[0], s4[1], s4[2], s4[3]};
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ small glue kernels
 struct PrepArgs { const void* x; const float* pos; const float* temporal; void* y; int B, N, C; };
 
@@ -1040,55 +1452,81 @@ __global__ __launch_bounds__(64) void attn_decode_kernel(DecArgs a) {
   stf((T*)a.o + (long long)b * a.ldo + h * 64 + lane, acc / sum);
 }
 
-// Row-coalesced variant (OMNI_DECODE_ATTN=2, f32 plans; untimed so far): one wave per (b, group of 4 heads).  A lane owns one
-// float4 of the group's 256 channels, so every K / V row is read as ONE contiguous 1 KiB access per wave (the kernel above gives
-// each lane its own row: 64 rows per load instruction); the 16 lanes of a head reduce their partial dot products by shuffles.
-// Same arithmetic up to the summation order of the 64-term dot product.
-__global__ __launch_bounds__(64) void attn_decode_rows_kernel(DecArgs a) {
-  OMNI_DYN_LDS(float, sp);                    // [4][nk_pad] scores -> probabilities of the group's heads
-  const int g = blockIdx.x, b = blockIdx.y, lane = threadIdx.x;
-  const int hl = lane >> 4;                   // head within the group
-  const int C = a.ldc;
-  const int ch = g * 256 + lane * 4;          // first of this lane's 4 channels
-  float* Kc = (float*)a.kc + (long long)b * a.cap * C + ch;
-  float* Vc = (float*)a.vc + (long long)b * a.cap * C + ch;
-  int nk;
-  if (a.nk_fixed > 0) {
-    nk = a.nk_fixed;
-  } else {
-    const int st = *a.step;
-    nk = st + 1;
-    *reinterpret_cast<f32x4*>(Kc + (long long)st * C) = *reinterpret_cast<const f32x4*>((const float*)a.knew + (long long)b * a.ldn + a.koff + ch);
-    *reinterpret_cast<f32x4*>(Vc + (long long)st * C) = *reinterpret_cast<const f32x4*>((const float*)a.vnew + (long long)b * a.ldn + a.voff + ch);
-    __syncthreads();
-  }
-  const int nkp = (a.nk_fixed > 0 ? a.nk_fixed : a.cap) + 1;        // row pitch of sp
-  float* mine = sp + hl * nkp;
-  const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)a.q + (long long)b * a.ldq + a.qoff + ch);
+// Cross-attention of a decode step (nk_fixed keys, f32 plans), round 3.  The kernel above gives every lane its own K row (64 dword
+// loads per lane, 64 cache lines per load instruction) and runs one wave per (row, head): 1.5 waves per SIMD at 128 crops, 2.5 TB/s
+// on the 460 MB cross-KV of a step.  Here a block of four waves serves one (row, head); each wave takes a quarter of the keys and
+// reads FOUR keys per load instruction as four contiguous 256-byte rows (lane = (key j = lane >> 4, 16-byte slot lane & 15)), the
+// 16 lanes of a key reduce their partial dot products with four xor-shuffles, eight such loads are in flight per lane.  P.V uses
+// the same mapping (a lane accumulates its slot over its keys, the four key lanes are folded at the end) and the four waves are
+// summed in wave order through LDS.  Same softmax (expf, max-subtracted), different summation order than the kernel above.
+__global__ __launch_bounds__(256) void attn_decode_cross_kernel(DecArgs a) {
+  OMNI_DYN_LDS(float, sp);                    // [nk] scores -> probabilities, then 8 reduction slots, then [4][64] partial outputs
+  const int h = blockIdx.x, b = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int j = lane >> 4, d4 = (lane & 15) * 4;
+  const int nk = a.nk_fixed, C = a.ldc;
+  float* red = sp + ((nk + 3) & ~3);
+  float* part = red + 8;
+  const float* __restrict__ Kc = (const float*)a.kc + (long long)b * a.cap * C + h * 64 + d4;
+  const float* __restrict__ Vc = (const float*)a.vc + (long long)b * a.cap * C + h * 64 + d4;
+  const f32x4 q = *reinterpret_cast<const f32x4*>((const float*)a.q + (long long)b * a.ldq + a.qoff + h * 64 + d4);
+  const int per = ((nk + 15) >> 4) << 2;      // keys per wave, a multiple of 4
+  const int k0 = wave * per, k1 = min(k0 + per, nk);
   float mx = -INFINITY;
-  for (int k = 0; k < nk; ++k) {
-    const f32x4 kv = *reinterpret_cast<const f32x4*>(Kc + (long long)k * C);
-    float s = (q[0] * kv[0] + q[1] * kv[1]) + (q[2] * kv[2] + q[3] * kv[3]);
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  for (int kb = k0; kb < k1; kb += 32) {      // eight 4-key loads in flight; all 64 lanes stay in the loop for the shuffles
+    f32x4 kv[8];
 #pragma unroll
-    for (int o = 8; o > 0; o >>= 1) s += __shfl_xor(s, o);             // the 16 lanes of a head
-    s *= a.scale;
-    if ((lane & 15) == 0) mine[k] = s;
-    mx = fmaxf(mx, s);
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb + 4 * u + j;
+      kv[u] = k < k1 ? *reinterpret_cast<const f32x4*>(Kc + (long long)k * C) : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb + 4 * u + j;
+      float s = (q[0] * kv[u][0] + q[1] * kv[u][1]) + (q[2] * kv[u][2] + q[3] * kv[u][3]);
+      s += __shfl_xor(s, 8); s += __shfl_xor(s, 4); s += __shfl_xor(s, 2); s += __shfl_xor(s, 1);
+      s *= a.scale;
+      if (k < k1) {
+        if ((lane & 15) == 0) sp[k] = s;
+        mx = fmaxf(mx, s);
+      }
+    }
   }
+  mx = wave_max(mx);
+  if (lane == 0) red[wave] = mx;
   __syncthreads();
+  mx = fmaxf(fmaxf(red[0], red[1]), fmaxf(red[2], red[3]));
   float sum = 0.f;
-  for (int k = lane & 15; k < nk; k += 16) { const float e = expf(mine[k] - mx); mine[k] = e; sum += e; }
-#pragma unroll
-  for (int o = 8; o > 0; o >>= 1) sum += __shfl_xor(sum, o);
+  for (int k = tid; k < nk; k += 256) { const float e = expf(sp[k] - mx); sp[k] = e; sum += e; }
+  sum = wave_sum(sum);
+  if (lane == 0) red[4 + wave] = sum;
   __syncthreads();
+  sum = ((red[4] + red[5]) + red[6]) + red[7];
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
-  for (int k = 0; k < nk; ++k) {
-    const float pk = mine[k];
-    const f32x4 v = *reinterpret_cast<const f32x4*>(Vc + (long long)k * C);
-    acc[0] += pk * v[0]; acc[1] += pk * v[1]; acc[2] += pk * v[2]; acc[3] += pk * v[3];
+  for (int kb = k0; kb < k1; kb += 32) {
+    f32x4 vv[8];
+    float pk[8];
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      const int k = kb + 4 * u + j;
+      const bool ok = k < k1;
+      vv[u] = ok ? *reinterpret_cast<const f32x4*>(Vc + (long long)k * C) : z4;
+      pk[u] = ok ? sp[k] : 0.0f;
+    }
+#pragma unroll
+    for (int u = 0; u < 8; ++u) {
+      acc[0] += pk[u] * vv[u][0]; acc[1] += pk[u] * vv[u][1]; acc[2] += pk[u] * vv[u][2]; acc[3] += pk[u] * vv[u][3];
+    }
   }
-  f32x4 o4 = {acc[0] / sum, acc[1] / sum, acc[2] / sum, acc[3] / sum};
-  *reinterpret_cast<f32x4*>((float*)a.o + (long long)b * a.ldo + ch) = o4;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) { acc[e] += __shfl_xor(acc[e], 16); acc[e] += __shfl_xor(acc[e], 32); }
+  if (lane < 16) *reinterpret_cast<f32x4*>(part + wave * 64 + d4) = acc;
+  __syncthreads();
+  if (tid < 64) {
+    const float o = ((part[tid] + part[64 + tid]) + part[128 + tid]) + part[192 + tid];
+    ((float*)a.o)[(long long)b * a.ldo + h * 64 + tid] = o / sum;
+  }
 }
 
 // ------------------------------------------------------------------------------------ greedy_step
@@ -1297,6 +1735,14 @@ int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(!a.osplit || (op->dtype == OMNI_F32 && a.C % 16 == 0), "dwconv3_ln: split output needs an f32 plan and C %% 16 == 0");
   OMNI_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= 1024 && a.C % V == 0, "dwconv3_ln: bad shape (C <= 1024, C %% %d == 0)", V);
   a.pixels = (long long)a.B * a.H * a.W;
+  static const bool use_strip = !(getenv("OMNI_DWLN_STRIP") && atoi(getenv("OMNI_DWLN_STRIP")) == 0);
+  if (op->dtype == OMNI_F32 && use_strip && (a.C == 128 || a.C == 256 || a.C == 512) && (long long)a.B * a.H * a.W < (1ll << 31)) {
+    if (a.C == 128) launch_dwln_strip<1, 32>(a, s);
+    else if (a.C == 256) launch_dwln_strip<1, 64>(a, s);
+    else launch_dwln_strip<2, 64>(a, s);
+    OMNI_HIP_CHECK(hipGetLastError());
+    return OMNI_OK;
+  }
   unsigned blocks = (unsigned)((a.pixels + 3) / 4);
   int rc = by_dtype(op->dtype, "dwconv3_ln",
       [&] { hipLaunchKernelGGL(dwconv3_ln_kernel<float>, dim3(blocks), dim3(256), 0, s, a); },
@@ -1352,8 +1798,11 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(!a.osplit || (use_mfma && ((a.mode == 1 && D == 32) || (a.mode == 0 && D == 64))), "attn_rows: split output exists on the MFMA kernels only");
   if (a.mode == 1 && D == 32 && use_mfma) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
+    const char* wv = getenv("OMNI_WINDOW_ATTN");     // 1 = the round-2 kernel (A/B knob, read per launch; captured graphs keep theirs)
+    const bool v2 = !(wv && atoi(wv) == 1);
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<float>), grid, dim3(192), 0, s, a); },
+      [&] { if (v2) hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a);
+            else hipLaunchKernelGGL((window_attn_mfma_kernel<float>), grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
   } else if (a.mode == 1 && D == 32) {    // VALU fallback path (OMNI_ATTN_MFMA=0): 144 queries in one 192-thread workgroup
     dim3 grid(1, a.heads, a.groups);
@@ -1389,6 +1838,14 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   a.scale = 1.0f / sqrtf((float)a.N);
   if (op->f[0] != 0.0f) a.scale = op->f[0];
   dim3 g1(a.chunks, a.G, a.B), g2((a.N + 255) / 256, a.G, a.B);
+  const char* cv = getenv("OMNI_CHAN_ATTN");               // 1 = the round-2 kernel pair (A/B knob, read per launch)
+  if (op->dtype == OMNI_F32 && !(cv && atoi(cv) == 1) && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
+    hipLaunchKernelGGL(chan_scores_mfma_kernel, g1, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_softmax_kernel, dim3(a.G, a.B), dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
+    OMNI_HIP_CHECK(hipGetLastError());
+    return OMNI_OK;
+  }
   int rc = by_dtype(op->dtype, "chan_attn",
       [&] { hipLaunchKernelGGL(chan_scores_kernel<float>, g1, dim3(256), 0, s, a);
             hipLaunchKernelGGL(chan_apply_kernel<float>, g2, dim3(256), 0, s, a); },
@@ -1410,11 +1867,12 @@ static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.q && a.kc && a.vc && a.o && B > 0 && a.heads > 0 && a.C == a.heads * 64, "attn_decode: bad arguments (head_dim 64)");
   OMNI_REQUIRE(a.nk_fixed > 0 || (a.knew && a.vnew && a.step), "attn_decode: self-attention needs new k/v and the step counter");
   int nk_max = a.nk_fixed > 0 ? a.nk_fixed : a.cap;
-  const char* dv = getenv("OMNI_DECODE_ATTN");
-  const int variant = dv ? atoi(dv) : 1;
-  if (variant == 2 && op->dtype == OMNI_F32 && a.heads % 4 == 0 && a.ldc % 4 == 0 && a.ldq % 4 == 0 && a.qoff % 4 == 0 && a.ldo % 4 == 0 &&
-      (a.nk_fixed > 0 || (a.ldn % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0))) {
-    hipLaunchKernelGGL(attn_decode_rows_kernel, dim3(a.heads / 4, B), dim3(64), (size_t)4 * (nk_max + 1) * 4, s, a);
+  const char* dv = getenv("OMNI_DECODE_ATTN");             // 1 = the round-2 kernel for cross-attention too (A/B knob, read per launch)
+  const int variant = dv ? atoi(dv) : 0;
+  if (variant != 1 && a.nk_fixed > 0 && op->dtype == OMNI_F32 && a.ldc % 4 == 0 && a.ldq % 4 == 0 && a.qoff % 4 == 0) {
+    // cross-attention over the fixed encoder keys: four waves per (row, head), four keys per load instruction
+    const size_t lds = (size_t)(((a.nk_fixed + 3) & ~3) + 8 + 256) * 4;
+    hipLaunchKernelGGL(attn_decode_cross_kernel, dim3(a.heads, B), dim3(256), lds, s, a);
     OMNI_HIP_CHECK(hipGetLastError());
     return OMNI_OK;
   }

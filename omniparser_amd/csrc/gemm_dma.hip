@@ -38,11 +38,10 @@ struct GemmArgs {
   float oscale;                       // 2^-k of the weight pre-scale
 };
 
-// VAR: K-loop schedule.  1 (default) = DMA pieces spread over the units, ds_reads / DMA pieces interleaved one per MFMA
-// (sched_group_barrier); 0 = all DMA pieces of the next slice right after the barrier, next-unit ds_reads pinned in front of
-// each unit's 12 MFMAs (measured 1-6 % slower, profiles/r2_gemm_diag.md).  ABL (tools/gemm_bench.py diagnostics, results WRONG): 1 no DMA in the loop, 2 no DMA and no
-// barrier, 3 MFMA only (fragments loaded once), 4 no MFMA.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int VAR = 1, int ABL = 0>
+// K-loop schedule: the DMA pieces of the slice NSTAGE-1 ahead are spread over the units, ds_reads / DMA pieces interleaved one per
+// MFMA (sched_group_barrier).  The alternative schedule (all DMA pieces right after the barrier: 1-6 % slower) and the ablation
+// variants that led here are recorded in profiles/r2_gemm_diag.md; they are not compiled into the library.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -155,56 +154,37 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   int stage = 0, nstage = NSTAGE - 1;          // ring positions of slice kt and of slice kt + NSTAGE - 1
-  constexpr int PPU = (DPS + NU - 1) / NU;     // DMA pieces per unit (VAR 1)
+  constexpr int PPU = (DPS + NU - 1) / NU;     // DMA pieces per unit
   AF af[2];
   WF wf[2];
-  if constexpr (ABL == 3) {
-    OMNI_WAIT_VMCNT(0);
-    __builtin_amdgcn_s_barrier();
-    loadW(lds, 0, wf[0]); loadW(lds, 1, wf[1]); loadA(lds, 0, 0, af[0]); loadA(lds, 1, 0, af[1]);
-  }
   // One K slice.  MORE (compile time): a further slice is issued into the ring — the steady-state loop and the drain loop are
   // separate copies so that no branch splits the scheduling region (ds_reads / DMA pieces interleave with the MFMAs).
   auto slice = [&](int kt, auto more_tag) {
-    constexpr bool MORE = decltype(more_tag)::value && (ABL == 0 || ABL == 4);
+    constexpr bool MORE = decltype(more_tag)::value;
     // slice kt landed (this wave's pieces), later slices may stay in flight; then everybody's pieces landed and everybody is
     // done reading the stage that the next DMA overwrites (it was read in iteration kt - 1)
-    if constexpr (ABL != 2 && ABL != 3) {
-      if constexpr (NSTAGE > 2 && decltype(more_tag)::value) OMNI_WAIT_VMCNT((NSTAGE - 2) * DPS);
-      else OMNI_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
-    }
+    if constexpr (NSTAGE > 2 && MORE) OMNI_WAIT_VMCNT((NSTAGE - 2) * DPS);
+    else OMNI_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
     const unsigned char* st = lds + stage * STAGE;
-    if constexpr (ABL != 3) {
-      loadW(st, 0, wf[0]);
-      loadA(st, 0, 0, af[0]);
-    }
-    if constexpr (VAR == 0 && MORE) issue(kt + NSTAGE - 1, nstage);
+    loadW(st, 0, wf[0]);
+    loadA(st, 0, 0, af[0]);
 #pragma unroll
     for (int u = 0; u < NU; ++u) {
       const int g = u / NP, ip = u % NP;
       int nds = 0;
-      if (ABL != 3 && u + 1 < NU) {
+      if (u + 1 < NU) {
         const int g2 = (u + 1) / NP, ip2 = (u + 1) % NP;
         if (g2 != g) { loadW(st, g2, wf[g2 & 1]); nds += 2 * TN; }
         loadA(st, g2, ip2, af[(u + 1) & 1]);
         nds += 4;
       }
-      if constexpr (VAR == 1 && MORE) {
+      if constexpr (MORE) {
 #pragma unroll
         for (int i = u * PPU; i < (u + 1) * PPU && i < DPS; ++i) issue_piece(kt + NSTAGE - 1, nstage, i);
       }
-      if constexpr (VAR == 0) __builtin_amdgcn_sched_barrier(0);   // pin "next unit's ds_reads, then this unit's 12 MFMAs"
-      if constexpr (ABL != 4) mma(ABL == 3 ? af[g & 1] : af[u & 1], wf[g & 1], ip);
-      else {
-#ifndef OMNI_HOST_EMU
-#pragma unroll
-        for (int t = 0; t < 2; ++t) asm volatile("" ::"v"(af[u & 1].h[t]), "v"(af[u & 1].l[t]));
-#pragma unroll
-        for (int j = 0; j < TN; ++j) asm volatile("" ::"v"(wf[g & 1].h[j]), "v"(wf[g & 1].l[j]));
-#endif
-      }
-      if constexpr (VAR == 1) {
+      mma(af[u & 1], wf[g & 1], ip);
+      {
         // one ds_read (then one DMA piece) behind each of the first MFMAs: they issue inside the 32-cycle MFMA slots
         const int npc = MORE ? PPU : 0;
 #pragma unroll
@@ -313,19 +293,6 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  int var = 1, abl = 0;
-  if (const char* e = getenv("OMNI_GEMM_VAR")) var = atoi(e);
-  if (const char* e = getenv("OMNI_GEMM_ABL")) abl = atoi(e);
-  if (act == OMNI_ACT_NONE && !osplit && !res && (var != 1 || abl)) {  // schedule A/B + ablations (tools/gemm_bench.py): plain epilogue only
-#define OMNI_GD(V, A) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false, V, A>), grid, block, 0, s, a)
-    if (abl == 1) OMNI_GD(0, 1);
-    else if (abl == 2) OMNI_GD(0, 2);
-    else if (abl == 3) OMNI_GD(0, 3);
-    else if (abl == 4) OMNI_GD(0, 4);
-    else OMNI_GD(0, 0);
-#undef OMNI_GD
-    return OMNI_OK;
-  }
   if (act == OMNI_ACT_NONE && !osplit && !res)
     hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false>), grid, block, 0, s, a);
   else if (act == OMNI_ACT_NONE && !osplit && res)

@@ -180,13 +180,16 @@ class _CaptionPlans:
                                 i={0: x.B, 1: x.H, 2: x.W, 3: x.C}))
             return out
 
-        fuse_dwln = os.environ.get("OMNI_FUSE_DWLN", "0") == "1"    # measured neutral on MI355X in round 1 (6.87 vs 6.90 screenshots/s): opt-in
-        # OMNI_ATTN_SPLIT_OUT=1: the attention kernels write their output pre-split for the projection GEMM (no split_convert pass)
-        attn_split = use_dma and os.environ.get("OMNI_ATTN_SPLIT_OUT", "0") == "1" and os.environ.get("OMNI_ATTN_MFMA", "1") != "0"
+        # x + dwconv(x) and the LayerNorm behind it as ONE strip kernel (csrc/caption_ops.hip::dwln_strip_kernel) wherever it exists
+        # (f32 plans, C = 128 / 256 / 512: DaViT stages 0-2); OMNI_FUSE_DWLN=0 keeps the two separate kernels (A/B knob)
+        fuse_env = os.environ.get("OMNI_FUSE_DWLN", "1") == "1"
+        # the attention kernels write their output pre-split for the projection GEMM (no split_convert pass: 22.5 -> 0.3 ms per step on
+        # the MI355X, BENCH_r02 extra.ab_opt_in_kernels); OMNI_ATTN_SPLIT_OUT=0 = f32 output + in-place conversion (A/B knob)
+        attn_split = use_dma and os.environ.get("OMNI_ATTN_SPLIT_OUT", "1") != "0" and os.environ.get("OMNI_ATTN_MFMA", "1") != "0"
 
         def dwconv_ln(conv_key, norm_key, x: View, y1: View, hout: View):
             """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
-            if not fuse_dwln:
+            if not (fuse_env and dt == L.F32 and x.C in (128, 256, 512)):
                 dwconv(conv_key, x, y1)
                 return layernorm(norm_key, y1, hout, split=hout)      # hbuf only feeds qkv / fc1
             ck = (conv_key, dt)

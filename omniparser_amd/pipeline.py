@@ -32,7 +32,7 @@ class _GlueState:
     """Device side of the detect -> caption hand-off for one detector plan (batch B): fixed buffers + one small plan of B
     OMNI_OP_GLUE ops replayed right behind the detector graph on the detector's stream."""
 
-    def __init__(self, dp, det, iw, ih, thr, fused=False):
+    def __init__(self, dp, det, iw, ih, thr):
         dev, B, md = det.device, dp.batch, dp.out_boxes.shape[1]
         self.B, self.md = B, md
         with torch.cuda.stream(det.stream):
@@ -42,10 +42,7 @@ class _GlueState:
             self.crops = torch.zeros(B, md, 4, dtype=torch.int32, device=dev)
             self.counts = torch.zeros(B, 4, dtype=torch.int32, device=dev)
             self.donors = torch.zeros(B, md, MASK_WORDS, dtype=torch.int64, device=dev)
-        # plain (pageable) staging + blocking uploads (a few KB per frame).  Tried as a cure for the replay stall described in
-        # profiles/r2_notes.md (no event on the detector's stream between the upload and the graph launch) — it was not the cause;
-        # kept because it is the simplest correct form
-        self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64)
+        self.h_ocr = torch.zeros(B, OCR_CAP, 4, dtype=torch.float64)          # host staging of the per-frame OCR tables (a few KB)
         self.h_meta = torch.zeros(B, 2 + 2 * OCR_CAP, dtype=torch.int32)
         lo, hi = _f64_bits(thr)
         ops = [L.make_op(L.OP_GLUE, L.F32,
@@ -53,19 +50,23 @@ class _GlueState:
                             self.elems[b].data_ptr(), self.crops[b].data_ptr(), self.counts[b].data_ptr(), self.donors[b].data_ptr()],
                          i={0: md, 1: OCR_CAP, 2: iw, 3: ih, 4: MASK_WORDS, 5: 0, 6: md + OCR_CAP, 7: 1, 8: lo, 9: hi})
                for b in range(B)]
-        self.plan = L.Plan(ops)        # run eagerly (B one-workgroup launches, ~5 us each), like the detector plan on this path:
-        det.stream.synchronize()       # see detect_glue and profiles/r2_notes.md
-        # OMNI_DEVICE_GLUE=2 (untimed, next GPU session): detector ops AND hand-off ops in ONE plan, captured as ONE hipGraph — the
-        # stream then sees what the default path sees (uploads, graph launch, read-back) and no kernel launch between two replays,
-        # the arrangement that stalled
-        self.fused = None
-        if fused:
-            self.fused = L.Plan(list(dp.plan.ops) + ops)
-            if det.use_graph:
-                self.fused.run(det.stream)
-                det.stream.synchronize()
-                self.fused.capture(det.stream)
-                det.stream.synchronize()
+        # detector ops AND hand-off ops as ONE plan, captured as ONE hipGraph (kernel nodes only): one launch per batch.  Round 2
+        # saw the second replay of the detector graph stall whenever hand-off kernels followed it; the detector graph then held a
+        # hipMemsetAsync node (the candidate-counter reset of OMNI_OP_DETECT_DECODE).  With that reset done by a kernel both
+        # arrangements ran 100 consecutive replays on the MI355X with the host twin's results (profiles/r3_s1_handoff_graph_replays.jsonl)
+        self.plan = L.Plan(list(dp.plan.ops) + ops)
+        det.stream.synchronize()
+        if det.use_graph:
+            self.plan.run(det.stream)
+            det.stream.synchronize()
+            self.plan.capture(det.stream)
+            det.stream.synchronize()
+
+    def launch(self, det):
+        if det.use_graph:
+            self.plan.replay(det.stream)
+        else:
+            self.plan.run(det.stream)
 
 
 class ScreenParser:
@@ -74,10 +75,10 @@ class ScreenParser:
                  tile_large=False):
         self.det, self.cap = detector, captioner
         self.tile_large = tile_large      # False = reference behaviour (whole frame letterboxed to `imgsz`)
-        # detect -> caption hand-off: host twin (`glue`, numpy) by default; OMNI_DEVICE_GLUE=1 = on the device (csrc/glue_ops.hip)
-        import os
-        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") in ("1", "2")
-        self.fused_glue = os.environ.get("OMNI_DEVICE_GLUE", "0") == "2"
+        # detect -> caption hand-off ON THE DEVICE (csrc/glue_ops.hip, inside the detector's graph): boxes never visit the host between
+        # the stages.  OMNI_DEVICE_GLUE=0 = the host twin (`glue`: the reference's list code), also taken automatically for inputs
+        # beyond the kernel's capacities (more than 512 detections or 1024 OCR boxes per frame)
+        self.device_glue = os.environ.get("OMNI_DEVICE_GLUE", "1") != "0" and max_det <= 512
         self.proc = processor or (U.FlorenceProcessor(captioner.w.dir) if captioner is not None else None)
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
@@ -192,20 +193,18 @@ class ScreenParser:
         ih, iw = frames[0].shape[:2]
         det = self.det
         dp = det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
-        key = ("glue", float(self.iou_threshold), self.fused_glue)
+        ocr_els = [self.ocr_elements(iw, ih, *(reversed(ocr[fi]) if ocr is not None else ([], []))) for fi in range(len(frames))]
+        if any(len(els) > OCR_CAP for els in ocr_els):
+            return None                                   # beyond the kernel's OCR capacity: the caller takes the host twin
+        key = ("glue", float(self.iou_threshold))
         gs = getattr(dp, "_glue", {}).get(key)
         if gs is None:
             with torch.cuda.device(det.device):
-                gs = _GlueState(dp, det, iw, ih, self.iou_threshold, fused=self.fused_glue)
+                gs = _GlueState(dp, det, iw, ih, self.iou_threshold)
             dp._glue = {**getattr(dp, "_glue", {}), key: gs}
-        ocr_els = []
         gs.h_meta.zero_()
         for fi in range(len(frames)):
-            texts, boxes = ocr[fi] if ocr is not None else ([], [])
-            els = self.ocr_elements(iw, ih, boxes, texts)
-            if len(els) > OCR_CAP:
-                raise ValueError(f"{len(els)} OCR boxes exceed the device hand-off capacity ({OCR_CAP}); set OMNI_DEVICE_GLUE=0")
-            ocr_els.append(els)
+            els = ocr_els[fi]
             m = len(els)
             if m:
                 gs.h_ocr[fi, :m] = torch.tensor([e["bbox"] for e in els], dtype=torch.float64)
@@ -223,18 +222,7 @@ class ScreenParser:
                 dp.img[bi].copy_(f, non_blocking=True)
             gs.ocr.copy_(gs.h_ocr)
             gs.meta.copy_(gs.h_meta)
-            # the detector plan runs EAGERLY on this path: the second replay of its hipGraph never completed when the hand-off
-            # kernels followed it on the same stream (ROCm 7.2, profiles/r2_notes.md); eager launches of the same ops are fine
-            if gs.fused is not None:
-                gs.fused.replay(det.stream)
-            elif os.environ.get("OMNI_DEVICE_GLUE_GRAPH", "0") == "1":
-                # experiment for the next GPU session: the arrangement that stalled (detector graph replay, then eager hand-off
-                # kernels), to be tried with DEBUG_CLR_GRAPH_PACKET_CAPTURE=0 (ROCm's pre-recorded AQL packets for graph kernel nodes)
-                dp.launch(det)
-                gs.plan.run(det.stream)
-            else:
-                dp.plan.run(det.stream)
-                gs.plan.run(det.stream)
+            gs.launch(det)                                        # detector + hand-off: one graph
             counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
         return dp, gs, ocr_els, counts
 
@@ -407,8 +395,9 @@ class ScreenParser:
 
     def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih, pad_to=None):
         tiled = self.tile_large and (iw > 1952 or ih > 1112)
-        if self.device_glue and not tiled:
-            dp, gs, ocr_els, counts = self.detect_glue(frames, ocr, pad_to)
+        handed = self.detect_glue(frames, ocr, pad_to) if (self.device_glue and not tiled) else None
+        if handed is not None:
+            dp, gs, ocr_els, counts = handed
             n_crops = [int(counts[f, 1]) for f in range(len(frames))]
             # crop rectangles were produced on the detector's stream, which the counts read-back above has drained: no event needed
             caps = self.caption(frames, n_crops, crops_dev=gs.crops)

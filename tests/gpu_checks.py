@@ -12,6 +12,7 @@ import torch.nn.functional as F
 
 from omniparser_amd import _lib as L
 from omniparser_amd.planner import PlanBuilder, View
+from plan_interp import split_decode
 
 DEV = "cuda"
 
@@ -725,14 +726,26 @@ def check_caption_ops(dtype=L.F32, seed=0):
             os.environ.pop("OMNI_DWCONV_STRIP", None)
         assert torch.equal(g_strip["y"].view(torch.uint8), g_point["y"].view(torch.uint8)), f"dwconv3 strip != point kernel, C={C}"
     # fused dwconv3 + layernorm (C = 128 uses half a wave, C = 1024 all four vectors per lane)
-    for Cc in (128, 512, 1024):
-        Bq, Hq, Wq = 2, 7, 9
+    # C = 128 / 256 / 512 on f32 plans: the strip kernel (ragged strips, 1-pixel-wide and 1-row images, f32 and format-B output);
+    # otherwise one wave per pixel
+    for (Bq, Hq, Wq, Cc, osplit) in ((2, 7, 9, 128, 0), (2, 7, 9, 512, 0), (2, 7, 9, 1024, 0), (1, 21, 5, 256, 0), (3, 1, 9, 128, 1),
+                                     (1, 13, 1, 512, 1), (2, 18, 10, 256, 1)):
+        if osplit and dtype != L.F32:
+            continue
         t = {"x": R(Bq, Hq, Wq, Cc).to(tdt), "w": (R(3, 3, Cc) * 0.3).to(tdt), "b": R(Cc), "g": R(Cc), "be": R(Cc),
              "y1": torch.zeros(Bq, Hq, Wq, Cc, dtype=tdt), "h": torch.zeros(Bq, Hq, Wq, Cc, dtype=tdt)}
         c, gq = _op_pair(t, lambda P: L.make_op(L.OP_DWCONV3_LN, dtype, p=[P("x"), P("w"), P("b"), P("h"), P("y1"), P("g"), P("be")],
-                                                i={0: Bq, 1: Hq, 2: Wq, 3: Cc}, f={0: 1e-5}))
-        res[f"dwconv3_ln{Cc}_y1"] = _cmp(gq["y1"], c["y1"], tol, f"dwconv3_ln y1 C={Cc}")
-        res[f"dwconv3_ln{Cc}_h"] = _cmp(gq["h"], c["h"], tol * 5, f"dwconv3_ln h C={Cc}")
+                                                i={0: Bq, 1: Hq, 2: Wq, 3: Cc, 6: osplit}, f={0: 1e-5}))
+        res[f"dwconv3_ln{Cc}_{Hq}x{Wq}_y1"] = _cmp(gq["y1"], c["y1"], tol, f"dwconv3_ln y1 C={Cc}")
+        if osplit:
+            hg = split_decode(gq["h"].reshape(-1, Cc)); hc = split_decode(c["h"].reshape(-1, Cc))
+            res[f"dwconv3_ln{Cc}_{Hq}x{Wq}_hsplit"] = _cmp(hg, hc, tol * 5, f"dwconv3_ln split h C={Cc}")
+        else:
+            res[f"dwconv3_ln{Cc}_{Hq}x{Wq}_h"] = _cmp(gq["h"], c["h"], tol * 5, f"dwconv3_ln h C={Cc}")
+        if dtype == L.F32:      # y1 is bit-identical to the stand-alone depthwise conv kernel
+            _, g_dw = _op_pair({k_: v for k_, v in t.items() if k_ in ("x", "w", "b")} | {"y": torch.zeros_like(t["y1"])},
+                               lambda P: L.make_op(L.OP_DWCONV3, dtype, p=[P("x"), P("w"), P("b"), None, P("y")], i={0: Bq, 1: Hq, 2: Wq, 3: Cc}))
+            assert torch.equal(g_dw["y"], gq["y1"]), f"dwconv3_ln y1 != dwconv3 y, C={Cc}"
     # layernorm (+ add table), several widths
     for Cc in (128, 256, 512, 768, 1024):
         rows, period = 24, 6
@@ -758,6 +771,22 @@ def check_caption_ops(dtype=L.F32, seed=0):
                                                 i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
                                                    11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D}, f={0: D ** -0.5}))
         res[f"attn_window_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh}")
+        if dtype == L.F32:
+            # the latency-oriented kernel (default) is bit-identical to the round-2 kernel, also with format-B output
+            mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype,
+                                             p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
+                                             i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
+                                                11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D, 16: osplit}, f={0: D ** -0.5})
+            os.environ["OMNI_WINDOW_ATTN"] = "1"
+            try:
+                _, g_old = _op_pair(t, lambda P: mk(P, 0))
+            finally:
+                os.environ.pop("OMNI_WINDOW_ATTN", None)
+            assert torch.equal(g_old["o"], gq["o"]), f"window attention: default kernel != round-2 kernel, H={Hh}"
+            if Cm % 16 == 0:
+                cs, gs = _op_pair(t, lambda P: mk(P, 1))
+                assert torch.equal(gs["o"].view(torch.uint8), cs["o"].view(torch.uint8)) or \
+                    _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"window attention split out H={Hh}") is not None
     # channel attention
     Bq, N, G = 2, 2500, 4
     Cm = G * 32
@@ -766,6 +795,24 @@ def check_caption_ops(dtype=L.F32, seed=0):
     c, gq = _op_pair(t, lambda P: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
                                             i={0: Bq, 1: N, 3: Cm, 4: G, 5: 1024}))
     res["chan_attn"] = _cmp(gq["o"], c["o"], tol * 10, "channel attention")
+    if dtype == L.F32:
+        # f32 plans: MFMA scores + one softmax per (image, group) + vector-load apply (default) vs the round-2 kernel pair, and the
+        # format-B output; a token count that is a multiple of the 32-token MFMA trip (the real shapes) and a tiny one (R = 64)
+        for (Bq2, N2) in ((2, 2500), (1, 4096), (3, 16)):
+            ch2 = (N2 + 1023) // 1024
+            t2 = {"qkv": R(Bq2 * N2, 3 * Cm).to(tdt), "o": torch.zeros(Bq2 * N2, Cm, dtype=tdt), "ws": torch.zeros(Bq2 * G * ch2 * 1024)}
+            mk = lambda P, osplit: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
+                                             i={0: Bq2, 1: N2, 3: Cm, 4: G, 5: 1024, 6: osplit})
+            c2, g_new = _op_pair(t2, lambda P: mk(P, 0))
+            res[f"chan_attn_{N2}"] = _cmp(g_new["o"], c2["o"], tol * 10, f"channel attention N={N2}")
+            os.environ["OMNI_CHAN_ATTN"] = "1"
+            try:
+                _, g_old = _op_pair(t2, lambda P: mk(P, 0))
+            finally:
+                os.environ.pop("OMNI_CHAN_ATTN", None)
+            _cmp(g_new["o"], g_old["o"], tol, f"channel attention: default kernels vs round-2 pair, N={N2}")
+            cs, gs = _op_pair(t2, lambda P: mk(P, 1))
+            _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 10, f"channel attention split out N={N2}")
     # proj_prep / assemble
     Bq, N, Cm = 2, 36, 256
     t = {"x": R(Bq, N, Cm).to(tdt), "pos": R(N, Cm), "tmp": R(Cm), "y": torch.zeros(Bq, N + 1, Cm, dtype=tdt)}
@@ -789,6 +836,19 @@ def check_caption_ops(dtype=L.F32, seed=0):
     c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_DECODE, dtype, p=[P("q"), None, None, P("kv"), P("o"), P("kv", Cm * esz), None],
                                             i={0: Cm, 1: 0, 5: Cm, 6: heads, 7: S, 8: S, 9: Cm, 10: Bq, 11: 2 * Cm}, f={0: 0.125}))
     res["attn_decode_cross"] = _cmp(gq["o"], c["o"], tol * 5, "attn_decode cross")
+    for S2 in (585, 3, 130):                  # encoder length at 768x768 crops; fewer keys than waves; ragged quarter
+        t = {"q": R(Bq, Cm).to(tdt), "kv": R(Bq, S2, 2 * Cm).to(tdt), "o": torch.zeros(Bq, Cm, dtype=tdt)}
+        mk = lambda P: L.make_op(L.OP_ATTN_DECODE, dtype, p=[P("q"), None, None, P("kv"), P("o"), P("kv", Cm * esz), None],
+                                 i={0: Cm, 1: 0, 5: Cm, 6: heads, 7: S2, 8: S2, 9: Cm, 10: Bq, 11: 2 * Cm}, f={0: 0.125})
+        c, gq = _op_pair(t, mk)
+        res[f"attn_decode_cross_{S2}"] = _cmp(gq["o"], c["o"], tol * 5, f"attn_decode cross S={S2}")
+        if dtype == L.F32:                    # the four-wave kernel (default) vs the round-2 one-wave kernel
+            os.environ["OMNI_DECODE_ATTN"] = "1"
+            try:
+                _, g_old = _op_pair(t, mk)
+            finally:
+                os.environ.pop("OMNI_DECODE_ATTN", None)
+            _cmp(gq["o"], g_old["o"], tol, f"attn_decode cross: default vs round-2 kernel, S={S2}")
     # embed_step + greedy_step (ngram ban, forced tokens, finished rows)
     Bq, Vv, T, Cm = 4, 1000, 21, 64
     ids = torch.zeros(Bq, T, dtype=torch.int32); ids[:, 0] = 2

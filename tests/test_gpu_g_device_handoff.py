@@ -1,6 +1,6 @@
-"""`-m gpu`: the opt-in device-side detect -> caption hand-off (OMNI_DEVICE_GLUE=1, csrc/glue_ops.hip) — the kernel against the fixtures
-recorded from the reference's own functions and against the host twin, then through `ScreenParser.parse_batch`.  Late in the
-suite: the path is experimental (profiles/r2_notes.md)."""
+"""`-m gpu`: the device-side detect -> caption hand-off (csrc/glue_ops.hip; the default of `ScreenParser`, OMNI_DEVICE_GLUE=0 = host
+twin) — the kernel against the fixtures recorded from the reference's own functions and against the host twin, then through
+`ScreenParser.parse_batch`, then 30 consecutive replays of the detector + hand-off graph."""
 import pytest
 
 pytestmark = pytest.mark.gpu
@@ -14,10 +14,8 @@ def test_device_handoff_matches_reference_fixtures_and_host_twin():
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(monkeypatch):
-    """same frames through parse_batch with the hand-off on the device (OMNI_DEVICE_GLUE=1) and on the host (default): identical element
-    lists, crop rectangles and caption ids.  (The device path launches the detector plan eagerly: a second replay of the detector
-    hipGraph followed by the hand-off kernels did not complete on ROCm 7.2 — profiles/r2_notes.md — which is also why the device
-    hand-off is opt-in.)"""
+    """same frames through parse_batch with the hand-off on the device (default: detector + hand-off ops captured as ONE hipGraph) and
+    on the host (OMNI_DEVICE_GLUE=0): identical element lists, crop rectangles and caption ids."""
     import torch
     from omniparser_amd.florence import Florence2Captioner
     from omniparser_amd.pipeline import ScreenParser
@@ -38,3 +36,27 @@ def test_parse_batch_device_handoff_equals_host_handoff(monkeypatch):
         res[mode] = (elems, [[r.tolist() for r in f] for f in ids], sp.last_crops)
     assert res["1"][0] == res["0"][0] and res["1"][2] == res["0"][2] and res["1"][1] == res["0"][1]
     assert sum(len(c) for c in res["1"][2]) > 50
+
+
+def test_handoff_graph_replays_stay_correct():
+    """30 consecutive replays of the detector + hand-off graph over rotating frames: every replay's crop rectangles equal the host
+    twin's for the same detector boxes (round 2 saw the SECOND replay stall while the detector graph still held a memset node)."""
+    import torch
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob
+    det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.5), device="cuda", precision="f32")
+    sp = ScreenParser(det, None, processor=object(), box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640)
+    assert sp.device_glue and det.use_graph
+    frames = [torch.from_numpy(synthetic_screenshot(s, 1920, 1080)).cuda() for s in range(4)]
+    ocr = [synthetic_ocr(s, 1920, 1080, 40) for s in range(4)]
+    for it in range(30):
+        rot = it % 4
+        fr, oc = frames[rot:] + frames[:rot], ocr[rot:] + ocr[:rot]
+        dp, gs, ocr_els, counts = sp.detect_glue(fr, oc)
+        assert gs.plan.captured
+        boxes, kc = dp.out_boxes.cpu(), dp.out_count.cpu()
+        for f in range(4):
+            el, cr = sp.glue(boxes[f, : int(kc[f])], 1920, 1080, oc[f][1], oc[f][0])
+            assert [list(c) for c in cr] == gs.crops[f, : int(counts[f, 1])].tolist(), (it, f)

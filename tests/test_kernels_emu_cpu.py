@@ -77,15 +77,6 @@ def test_caption_kernels_vs_interpreter(emu, dtype):
     G.check_caption_ops(dtype)
 
 
-def test_caption_kernels_with_row_coalesced_decode_attention(emu, monkeypatch):
-    """OMNI_DECODE_ATTN=2 (attn_decode_rows_kernel: one wave per 4 heads, K / V rows read as contiguous 1 KiB accesses; opt-in,
-    untimed): same checks as the default kernel — self attention with the cache append, cross attention."""
-    import gpu_checks as G
-    monkeypatch.setenv("OMNI_DECODE_ATTN", "2")
-    r = G.check_caption_ops(L.F32)
-    assert r["attn_decode_self"] < 1e-5 and r["attn_decode_cross"] < 1e-5
-
-
 def test_presplit_gemm_accuracy_versus_activation_scale(emu):
     """Format B stores an activation as hi + lo with BOTH halves f16: once |x| < 2^-4 the lo half is subnormal and the pair resolves
     x to 2^-24 absolute, i.e. 2^-24 / |x| relative.  f32-class accuracy therefore holds for O(1) activations — LayerNorm outputs,

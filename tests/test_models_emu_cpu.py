@@ -38,14 +38,16 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     assert G.rel_err(cp.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
     assert G.rel_err(cp.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
     assert got.shape == ids.shape and torch.equal(got, ids), (got, ids)
-    # the opt-in format-B producers (attention / channel attention / fused dwconv + LayerNorm write the split operand of the next
-    # GEMM directly: OMNI_ATTN_SPLIT_OUT, OMNI_FUSE_DWLN — untimed on the MI355X so far): same features, encode pass only
-    monkeypatch.setenv("OMNI_ATTN_SPLIT_OUT", "1")
-    monkeypatch.setenv("OMNI_FUSE_DWLN", "1")
+    # default plan: attention / channel attention write format B themselves and x + dwconv(x) -> LayerNorm is ONE kernel in stages
+    # 0-2; with both switched off (the round-2 composition: separate dwconv / LayerNorm kernels, f32 attention output converted in
+    # place) the same features come out — encode pass only
+    assert any(op.kind == L.OP_DWCONV3_LN for op in cp.encode_plan.ops)
+    monkeypatch.setenv("OMNI_ATTN_SPLIT_OUT", "0")
+    monkeypatch.setenv("OMNI_FUSE_DWLN", "0")
     cap2 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     cp2 = cap2.plans(1, 64, max_new)
-    assert any(op.kind == L.OP_DWCONV3_LN for op in cp2.encode_plan.ops) and not any(op.kind == L.OP_DWCONV3_LN for op in cp.encode_plan.ops)
-    assert sum(op.kind == L.OP_SPLIT_CONVERT for op in cp2.encode_plan.ops) < sum(op.kind == L.OP_SPLIT_CONVERT for op in cp.encode_plan.ops)
+    assert not any(op.kind == L.OP_DWCONV3_LN for op in cp2.encode_plan.ops)
+    assert sum(op.kind == L.OP_SPLIT_CONVERT for op in cp2.encode_plan.ops) > sum(op.kind == L.OP_SPLIT_CONVERT for op in cp.encode_plan.ops)
     with torch.inference_mode():
         cp2.reset()
         cp2.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
@@ -55,7 +57,7 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
-    """ScreenParser.parse_batch with the detect -> caption hand-off on the device (OMNI_DEVICE_GLUE=1: eager detector plan, glue kernel,
+    """ScreenParser.parse_batch with the detect -> caption hand-off on the device (the default: detector + hand-off ops in one plan, glue kernel,
     crop rectangles that never visit the host, packed caption micro-batches) against the default host hand-off of the same frames:
     identical element tables and crop rectangles; captions present on every icon without OCR text."""
     from omniparser_amd.florence import Florence2Captioner

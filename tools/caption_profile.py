@@ -1,0 +1,81 @@
+"""Per-op device time of the caption plans (HIP events around every op of an eager replay: omni_plan_profile), with the
+algorithmic bytes / FLOPs of each op -> GB/s and TF/s per op, aggregated by (kernel family, tensor shape).
+usage: python tools/caption_profile.py [capacity=128] [R=768] [repeat=2]   -> JSON on stdout, table on stderr"""
+import json
+import os
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+
+
+def op_shape(op):
+    i, k = op.i, op.kind
+    if k in (1, 19):
+        return (i[0] * max(i[10], 1) * max(i[11], 1) if k == 1 else i[0] * max(i[1], 1), i[12] if k == 1 else i[3], i[6] * i[7] * i[3] if k == 1 else 0)
+    if k in (8, 18):
+        return (i[0] * i[1] * i[2], i[3], 0)
+    if k == 9:
+        return (i[0] * max(i[1], 1), i[3], i[6])
+    if k == 10:
+        return (i[11] * i[9], i[8] * i[15], i[12])
+    if k == 11:
+        return (i[0] * i[1], i[3], 0)
+    if k == 15:
+        return (i[10], i[9], i[7] if i[7] > 0 else i[8])
+    return (i[0], i[3], 0)
+
+
+def main():
+    import torch
+    from omniparser_amd import _lib as L
+    from omniparser_amd.florence import Florence2Captioner
+    from tools.make_weights import caption_dir, ensure_via_subprocess
+    from tools.plan_table import NAMES, op_work
+    B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
+    R = int(sys.argv[2]) if len(sys.argv) > 2 else 768
+    rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    ensure_via_subprocess("caption", seed=0)
+    os.environ["OMNI_HIPGRAPH_CAP"] = "0"
+    cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
+    cp = cap.plans(B, R, 20)
+    g = torch.Generator().manual_seed(0)
+    with torch.inference_mode(), torch.cuda.stream(cap.stream):
+        # smooth inputs (what crops look like), not randn
+        low = torch.randn(B, 8, 8, 3, generator=g).permute(0, 3, 1, 2)
+        x = torch.nn.functional.interpolate(low, size=(R, R), mode="bicubic").permute(0, 2, 3, 1).contiguous()
+        cp.x_in.t[:, :, :, :3] = x.to(cap.device)
+        cp.reset()
+        cp.encode_plan.run(cap.stream); cp.step_plan.run(cap.stream)
+        cap.stream.synchronize()
+    out = {"capacity": B, "R": R, "plans": {}}
+    for name, plan, reps in (("encode", cp.encode_plan, rep), ("step", cp.step_plan, 20)):
+        ms = [0.0] * len(plan.ops)
+        with torch.inference_mode():
+            if name == "step":
+                with torch.cuda.stream(cap.stream):
+                    cp.reset()
+            for _ in range(reps):
+                for j, t in enumerate(plan.profile(cap.stream)):
+                    ms[j] += t / reps
+        agg = {}
+        for op, t in zip(plan.ops, ms):
+            f, b = op_work(op)
+            key = (NAMES.get(op.kind, {19: "split_convert", 16: "greedy_step"}.get(op.kind, str(op.kind))), op_shape(op))
+            a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
+            a[0] += 1; a[1] += t; a[2] += f; a[3] += b
+        rows = [{"kernel": k[0], "shape": list(k[1]), "n": a[0], "ms": round(a[1], 3), "GBps": round(a[3] / max(a[1], 1e-9) / 1e6, 1),
+                 "TFps": round(a[2] / max(a[1], 1e-9) / 1e9, 1)} for k, a in sorted(agg.items(), key=lambda kv: -kv[1][1])]
+        fam = {}
+        for r in rows:
+            fam[r["kernel"]] = round(fam.get(r["kernel"], 0.0) + r["ms"], 3)
+        out["plans"][name] = {"total_ms": round(sum(ms), 3), "by_family_ms": dict(sorted(fam.items(), key=lambda kv: -kv[1])), "rows": rows}
+        print(f"--- {name}: {sum(ms):.2f} ms ({'per replay' if name == 'encode' else 'per step'})", file=sys.stderr)
+        for r in rows[:40]:
+            print("%-26s %-22s n=%-3d %8.3f ms %8.1f GB/s %7.1f TF/s" % (r["kernel"], r["shape"], r["n"], r["ms"], r["GBps"], r["TFps"]), file=sys.stderr)
+    print(json.dumps(out))
+
+
+if __name__ == "__main__":
+    main()
