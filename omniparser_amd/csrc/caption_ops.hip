@@ -805,12 +805,28 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
   }
 }
 
-// Round-3 rewrite of the f32 window kernel for LATENCY: the kernel above walks global memory in dependent phases (seven staging
-// iterations with a load -> convert -> LDS-write chain each, then per query tile a Q load right in front of its first MFMA), with
-// three 3-wave blocks per CU nothing hid those round trips and it ran at 2.0 TB/s (profiles/r2_pmc_*: 25 % of HBM).  Same
-// arithmetic, same LDS image, same MFMA sequence per query tile — bit-identical output — but every global load of the block is
-// issued before the first use: the wave's three Q tiles first, then K (six 16-byte loads per thread) and V (four or eight);
-// V is transposed in registers per (4 keys x 4 channels) item so V^T goes to LDS as 8-byte writes instead of 2-byte ones.
+// Round-3 rewrite of the f32 window kernel.  The kernel above walks global memory in dependent phases (seven staging iterations with a
+// load -> convert -> LDS-write chain each, then per query tile a Q load right in front of its first MFMA) and spends ~870 VALU
+// instructions per 16-query tile on one-value-at-a-time f32 -> (hi, lo) conversions; with three 3-wave blocks per CU it ran at
+// 2.0-2.2 TB/s.  Here (a) every global load of the block is issued before the first use — the wave's three Q tiles, then K (six
+// 16-byte loads per thread) and V (four or eight); (b) V is transposed in registers per (4 keys x 4 channels) item, so V^T goes to
+// LDS as 8-byte writes instead of 2-byte ones; (c) conversions work on PAIRS (v_cvt_pkrtz + packed f32 sub / mul: 3 instructions
+// per value instead of 5), the softmax scale is folded into Q, hi + lo/2048 is one fma.  Same split-f16 x3 MFMA arithmetic; the hi
+// halves are now round-toward-zero (the lo half absorbs the remainder either way), so results agree with the kernel above to f32
+// rounding, not bit for bit.
+__device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& l) {
+  typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+  const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const f32x2 r = (f32x2{a, b} - f32x2{(float)hh[0], (float)hh[1]}) * 2048.0f;
+  const hv2 ll = __builtin_amdgcn_cvt_pkrtz(r[0], r[1]);
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void split4v(const f32x4& v, uint2& h, uint2& l) {
+  split2(v[0], v[1], h.x, l.x);
+  split2(v[2], v[3], h.y, l.y);
+}
+
 __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
   constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
@@ -866,17 +882,16 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
 #pragma unroll
   for (int j = 0; j < 6; ++j) {
     const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
-    half_t kh[4], kl[4];
-#pragma unroll
-    for (int u = 0; u < 4; ++u) split1(kraw[j][u], kh[u], kl[u]);
-    *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = h16x4{kh[0], kh[1], kh[2], kh[3]};
-    *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = h16x4{kl[0], kl[1], kl[2], kl[3]};
+    uint2 kh, kl;
+    split4v(kraw[j], kh, kl);
+    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = kh;
+    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = kl;
   }
   if (tid < 128) {                                    // padding keys 144..159: 16 keys x 8 channel groups
     const int key = 144 + (tid >> 3), d0 = (tid & 7) * 4;
-    const h16x4 zh = {(half_t)0.f, (half_t)0.f, (half_t)0.f, (half_t)0.f};
-    *reinterpret_cast<h16x4*>(Kh + key * KROW + d0 * 2) = zh;
-    *reinterpret_cast<h16x4*>(Kl + key * KROW + d0 * 2) = zh;
+    const uint2 zh = {0u, 0u};
+    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = zh;
+    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = zh;
   } else {                                            // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
     const int r = tid - 128;                          // 0..63: (hi | lo, d)
     unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
@@ -890,11 +905,10 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
     if (e < 288) {
 #pragma unroll
       for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
-        half_t vh[4], vl[4];
-#pragma unroll
-        for (int u = 0; u < 4; ++u) split1(vraw[j][u][dd], vh[u], vl[u]);
-        *reinterpret_cast<h16x4*>(Vh + (d0 + dd) * VROW + kq * 8) = h16x4{vh[0], vh[1], vh[2], vh[3]};
-        *reinterpret_cast<h16x4*>(Vl + (d0 + dd) * VROW + kq * 8) = h16x4{vl[0], vl[1], vl[2], vl[3]};
+        uint2 vh, vl;
+        split4v(f32x4{vraw[j][0][dd], vraw[j][1][dd], vraw[j][2][dd], vraw[j][3][dd]}, vh, vl);
+        *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + kq * 8) = vh;
+        *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + kq * 8) = vl;
       }
     }
   }
@@ -904,13 +918,16 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
 #pragma unroll
   for (int t = 0; t < 3; ++t) {
     const int qt = wave + 3 * t;
-    h16x8 qh, ql;
-#pragma unroll
-    for (int u = 0; u < 8; ++u) {
-      half_t hh, ll;
-      split1(qraw[t][u >> 2][u & 3], hh, ll);
-      qh[u] = hh; ql[u] = ll;
+    u32x4 qhu, qlu;                                   // Q fragment (8 halves each), pre-multiplied by the softmax scale
+    {
+      const f32x4 q0 = qraw[t][0] * a.scale, q1 = qraw[t][1] * a.scale;
+      uint2 h0, l0, h1, l1;
+      split4v(q0, h0, l0);
+      split4v(q1, h1, l1);
+      qhu = u32x4{h0.x, h0.y, h1.x, h1.y};
+      qlu = u32x4{l0.x, l0.y, l1.x, l1.y};
     }
+    const h16x8 qh = __builtin_bit_cast(h16x8, qhu), ql = __builtin_bit_cast(h16x8, qlu);
     float sc[40];
     float mx = -INFINITY;
 #pragma unroll
@@ -924,8 +941,8 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
       accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
 #pragma unroll
       for (int r = 0; r < 4; ++r) {
-        int key = kt * 16 + grp * 4 + r;
-        float sv = (accM[r] + accC[r] * inv2048) * a.scale;
+        const int key = kt * 16 + grp * 4 + r;
+        float sv = __builtin_fmaf(accC[r], inv2048, accM[r]);
         sv = key < 144 ? sv : -INFINITY;
         sc[kt * 4 + r] = sv;
         mx = fmaxf(mx, sv);
@@ -943,20 +960,18 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
     for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
 #pragma unroll
     for (int j = 0; j < 5; ++j) {
-      h16x8 ph, pl;
-#pragma unroll
-      for (int u = 0; u < 8; ++u) {
-        half_t hh, ll;
-        split1(sc[(2 * j + (u >> 2)) * 4 + (u & 3)], hh, ll);
-        ph[u] = hh; pl[u] = ll;
-      }
+      uint2 h0, l0, h1, l1;
+      split4v(f32x4{sc[8 * j + 0], sc[8 * j + 1], sc[8 * j + 2], sc[8 * j + 3]}, h0, l0);
+      split4v(f32x4{sc[8 * j + 4], sc[8 * j + 5], sc[8 * j + 6], sc[8 * j + 7]}, h1, l1);
+      const h16x8 ph = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+      const h16x8 pl = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
 #pragma unroll
       for (int dt = 0; dt < 2; ++dt) {
         const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
-        h16x4 a0 = *reinterpret_cast<const h16x4*>(vr), a1 = *reinterpret_cast<const h16x4*>(vr + 32);
-        h16x4 b0 = *reinterpret_cast<const h16x4*>(vr + D * VROW), b1 = *reinterpret_cast<const h16x4*>(vr + D * VROW + 32);
-        h16x8 vh = {a0[0], a0[1], a0[2], a0[3], a1[0], a1[1], a1[2], a1[3]};
-        h16x8 vl = {b0[0], b0[1], b0[2], b0[3], b1[0], b1[1], b1[2], b1[3]};
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 32);
+        const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 32);
+        const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+        const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
         oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
         oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
         oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
@@ -971,7 +986,7 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
         const float inv = 1.0f / rs;
 #pragma unroll
         for (int dt = 0; dt < 2; ++dt)
-          store_out<float>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, (oM[dt][r] + oC[dt][r] * inv2048) * inv, a.osplit);
+          store_out<float>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, __builtin_fmaf(oC[dt][r], inv2048, oM[dt][r]) * inv, a.osplit);
       }
     }
   }

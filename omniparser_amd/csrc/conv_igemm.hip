@@ -65,7 +65,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, int mb, int n, 
     float v = get(e) + bias;
     if (scale != 0.0f) v *= scale;
     if constexpr (ACT == OMNI_ACT_SILU) v = v / (1.0f + expf(-v));                                   // torch CPU: x / (1 + exp(-x))
-    else if constexpr (ACT == OMNI_ACT_GELU) v = 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));   // exact erf GELU
+    else if constexpr (ACT == OMNI_ACT_GELU) v = omni_gelu(v);                                     // exact erf GELU
     v += r[e];
     if (mb + dm < a.M) Yb[dm * a.ldo] = ElemTraits<T>::from_f32(v);
   }

@@ -56,7 +56,7 @@ __device__ __forceinline__ float act_apply(float v, int act) {
     return v / (1.0f + expf(-v));
   } else if (act == OMNI_ACT_GELU) {
     // exact erf GELU (hf ACT2FN["gelu"]): 0.5 * x * (1 + erf(x / sqrt(2)))
-    return 0.5f * v * (1.0f + erff(v * 0.70710678118654752440f));
+    return omni_gelu(v);
   }
   return v;
 }

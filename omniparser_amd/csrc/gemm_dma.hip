@@ -41,7 +41,9 @@ struct GemmArgs {
 // K-loop schedule: the DMA pieces of the slice NSTAGE-1 ahead are spread over the units, ds_reads / DMA pieces interleaved one per
 // MFMA (sched_group_barrier).  The alternative schedule (all DMA pieces right after the barrier: 1-6 % slower) and the ablation
 // variants that led here are recorded in profiles/r2_gemm_diag.md; they are not compiled into the library.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES>
+// SCHED 1 (OMNI_GEMM_SCHED=1, tools/gemm_bench.py A/B): the DMA pieces of the next slice are issued in the FIRST half of the units, so
+// that the last piece has at least half a slice to land before the wait at the top of the next slice.
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -154,7 +156,8 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
   int stage = 0, nstage = NSTAGE - 1;          // ring positions of slice kt and of slice kt + NSTAGE - 1
-  constexpr int PPU = (DPS + NU - 1) / NU;     // DMA pieces per unit
+  constexpr int IU = SCHED == 1 ? (NU + 1) / 2 : NU;   // units that issue DMA pieces
+  constexpr int PPU = (DPS + IU - 1) / IU;     // DMA pieces per issuing unit
   AF af[2];
   WF wf[2];
   // One K slice.  MORE (compile time): a further slice is issued into the ring — the steady-state loop and the drain loop are
@@ -186,7 +189,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
       mma(af[u & 1], wf[g & 1], ip);
       {
         // one ds_read (then one DMA piece) behind each of the first MFMAs: they issue inside the 32-cycle MFMA slots
-        const int npc = MORE ? PPU : 0;
+        const int npc = (MORE && u < IU) ? PPU : 0;
 #pragma unroll
         for (int k = 0; k < 12; ++k) {
           __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
@@ -206,55 +209,83 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   for (; kt < nk; ++kt) slice(kt, std::false_type{});
 
   // ---- epilogue.  D^T layout: lane -> token (lane & 31) of each token tile; accumulator quad q of channel tile j holds
-  // channels j*32 + 8q + 4*(lane >> 5) + 0..3.
-  const int mrow = m0 + wm * (BM / WM) + (lane & 31);
-  const int nb = n0 + wn * (BN / WN) + 4 * hsel;
+  // channels j*32 + 8q + 4*(lane >> 5) + 0..3.  A lane therefore owns 16-byte pieces of 32 different rows: stored directly, one
+  // store instruction scatters 32 x 32 bytes (the write-heavy layers — fc1, qkv of DaViT stages 0-1 — ran at 2.7-2.9 TB/s while
+  // read-heavy ones streamed at 5.1, profiles/r3_s2b_caption_per_op.txt).  So each wave transposes one 32-row token tile at a time
+  // through its own slice of the (now idle) LDS ring: rows are assembled in LDS exactly as they lie in memory (f32, or format B as
+  // two 8-byte halves), then 16 lanes read one row's 256 bytes and store them contiguously — 4 rows x 256 B per instruction; the
+  // residual is added after the transposition, from equally coalesced loads.
+  static_assert(TN == 2, "epilogue staging assumes 64 channels (256 bytes per row) per wave");
+  constexpr int EP = 272;                                    // staged row pitch: 256 + 16 (conflict-free 16-byte column writes)
+  static_assert(NW * 32 * EP <= NSTAGE * STAGE, "epilogue staging must fit the LDS ring");
+  __syncthreads();                                           // every wave is done reading the last K slice
+  unsigned char* stg = lds + wave * (32 * EP);
+  const int nw0 = n0 + wn * (BN / WN);                       // first channel of this wave
   f32x4 bq[TN][4];
 #pragma unroll
   for (int j = 0; j < TN; ++j)
 #pragma unroll
     for (int q = 0; q < 4; ++q)
-      bq[j][q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nb + j * 32 + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
+      bq[j][q] = a.bias ? *reinterpret_cast<const f32x4*>(a.bias + nw0 + 4 * hsel + j * 32 + q * 8) : f32x4{0.f, 0.f, 0.f, 0.f};
   const float osc = a.oscale;
+  const int rrow = lane >> 4, chunk = lane & 15;             // read phase: 16 lanes per row, 16 bytes per lane
+  static_assert(!(RES && OSPLIT), "residual + format-B output is not a layer of this model");
+  f32x4 rres[8];
+  auto load_res = [&](int i) {                               // residual rows of token tile i in the read-phase layout (rows clamped: M tail)
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = min(m0 + wm * (BM / WM) + i * 32 + it * 4 + rrow, a.M - 1);
+      rres[it] = *reinterpret_cast<const f32x4*>(a.res + (long long)m * a.ldr + a.res_coff + nw0 + chunk * 4);
+    }
+  };
+  if constexpr (RES) load_res(0);
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    const int m = mrow + i * 32;
-    const bool ok = m < a.M;
-    f32x4 rq[TN][4];
-    if constexpr (RES) {
-      const float* __restrict__ Rr = a.res + (long long)(ok ? m : 0) * a.ldr + a.res_coff + nb;
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-#pragma unroll
-        for (int q = 0; q < 4; ++q) rq[j][q] = *reinterpret_cast<const f32x4*>(Rr + j * 32 + q * 8);
-    }
-    unsigned char* __restrict__ Yr = a.y + ((long long)(ok ? m : 0) * a.ldo + a.out_coff) * 4;
+    unsigned char* wr = stg + (lane & 31) * EP;
 #pragma unroll
     for (int j = 0; j < TN; ++j)
 #pragma unroll
       for (int q = 0; q < 4; ++q) {
         float v[4];
+        if constexpr (ACT == OMNI_ACT_GELU) {                // two elements per packed instruction
 #pragma unroll
-        for (int c = 0; c < 4; ++c) {
-          float t = acc[i][j][q * 4 + c] * osc + bq[j][q][c];
-          if constexpr (ACT == OMNI_ACT_GELU) t = 0.5f * t * (1.0f + erff(t * 0.70710678118654752440f));
-          else if constexpr (ACT == OMNI_ACT_SILU) t = t / (1.0f + expf(-t));
-          if constexpr (RES) t += rq[j][q][c];
-          v[c] = t;
-        }
-        const int n = nb + j * 32 + q * 8;
-        if (ok) {
-          if constexpr (OSPLIT) {
-            uint2 hi, lo;
-            omni_split4(v, hi, lo);
-            unsigned char* p = Yr + omni_split_off(n);
-            *reinterpret_cast<uint2*>(p) = hi;
-            *reinterpret_cast<uint2*>(p + 32) = lo;
-          } else {
-            *reinterpret_cast<f32x4*>(Yr + n * 4) = f32x4{v[0], v[1], v[2], v[3]};
+          for (int c = 0; c < 4; c += 2) {
+            const f32x2 g = omni_gelu2(f32x2{acc[i][j][q * 4 + c], acc[i][j][q * 4 + c + 1]} * osc + f32x2{bq[j][q][c], bq[j][q][c + 1]});
+            v[c] = g[0]; v[c + 1] = g[1];
+          }
+        } else {
+#pragma unroll
+          for (int c = 0; c < 4; ++c) {
+            float t = acc[i][j][q * 4 + c] * osc + bq[j][q][c];
+            if constexpr (ACT == OMNI_ACT_SILU) t = t / (1.0f + expf(-t));
+            v[c] = t;
           }
         }
+        const int cl = j * 32 + q * 8 + 4 * hsel;            // channel within the wave's 64
+        if constexpr (OSPLIT) {
+          uint2 hi, lo;
+          omni_split4(v, hi, lo);
+          *reinterpret_cast<uint2*>(wr + omni_split_off(cl)) = hi;
+          *reinterpret_cast<uint2*>(wr + omni_split_off(cl) + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(wr + cl * 4) = f32x4{v[0], v[1], v[2], v[3]};
+        }
       }
+    OMNI_WAVE_SYNC();
+    const int mt0 = m0 + wm * (BM / WM) + i * 32;
+    f32x4 ov[8];
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      ov[it] = *reinterpret_cast<const f32x4*>(stg + (it * 4 + rrow) * EP + chunk * 16);
+      if constexpr (RES) ov[it] += rres[it];
+    }
+    if constexpr (RES) { if (i + 1 < TM) load_res(i + 1); }  // next tile's residual rows: in flight under the stores and the next tile's arithmetic
+#pragma unroll
+    for (int it = 0; it < 8; ++it) {
+      const int m = mt0 + it * 4 + rrow;
+      if (m < a.M) *reinterpret_cast<f32x4*>(a.y + ((long long)m * a.ldo + a.out_coff + nw0) * 4 + chunk * 16) = ov[it];
+    }
+    OMNI_WAVE_SYNC();                                        // the next token tile overwrites the staging rows
   }
 #endif
 }
@@ -293,16 +324,21 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  if (act == OMNI_ACT_NONE && !osplit && !res)
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_NONE && !osplit && res)
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, false, true>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_NONE && osplit && !res)
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_NONE, true, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_GELU && osplit && !res)
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_GELU, true, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_GELU && !osplit && !res)
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, OMNI_ACT_GELU, false, false>), grid, block, 0, s, a);
+  int sched = 0;
+  if constexpr (BM == 256 && BN == 256) { if (const char* e = getenv("OMNI_GEMM_SCHED")) sched = atoi(e) == 1 ? 1 : 0; }
+#define OMNI_GD(ACT_, OS_, RES_)                                                                                         \
+  do {                                                                                                                   \
+    if constexpr (BM == 256 && BN == 256) {                                                                              \
+      if (sched == 1) { hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 1>), grid, block, 0, s, a); break; } \
+    }                                                                                                                    \
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 0>), grid, block, 0, s, a);            \
+  } while (0)
+  if (act == OMNI_ACT_NONE && !osplit && !res) OMNI_GD(OMNI_ACT_NONE, false, false);
+  else if (act == OMNI_ACT_NONE && !osplit && res) OMNI_GD(OMNI_ACT_NONE, false, true);
+  else if (act == OMNI_ACT_NONE && osplit && !res) OMNI_GD(OMNI_ACT_NONE, true, false);
+  else if (act == OMNI_ACT_GELU && osplit && !res) OMNI_GD(OMNI_ACT_GELU, true, false);
+  else if (act == OMNI_ACT_GELU && !osplit && !res) OMNI_GD(OMNI_ACT_GELU, false, false);
+#undef OMNI_GD
   else {
     omni_set_error("gemm_dma: unsupported epilogue (act %d, split out %d, residual %d)", act, osplit, (int)res);
     return OMNI_E_ARG;

@@ -772,7 +772,8 @@ def check_caption_ops(dtype=L.F32, seed=0):
                                                    11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D}, f={0: D ** -0.5}))
         res[f"attn_window_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh}")
         if dtype == L.F32:
-            # the latency-oriented kernel (default) is bit-identical to the round-2 kernel, also with format-B output
+            # the round-3 kernel (default) against the round-2 kernel (same split-f16 x3 arithmetic, hi halves rounded toward zero
+            # instead of to nearest): f32-rounding agreement; and its format-B output
             mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype,
                                              p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
                                              i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
@@ -782,7 +783,7 @@ def check_caption_ops(dtype=L.F32, seed=0):
                 _, g_old = _op_pair(t, lambda P: mk(P, 0))
             finally:
                 os.environ.pop("OMNI_WINDOW_ATTN", None)
-            assert torch.equal(g_old["o"], gq["o"]), f"window attention: default kernel != round-2 kernel, H={Hh}"
+            _cmp(gq["o"], g_old["o"], tol, f"window attention: default vs round-2 kernel, H={Hh}")
             if Cm % 16 == 0:
                 cs, gs = _op_pair(t, lambda P: mk(P, 1))
                 assert torch.equal(gs["o"].view(torch.uint8), cs["o"].view(torch.uint8)) or \

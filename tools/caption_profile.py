@@ -32,7 +32,12 @@ def main():
     from omniparser_amd import _lib as L
     from omniparser_amd.florence import Florence2Captioner
     from tools.make_weights import caption_dir, ensure_via_subprocess
-    from tools.plan_table import NAMES, op_work
+    split_env = os.environ.get("OMNI_CONV_SPLIT")
+    from tools.plan_table import NAMES, op_work          # (its import sets OMNI_CONV_SPLIT=0 for CPU-only plan tables: undo that)
+    if split_env is None:
+        os.environ.pop("OMNI_CONV_SPLIT", None)
+    else:
+        os.environ["OMNI_CONV_SPLIT"] = split_env
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 768
     rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
@@ -49,11 +54,11 @@ def main():
         cp.reset()
         cp.encode_plan.run(cap.stream); cp.step_plan.run(cap.stream)
         cap.stream.synchronize()
-    out = {"capacity": B, "R": R, "plans": {}}
-    for name, plan, reps in (("encode", cp.encode_plan, rep), ("step", cp.step_plan, 20)):
+    out = {"capacity": B, "R": R, "use_dma": bool(cp.use_dma), "plans": {}}
+    for pname, plan, reps in (("encode", cp.encode_plan, rep), ("step", cp.step_plan, 20)):
         ms = [0.0] * len(plan.ops)
         with torch.inference_mode():
-            if name == "step":
+            if pname == "step":
                 with torch.cuda.stream(cap.stream):
                     cp.reset()
             for _ in range(reps):
@@ -62,7 +67,10 @@ def main():
         agg = {}
         for op, t in zip(plan.ops, ms):
             f, b = op_work(op)
-            key = (NAMES.get(op.kind, {19: "split_convert", 16: "greedy_step"}.get(op.kind, str(op.kind))), op_shape(op))
+            name = NAMES.get(op.kind, {19: "split_convert", 16: "greedy_step"}.get(op.kind, str(op.kind)))
+            if op.kind == 1:
+                name = "gemm_dma" if op.i[20] == 2 else ("conv_split" if op.i[20] else "conv_igemm")
+            key = (name, op_shape(op))
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += t; a[2] += f; a[3] += b
         rows = [{"kernel": k[0], "shape": list(k[1]), "n": a[0], "ms": round(a[1], 3), "GBps": round(a[3] / max(a[1], 1e-9) / 1e6, 1),
@@ -70,8 +78,8 @@ def main():
         fam = {}
         for r in rows:
             fam[r["kernel"]] = round(fam.get(r["kernel"], 0.0) + r["ms"], 3)
-        out["plans"][name] = {"total_ms": round(sum(ms), 3), "by_family_ms": dict(sorted(fam.items(), key=lambda kv: -kv[1])), "rows": rows}
-        print(f"--- {name}: {sum(ms):.2f} ms ({'per replay' if name == 'encode' else 'per step'})", file=sys.stderr)
+        out["plans"][pname] = {"total_ms": round(sum(ms), 3), "by_family_ms": dict(sorted(fam.items(), key=lambda kv: -kv[1])), "rows": rows}
+        print(f"--- {pname}: {sum(ms):.2f} ms ({'per replay' if pname == 'encode' else 'per step'})", file=sys.stderr)
         for r in rows[:40]:
             print("%-26s %-22s n=%-3d %8.3f ms %8.1f GB/s %7.1f TF/s" % (r["kernel"], r["shape"], r["n"], r["ms"], r["GBps"], r["TFps"]), file=sys.stderr)
     print(json.dumps(out))

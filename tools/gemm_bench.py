@@ -15,7 +15,7 @@ SHAPES = [  # name, M, N, K, act, res
     ("s2.fc1", 294912, 2048, 512, 2, False), ("s2.fc2", 294912, 512, 2048, 0, True), ("s2.qkv", 294912, 1536, 512, 0, False),
     ("s2.proj", 294912, 512, 512, 0, True), ("s0.fc1", 4718592, 512, 128, 2, False), ("s0.fc2", 4718592, 128, 512, 0, True),
     ("enc.fc1", 74880, 3072, 768, 2, False), ("s3.fc1", 73728, 4096, 1024, 2, False), ("det.p3", 51200, 128, 1152, 1, False),
-    ("s2.fc2n", 294912, 512, 2048, 0, False),     # fc2 shape with the plain epilogue (schedule variants / ablations apply to it)
+    ("s0.qkv", 4718592, 384, 128, 0, False), ("s1.fc1", 1179648, 1024, 256, 2, False), ("s1.qkv", 1179648, 768, 256, 0, False),
 ]
 
 
@@ -29,7 +29,7 @@ def main():
     for variant in os.environ.get("VARIANTS", "split:128x128,dma,dma:256x128,dma:128x128").split(","):
         os.environ["OMNI_CONV_SPLIT"] = "0" if variant.startswith("f32") else "1"
         variant, *envs = variant.split("+")
-        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE", "OMNI_GEMM_VAR", "OMNI_GEMM_ABL"):
+        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE", "OMNI_GEMM_SCHED"):
             os.environ.pop(k, None)
         for kv in envs:
             k, v = kv.split("=")
@@ -69,11 +69,19 @@ def main():
             rows = torch.cat([torch.arange(128), torch.arange(M - 128, M), torch.randint(0, M, (1792,))]).cuda()
             xs = xref[0, rows, 0, :].double().cpu()
             ref = xs @ wcpu.double().t()
-            got = y.t[0, rows, 0, :].double().cpu()
-            if act == 0 and not res:
-                err = ((got - (ref + bias.double())).abs().max() / ref.abs().max()).item()
-            else:
-                err = float("nan")
+            got = y.t[0, rows, 0, :].cpu()
+            if dma and act == 2:            # format-B output: [C/16 groups][16 hi halves | 16 lo halves]
+                hv = got.contiguous().view(torch.float16).view(got.shape[0], N // 16, 2, 16).double()
+                got = (hv[:, :, 0] + hv[:, :, 1]).reshape(got.shape[0], N)
+            got = got.double()
+            ref = ref + bias.double()
+            if act == 2:
+                ref = torch.nn.functional.gelu(ref)
+            elif act == 1:
+                ref = torch.nn.functional.silu(ref)
+            if res:
+                ref = ref + r.t[0, rows, 0, :].double().cpu()
+            err = ((got - ref).abs().max() / ref.abs().max()).item()
             print(f"{name:8s} M={M:8d} N={N:5d} K={K:5d}  {ms:8.3f} ms  {2*M*N*K/ms/1e9:7.1f} TF/s  relerr {err:.2e}")
             del pb, plan, x, y, r
             torch.cuda.empty_cache()
