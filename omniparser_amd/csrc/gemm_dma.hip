@@ -41,8 +41,9 @@ struct GemmArgs {
 // K-loop schedule: the DMA pieces of the slice NSTAGE-1 ahead are spread over the units, ds_reads / DMA pieces interleaved one per
 // MFMA (sched_group_barrier).  The alternative schedule (all DMA pieces right after the barrier: 1-6 % slower) and the ablation
 // variants that led here are recorded in profiles/r2_gemm_diag.md; they are not compiled into the library.
-// SCHED 1 (OMNI_GEMM_SCHED=1, tools/gemm_bench.py A/B): the DMA pieces of the next slice are issued in the FIRST half of the units, so
-// that the last piece has at least half a slice to land before the wait at the top of the next slice.
+// SCHED 1 (default for the 256x256 tile since round 3; OMNI_GEMM_SCHED=0 = pieces spread over all units, tools/gemm_bench.py A/B): the
+// DMA pieces of the next slice are issued in the FIRST half of the units, so that the last piece has at least half a slice to land
+// before the wait at the top of the next slice: +2-5 % on the K >= 512 shapes (profiles/r3_s3_gemm_bench.txt).
 template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
@@ -324,8 +325,8 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  int sched = 0;
-  if constexpr (BM == 256 && BN == 256) { if (const char* e = getenv("OMNI_GEMM_SCHED")) sched = atoi(e) == 1 ? 1 : 0; }
+  int sched = 1;
+  if constexpr (BM == 256 && BN == 256) { if (const char* e = getenv("OMNI_GEMM_SCHED")) sched = atoi(e) == 0 ? 0 : 1; }
 #define OMNI_GD(ACT_, OS_, RES_)                                                                                         \
   do {                                                                                                                   \
     if constexpr (BM == 256 && BN == 256) {                                                                              \

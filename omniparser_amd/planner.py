@@ -49,6 +49,33 @@ class View:
         return self.t[..., self.coff:self.coff + self.C].permute(0, 3, 1, 2).float()
 
 
+# Every device tensor a PlanBuilder creates, by base address: (weak reference, role).  role: "const" = uploaded content that must
+# travel with an exported plan (weights, tables), "zero" = zero-initialised state, "scratch" = written before it is read.
+# omniparser_amd/bundle.py resolves the raw pointers of a plan's ops against this registry when it exports a plan bundle for
+# the model-level C entry points (include/omni_amd.h: omni_model_*).
+import weakref
+
+_TENSORS = {}
+
+
+def _register(t: torch.Tensor, role: str) -> torch.Tensor:
+    if t.numel():
+        _TENSORS[t.data_ptr()] = (weakref.ref(t), role, t.numel() * t.element_size())
+    return t
+
+
+def live_tensors():
+    """[(base address, nbytes, role, tensor)] of the registered tensors that are still alive, sorted by address."""
+    out = []
+    for ptr, (ref, role, nbytes) in list(_TENSORS.items()):
+        t = ref()
+        if t is None or t.data_ptr() != ptr:
+            _TENSORS.pop(ptr, None)
+            continue
+        out.append((ptr, nbytes, role, t))
+    return sorted(out, key=lambda r: r[0])
+
+
 class PlanBuilder:
     def __init__(self, device, dtype: int):
         self.device = torch.device(device)
@@ -68,17 +95,17 @@ class PlanBuilder:
     def alloc(self, B, H, W, C, zero=False) -> View:
         fn = torch.zeros if zero else torch.empty
         t = fn((B, H, W, C), dtype=torch_dtype(self.dtype), device=self.device)
-        self.keep.append(t)
+        self.keep.append(_register(t, "zero" if zero else "scratch"))
         return View(t, 0, C)
 
     def raw(self, shape, dtype, zero=True) -> torch.Tensor:
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
-        self.keep.append(t)
+        self.keep.append(_register(t, "zero" if zero else "scratch"))
         return t
 
     def upload(self, host_tensor: torch.Tensor) -> torch.Tensor:
         t = host_tensor.contiguous().to(self.device)
-        self.keep.append(t)
+        self.keep.append(_register(t, "const"))
         return t
 
     @staticmethod
