@@ -244,6 +244,42 @@ int omni_debug_tile_map(int mtiles, int ntiles, int xcd_n, long long weight_byte
  * infrastructure for boxes without a GPU; never used by omni_op_launch or plans. */
 int omni_debug_host_op(const omni_op_t* op, int variant);
 
+/* ------------------------------------------------------------------------ *
+ * Model-level entry points: the two models of the hot path for hosts
+ * without Python.  A model is a PLAN BUNDLE file written by omniparser_amd/bundle.py
+ * (export_detector / export_captioner): the op lists above over a fixed set of device
+ * buffers, with constants and named I/O tensors.  omni_model_load allocates the
+ * buffers, uploads the constants, relocates the ops and captures every plan as a
+ * hipGraph on a stream owned by the model.  All calls below are SYNCHRONOUS.
+ * ------------------------------------------------------------------------ */
+typedef struct omni_model omni_model_t;
+
+int  omni_model_load(const char* bundle_path, omni_model_t** out);
+void omni_model_destroy(omni_model_t* model);
+/* scalars / named device tensors of a bundle ("batch", "img_w", "capacity", "T", ... ; "img", "out_boxes", "x_in", "ids", ...). */
+int  omni_model_int(const omni_model_t* model, const char* name, long long* value);
+int  omni_model_tensor(const omni_model_t* model, const char* name, void** d_ptr, long long* nbytes);
+/* replay one plan of the bundle ("detect", "encode", "step") and wait for it. */
+int  omni_model_run(omni_model_t* model, const char* plan_name);
+
+/* Detector = YOLOv9Detector.predict on one batch (ref:util/yolov9.py:115-136: letterbox, network, decode, threshold,
+ * batched_nms[:max_det], clamp).  The bundle fixes image size, network size, thresholds, max_det and batch.
+ *  images_rgb  n_images x [img_h, img_w, 3] uint8, host (on_device = 0) or device memory
+ *  h_boxes     [n_images, max_det, 4] f32 xyxy pixels; h_scores / h_classes [n_images, max_det] (may be NULL);
+ *  h_counts    [n_images] number of valid rows per image. */
+int  omni_detector_create(const char* bundle_path, omni_model_t** out);
+int  omni_detector_infer(omni_model_t* det, const uint8_t* images_rgb, int n_images, int on_device, float* h_boxes, float* h_scores,
+                         int32_t* h_classes, int32_t* h_counts);
+
+/* Captioner = the icon_caption loop of ref:util/utils.py:88-132 on one screenshot: crop each box, cv2.resize 64x64, processor
+ * (bicubic to R x R on the 768 path, rescale, normalise), Florence-2 generate(num_beams=1, max_new_tokens) — greedy ids.
+ *  image_rgb   [img_h, img_w, 3] uint8, host or device;   h_boxes_px [n, 4] int32 xyxy pixels (any n: micro-batches of the
+ *  bundle's capacity);   h_ids [n, T] int32, T = omni_model_int("T") = max_new_tokens + 1; rows are padded with the pad id
+ *  after EOS exactly as generate() pads them. */
+int  omni_captioner_create(const char* bundle_path, omni_model_t** out);
+int  omni_captioner_caption(omni_model_t* cap, const uint8_t* image_rgb, int on_device, int img_h, int img_w, const int32_t* h_boxes_px,
+                            int n, int32_t* h_ids);
+
 #ifdef __cplusplus
 }
 #endif

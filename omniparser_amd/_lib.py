@@ -22,6 +22,8 @@ EXPORTS = [
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
     "omni_debug_host_op", "omni_plan_profile",
+    "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
+    "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
 ]
 
 
@@ -89,6 +91,23 @@ def bind(path):
     L.omni_debug_tile_map.restype = c_int
     L.omni_debug_host_op.argtypes = [POINTER(OmniOp), c_int]
     L.omni_debug_host_op.restype = c_int
+    c_ll = ctypes.c_longlong
+    for name in ("omni_model_load", "omni_detector_create", "omni_captioner_create"):
+        fn = getattr(L, name)
+        fn.argtypes = [c_char_p, POINTER(c_void_p)]
+        fn.restype = c_int
+    L.omni_model_destroy.argtypes = [c_void_p]
+    L.omni_model_destroy.restype = None
+    L.omni_model_int.argtypes = [c_void_p, c_char_p, POINTER(c_ll)]
+    L.omni_model_int.restype = c_int
+    L.omni_model_tensor.argtypes = [c_void_p, c_char_p, POINTER(c_void_p), POINTER(c_ll)]
+    L.omni_model_tensor.restype = c_int
+    L.omni_model_run.argtypes = [c_void_p, c_char_p]
+    L.omni_model_run.restype = c_int
+    L.omni_detector_infer.argtypes = [c_void_p, c_void_p, c_int, c_int, POINTER(c_float), POINTER(c_float), POINTER(c_int32), POINTER(c_int32)]
+    L.omni_detector_infer.restype = c_int
+    L.omni_captioner_caption.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_int, POINTER(c_int32)]
+    L.omni_captioner_caption.restype = c_int
     if L.omni_abi_version() != 1:
         raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
     return L
@@ -212,3 +231,52 @@ def tile_map(mtiles: int, ntiles: int, bid: int, xcd_n: int = 1, weight_bytes: i
 def host_op(op, variant: int = 1):
     """Run the host emulation of `op` (host pointers!) — the same per-thread source the GPU kernel runs."""
     check(lib().omni_debug_host_op(ctypes.byref(op), variant))
+
+
+class CModel:
+    """A plan bundle loaded through the model-level C entry points (include/omni_amd.h: omni_detector_* / omni_captioner_*) — what a
+    C / C++ host does, driven from Python for the tests and INTEGRATION.md's examples.  numpy in, numpy out; no torch involved."""
+
+    def __init__(self, path, kind):
+        h = c_void_p()
+        fn = {"detector": lib().omni_detector_create, "captioner": lib().omni_captioner_create, "model": lib().omni_model_load}[kind]
+        check(fn(str(path).encode(), ctypes.byref(h)))
+        self._h, self.kind = h, kind
+
+    def int(self, name):
+        v = ctypes.c_longlong()
+        check(lib().omni_model_int(self._h, name.encode(), ctypes.byref(v)))
+        return v.value
+
+    def infer(self, images_u8):
+        """images_u8: numpy uint8 [n, H, W, 3] (host) -> (boxes [n, max_det, 4], scores, classes, counts)."""
+        import numpy as np
+        n, md = images_u8.shape[0], self.int("max_det")
+        im = np.ascontiguousarray(images_u8)
+        boxes = np.zeros((n, md, 4), np.float32); scores = np.zeros((n, md), np.float32)
+        cls = np.zeros((n, md), np.int32); cnt = np.zeros((n,), np.int32)
+        check(lib().omni_detector_infer(self._h, im.ctypes.data_as(c_void_p), n, 0, boxes.ctypes.data_as(POINTER(c_float)),
+                                        scores.ctypes.data_as(POINTER(c_float)), cls.ctypes.data_as(POINTER(c_int32)),
+                                        cnt.ctypes.data_as(POINTER(c_int32))))
+        return boxes, scores, cls, cnt
+
+    def caption(self, image_u8, boxes_px):
+        """image_u8: numpy uint8 [H, W, 3]; boxes_px: [n, 4] ints -> ids int32 [n, T]."""
+        import numpy as np
+        im = np.ascontiguousarray(image_u8)
+        bx = np.ascontiguousarray(np.asarray(boxes_px, dtype=np.int32).reshape(-1, 4))
+        ids = np.zeros((bx.shape[0], self.int("T")), np.int32)
+        check(lib().omni_captioner_caption(self._h, im.ctypes.data_as(c_void_p), 0, im.shape[0], im.shape[1],
+                                           bx.ctypes.data_as(POINTER(c_int32)), bx.shape[0], ids.ctypes.data_as(POINTER(c_int32))))
+        return ids
+
+    def close(self):
+        if self._h:
+            lib().omni_model_destroy(self._h)
+            self._h = None
+
+    def __del__(self):
+        try:
+            self.close()
+        except Exception:
+            pass

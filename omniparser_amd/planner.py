@@ -183,6 +183,8 @@ class PlanBuilder:
         b = None
         if bias is not None:
             b = bias if bias.device == self.device and bias.dtype == torch.float32 else self.upload(bias.detach().float())
+            if b.data_ptr() not in _TENSORS:
+                _register(b, "const")            # a caller-owned device tensor: exported with the plan like an uploaded one
             self.keep.append(b)
             assert b.numel() == cout
         if self.ws is None and self.device.type == "cuda":
