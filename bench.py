@@ -47,7 +47,7 @@ def parse_args():
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
     ap.add_argument("--pipeline", action="store_true", help="time the K steps through ScreenParser.parse_stream (steps overlap) instead of K parse_batch calls")
-    ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.ab_opt_in_kernels`, `extra.annotate_tail`, `extra.stream_*`)")
+    ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -220,6 +220,9 @@ def main():
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
+        out["config"]["decode"] = ("one 20-step decode over all crops of the batch (cross-attention K/V of every micro-batch copied into one plan)"
+                                   if os.environ.get("OMNI_MERGED_DECODE", "1") != "0" else "per micro-batch")
+        out["config"]["hand_off"] = "device (detector + hand-off ops in one hipGraph)" if getattr(parser, "device_glue", False) else "host"
 
     if rank == 0:
         # the timed result above is final: nothing below may keep the JSON line from being printed
@@ -244,15 +247,15 @@ def main():
                 gc.collect(); torch.cuda.empty_cache()
             except Exception:      # noqa: BLE001
                 pass
-            # opt-in kernels that have never been timed, each in its OWN process with a hard limit (a fault or a stall there
-            # cannot take this line with it): the format-B producers + the row-coalesced decode attention (compare
-            # roofline.kernel_family_ms_per_step family by family with the line's own), and the annotate / PNG tail on the device
-            out["extra"]["ab_opt_in_kernels"] = child_json(
-                [sys.executable, os.path.abspath(__file__), "--steps", "3", "--warmup", "1", "--no-extra", "--no-cpu-baseline", "--pipeline"],
-                {"OMNI_ATTN_SPLIT_OUT": "1", "OMNI_FUSE_DWLN": "1", "OMNI_DECODE_ATTN": "2"}, 150,
-                keep=("value", "ms_per_step", "steps", ("config", "steps_pipelined"), ("roofline", "non_gemm_share"), ("roofline", "gemm_ms_per_step"),
-                      ("roofline", "kernel_family_ms_per_step"), ("roofline", "crops_per_step")))
-            note("ab_opt_in_kernels done")
+            # the reference's OWN cuda branch as a labelled line (ref:util/utils.py:120-121: 64x64 crops, do_resize=False, fp16): same
+            # pipeline, f16 plans.  Not the parity mode: its parity class is a token-match RATE against the fp32 oracle
+            # (tests/test_gpu_b_caption_model.py::test_captioner_f16_token_match_rate_r64), not exactness.  Own process, hard limit.
+            out["extra"]["e2e_r64_f16_reference_cuda_branch"] = child_json(
+                [sys.executable, os.path.abspath(__file__), "--steps", "5", "--warmup", "2", "--no-extra", "--no-cpu-baseline", "--caption-res", "64",
+                 "--precision", "f16"], {}, 150,
+                keep=("value", "ms_per_step", "steps", "dtype", ("config", "workload"), ("config", "mean_crops_per_screenshot"),
+                      ("roofline", "gemm_ms_per_step"), ("roofline", "achieved")))
+            note("e2e_r64_f16 done")
             out["extra"]["annotate_tail"] = child_json([sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools",
                                                                                      "annotate_bench.py")], {}, 120)
             note("annotate_tail done")
@@ -351,24 +354,39 @@ def roofline(args, det, parser, dp, crop_counts, B):
         crops = int(round(sum(crop_counts) / max(len(crop_counts), 1)))
         mbs = [128] * (crops // 128) + ([cap.bucket(crops % 128)] if crops % 128 else [])
         per_crop = 0.0
+        merged = crops > 128 and os.environ.get("OMNI_MERGED_DECODE", "1") != "0"      # one decode over all crops (florence.py::_DecodePlans)
+        import torch
         for bucket in sorted(set(mbs)):
             cp = cap._plans.get((bucket, cap.resolution, 20))
             if cp is None:
                 continue
             cnt = mbs.count(bucket)
-            import torch
             with torch.inference_mode(), torch_stream(cap.stream):
                 cp.reset()
             be, ne = profile_plan(cp.encode_plan, cap.stream)
-            bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20)
-            add(be, cnt); add(bs, cnt)
-            gemm_ms += cnt * (be.get(1, 0.0) + bs.get(1, 0.0))
-            launches += cnt * (ne + ns)
-            parts["caption_mb%d_x%d" % (bucket, cnt)] = {
-                "encode_gemm_ms": round(be.get(1, 0.0), 3), "decode20_gemm_ms": round(bs.get(1, 0.0), 3),
-                "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2), "step_gflop_per_crop": round(cp.step_flops / cp.B / 1e9, 4),
-                "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
+            add(be, cnt)
+            gemm_ms += cnt * be.get(1, 0.0)
+            launches += cnt * ne
+            part = {"encode_gemm_ms": round(be.get(1, 0.0), 3), "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2),
+                    "step_gflop_per_crop": round(cp.step_flops / cp.B / 1e9, 4), "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
+            if not merged:
+                bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20)
+                add(bs, cnt)
+                gemm_ms += cnt * bs.get(1, 0.0)
+                launches += cnt * ns
+                part["decode20_gemm_ms"] = round(bs.get(1, 0.0), 3)
+            parts["caption_mb%d_x%d" % (bucket, cnt)] = part
             per_crop = cp.encode_flops / cp.B + 20 * cp.step_flops / cp.B
+        if merged:
+            dec = cap._plans.get(("dec", cap.decode_bucket(crops), cap.resolution, 20))
+            if dec is not None:
+                with torch.inference_mode(), torch_stream(cap.stream):
+                    dec.reset()
+                bs, ns = profile_plan(dec.step_plan, cap.stream, repeat=20)
+                add(bs)
+                gemm_ms += bs.get(1, 0.0)
+                launches += ns
+                parts["decode_rows%d" % dec.B] = {"decode20_gemm_ms": round(bs.get(1, 0.0), 3), "decode20_all_ms": round(sum(bs.values()), 3)}
         flops += crops * per_crop          # ALGORITHMIC: real crops (bucket padding is wasted time, not work)
     achieved = flops / (gemm_ms * 1e-3) / 1e12
     split = args.precision == "f32" and os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
@@ -494,7 +512,7 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
     from tools.make_weights import build_random_captioner
     cap = build_random_captioner(0)
     R = args.caption_res
-    n = 4
+    n = 8
     rng = np.random.default_rng(0)
     img = synthetic_screenshot(0)
     boxes = [(int(x), int(y), int(x) + 60, int(y) + 48) for x, y in zip(rng.integers(0, 1800, n), rng.integers(0, 1000, n))]

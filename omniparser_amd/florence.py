@@ -96,7 +96,146 @@ class FlorenceWeights:
 
 
 # ------------------------------------------------------------------------------------------ plans
-class _CaptionPlans:
+class _StepPlans:
+    """The decoder-step plan over B rows (embedding, 6 BART decoder layers with self-KV cache and fixed cross-KV, lm_head, logits
+    processors + arg-max on the device) and its state: shared by _CaptionPlans (encode + decode of one micro-batch) and _DecodePlans."""
+
+    def _build_step(self, cap, B, max_new, S, cross_kv, ws=None):
+        w, dev, dt = cap.w, cap.device, cap.dtype
+        sd, wc = w.sd, cap._wcache
+        D, nh, lm = w.d_model, w.n_heads, "model.language_model."
+        self.T = max_new + 1
+        pb = PlanBuilder(dev, dt)                          # weights / tables missing from the model's cache are uploaded through it
+
+        def packed(key, make):
+            ck = (key, dt)
+            if ck not in wc:
+                wt, b = make()
+                wc[ck] = (pb.pack_weight(wt if wt.dim() == 4 else wt[:, :, None, None]), pb.upload(b.float()) if b is not None else None)
+            return wc[ck]
+
+        def f32(key):
+            ck = (key, "f32")
+            if ck not in wc:
+                wc[ck] = pb.upload(sd[key].float())
+            return wc[ck]
+
+        pd_ = PlanBuilder(dev, dt)
+        pd_.ws = ws
+        self.pd = pd_
+        T = self.T
+        self.B = B
+        self.ids = pd_.raw((B, T), torch.int32)
+        self.finished = pd_.raw((B,), torch.int32)
+        self.step = pd_.raw((1,), torch.int32)
+        esz = 4 if dt == L.F32 else 2
+
+        def dlinear(key, xin: View, out: View, act=L.ACT_NONE, res=None, keys=None, bias=True):
+            keys = keys or [key]
+            def make():
+                wt = torch.cat([sd[k + ".weight"] for k in keys], 0)
+                b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
+                return wt, b
+            wp, bp = packed("|".join(keys), make)
+            return pd_.conv(xin, wp, bp, out, 1, act=act, res=res)
+
+        def dln(key, xin: View, out: View):
+            pd_.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[xin.ptr, None, f32(key + ".weight").data_ptr(),
+                                                       f32(key + ".bias").data_ptr(), out.ptr],
+                                 i={0: B, 1: 1, 3: D, 5: 0}, f={0: 1e-5}))
+            return out
+
+        ck = ("dectab", dt)
+        if ck not in wc:
+            wc[ck] = (pb.upload(sd[lm + "shared.weight"].to(torch_dtype(dt))),
+                      pb.upload(sd[lm + "decoder.embed_positions.weight"].to(torch_dtype(dt))))
+        table, dpos = wc[ck]
+        pd_.keep += [table, dpos]
+        e = pd_.alloc(B, 1, 1, D)
+        pd_.add_op(L.make_op(L.OP_EMBED_STEP, dt, p=[table.data_ptr(), dpos.data_ptr(), self.ids.data_ptr(), None, e.ptr,
+                                                     None, self.step.data_ptr()],
+                             i={0: B, 3: D, 4: T, 5: 2}, f={0: w.embed_scale}))
+        xd = pd_.alloc(B, 1, 1, D)
+        dln(lm + "decoder.layernorm_embedding", e, xd)
+        dqkv = pd_.alloc(B, 1, 1, 3 * D)
+        dq = pd_.alloc(B, 1, 1, D)
+        da = pd_.alloc(B, 1, 1, D)
+        dt_ = pd_.alloc(B, 1, 1, D)
+        dffn = pd_.alloc(B, 1, 1, sd[lm + "decoder.layers.0.fc1.weight"].shape[0])
+        self.self_k = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
+        self.self_v = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
+        for l in range(w.dec_layers):
+            pre = f"{lm}decoder.layers.{l}."
+            dlinear(None, xd, dqkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
+            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
+                                 p=[dqkv.ptr, dqkv.ptr, dqkv.ptr, self.self_k[l].ptr, da.ptr, self.self_v[l].ptr, self.step.data_ptr()],
+                                 i={0: 3 * D, 1: 0, 2: 3 * D, 3: D, 4: 2 * D, 5: D, 6: nh, 7: 0, 8: T, 9: D, 10: B, 11: D},
+                                 f={0: 64 ** -0.5}))
+            dlinear(pre + "self_attn.out_proj", da, dt_, res=xd)
+            dln(pre + "self_attn_layer_norm", dt_, xd)
+            dlinear(pre + "encoder_attn.q_proj", xd, dq)
+            kv = self.cross_kv[l]
+            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
+                                 p=[dq.ptr, None, None, kv.ptr, da.ptr, kv.ptr + D * esz, None],
+                                 i={0: D, 1: 0, 2: 0, 3: 0, 4: 0, 5: D, 6: nh, 7: S, 8: S, 9: D, 10: B, 11: 2 * D},
+                                 f={0: 64 ** -0.5}))
+            dlinear(pre + "encoder_attn.out_proj", da, dt_, res=xd)
+            dln(pre + "encoder_attn_layer_norm", dt_, xd)
+            dlinear(pre + "fc1", xd, dffn, act=L.ACT_GELU)
+            dlinear(pre + "fc2", dffn, dt_, res=xd)
+            dln(pre + "final_layer_norm", dt_, xd)
+        logits = pd_.alloc(B, 1, 1, w.vocab)
+        self.logits = logits
+        wp, _ = packed("lm_head", lambda: (sd["lm_head.weight"], None))
+        pd_.conv(xd, wp, None, logits, 1)
+        flb = None
+        if "final_logits_bias" in sd:
+            flb = f32("final_logits_bias")
+            pd_.keep.append(flb)
+        pd_.add_op(L.make_op(L.OP_GREEDY_STEP, dt,
+                             p=[logits.ptr, flb.data_ptr() if flb is not None else None, self.ids.data_ptr(),
+                                self.finished.data_ptr(), None, None, self.step.data_ptr()],
+                             i={0: B, 1: w.vocab, 2: w.vocab, 3: T, 4: max_new, 5: w.ngram, 6: w.bos, 7: w.eos, 8: w.pad,
+                                9: w.forced_bos, 10: w.forced_eos, 11: 1}))
+        self.step_flops = pd_.flops
+        self.step_plan = pd_.build()
+        self.start_token = w.start
+
+    def reset(self):
+        self.ids.zero_()
+        self.ids[:, 0] = self.start_token
+        self.finished.zero_()
+        self.step.zero_()
+
+
+class _DecodePlans(_StepPlans):
+    """Decode for the crops of SEVERAL caption micro-batches at once.  The encode side of a batch of screenshots runs in micro-batches
+    of <= 128 crops (60 GB of activations each at 768x768); the decode side is 20 steps of ~110 small kernels whose cost hardly
+    depends on the row count (launch-bound GEMMs over 128 rows) — per micro-batch that was 29 ms, 80 ms of a 750 ms step.  Here the
+    cross-attention K / V of every micro-batch are copied (6 x 460 MB per 128 crops, ~1 ms) into the row range of ONE decode plan over
+    B rows, which then runs its 20 steps once.  Rows are independent: ids per crop are what the per-micro-batch decode produces
+    (same kernels; the split-K choice of the step GEMMs, hence the last bits of the logits, depends on the row count)."""
+
+    def __init__(self, cap: "Florence2Captioner", B: int, R: int, max_new: int):
+        w, dev, dt = cap.w, cap.device, cap.dtype
+        self.B, self.R = B, R
+        S = (R // 32) ** 2 + 1 + len(PROMPT_IDS)
+        self.S = S
+        pk = PlanBuilder(dev, dt)
+        self.cross_kv = [pk.alloc(B, S, 1, 2 * w.d_model) for _ in range(w.dec_layers)]
+        self._keep = pk.keep
+        self._build_step(cap, B, max_new, S, self.cross_kv)
+        if dev.type == "cuda":
+            torch.cuda.synchronize(dev)
+        if cap.use_graph:
+            self.reset()
+            self.step_plan.run(cap.stream)
+            cap.stream.synchronize()
+            self.step_plan.capture(cap.stream)
+            cap.stream.synchronize()
+
+
+class _CaptionPlans(_StepPlans):
     """Static plans for B crops at resolution R."""
 
     def __init__(self, cap: "Florence2Captioner", B: int, R: int, max_new: int):
@@ -345,86 +484,8 @@ class _CaptionPlans:
         self.n_encode_ops = len(pb.ops)
         self.encode_flops = pb.flops
         self.encode_plan = pb.build()
-        # ---------------- decoder step plan
-        pd_ = PlanBuilder(dev, dt)
-        pd_.ws = pb.ws
-        self.pd = pd_
-        T = self.T
-        self.ids = pd_.raw((B, T), torch.int32)
-        self.finished = pd_.raw((B,), torch.int32)
-        self.step = pd_.raw((1,), torch.int32)
-        esz = 4 if dt == L.F32 else 2
-
-        def dlinear(key, xin: View, out: View, act=L.ACT_NONE, res=None, keys=None, bias=True):
-            keys = keys or [key]
-            def make():
-                wt = torch.cat([sd[k + ".weight"] for k in keys], 0)
-                b = torch.cat([sd[k + ".bias"] for k in keys], 0) if bias else None
-                return wt, b
-            wp, bp = packed("|".join(keys), make)
-            return pd_.conv(xin, wp, bp, out, 1, act=act, res=res)
-
-        def dln(key, xin: View, out: View):
-            pd_.add_op(L.make_op(L.OP_LAYERNORM, dt, p=[xin.ptr, None, f32(key + ".weight").data_ptr(),
-                                                       f32(key + ".bias").data_ptr(), out.ptr],
-                                 i={0: B, 1: 1, 3: D, 5: 0}, f={0: 1e-5}))
-            return out
-
-        ck = ("dectab", dt)
-        if ck not in wc:
-            wc[ck] = (pb.upload(sd[lm + "shared.weight"].to(torch_dtype(dt))),
-                      pb.upload(sd[lm + "decoder.embed_positions.weight"].to(torch_dtype(dt))))
-        table, dpos = wc[ck]
-        pd_.keep += [table, dpos]
-        e = pd_.alloc(B, 1, 1, D)
-        pd_.add_op(L.make_op(L.OP_EMBED_STEP, dt, p=[table.data_ptr(), dpos.data_ptr(), self.ids.data_ptr(), None, e.ptr,
-                                                     None, self.step.data_ptr()],
-                             i={0: B, 3: D, 4: T, 5: 2}, f={0: w.embed_scale}))
-        xd = pd_.alloc(B, 1, 1, D)
-        dln(lm + "decoder.layernorm_embedding", e, xd)
-        dqkv = pd_.alloc(B, 1, 1, 3 * D)
-        dq = pd_.alloc(B, 1, 1, D)
-        da = pd_.alloc(B, 1, 1, D)
-        dt_ = pd_.alloc(B, 1, 1, D)
-        dffn = pd_.alloc(B, 1, 1, sd[lm + "decoder.layers.0.fc1.weight"].shape[0])
-        self.self_k = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
-        self.self_v = [pd_.alloc(B, T, 1, D) for _ in range(w.dec_layers)]
-        for l in range(w.dec_layers):
-            pre = f"{lm}decoder.layers.{l}."
-            dlinear(None, xd, dqkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
-            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
-                                 p=[dqkv.ptr, dqkv.ptr, dqkv.ptr, self.self_k[l].ptr, da.ptr, self.self_v[l].ptr, self.step.data_ptr()],
-                                 i={0: 3 * D, 1: 0, 2: 3 * D, 3: D, 4: 2 * D, 5: D, 6: nh, 7: 0, 8: T, 9: D, 10: B, 11: D},
-                                 f={0: 64 ** -0.5}))
-            dlinear(pre + "self_attn.out_proj", da, dt_, res=xd)
-            dln(pre + "self_attn_layer_norm", dt_, xd)
-            dlinear(pre + "encoder_attn.q_proj", xd, dq)
-            kv = self.cross_kv[l]
-            pd_.add_op(L.make_op(L.OP_ATTN_DECODE, dt,
-                                 p=[dq.ptr, None, None, kv.ptr, da.ptr, kv.ptr + D * esz, None],
-                                 i={0: D, 1: 0, 2: 0, 3: 0, 4: 0, 5: D, 6: nh, 7: S, 8: S, 9: D, 10: B, 11: 2 * D},
-                                 f={0: 64 ** -0.5}))
-            dlinear(pre + "encoder_attn.out_proj", da, dt_, res=xd)
-            dln(pre + "encoder_attn_layer_norm", dt_, xd)
-            dlinear(pre + "fc1", xd, dffn, act=L.ACT_GELU)
-            dlinear(pre + "fc2", dffn, dt_, res=xd)
-            dln(pre + "final_layer_norm", dt_, xd)
-        logits = pd_.alloc(B, 1, 1, w.vocab)
-        self.logits = logits
-        wp, _ = packed("lm_head", lambda: (sd["lm_head.weight"], None))
-        pd_.conv(xd, wp, None, logits, 1)
-        flb = None
-        if "final_logits_bias" in sd:
-            flb = f32("final_logits_bias")
-            pd_.keep.append(flb)
-        pd_.add_op(L.make_op(L.OP_GREEDY_STEP, dt,
-                             p=[logits.ptr, flb.data_ptr() if flb is not None else None, self.ids.data_ptr(),
-                                self.finished.data_ptr(), None, None, self.step.data_ptr()],
-                             i={0: B, 1: w.vocab, 2: w.vocab, 3: T, 4: max_new, 5: w.ngram, 6: w.bos, 7: w.eos, 8: w.pad,
-                                9: w.forced_bos, 10: w.forced_eos, 11: 1}))
-        self.step_flops = pd_.flops
-        self.step_plan = pd_.build()
-        self.start_token = w.start
+        # ---------------- decoder step plan (for a single micro-batch; batches of several micro-batches decode through _DecodePlans)
+        self._build_step(cap, B, max_new, S, self.cross_kv, pb.ws)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)      # allocations / uploads ran on the current stream: order them before cap.stream
         if cap.use_graph:
@@ -434,12 +495,6 @@ class _CaptionPlans:
             self.encode_plan.capture(cap.stream)
             self.step_plan.capture(cap.stream)
             cap.stream.synchronize()
-
-    def reset(self):
-        self.ids.zero_()
-        self.ids[:, 0] = self.start_token
-        self.finished.zero_()
-        self.step.zero_()
 
 
 # ------------------------------------------------------------------------------------------ public objects
@@ -488,6 +543,21 @@ class Florence2Captioner:
                 return b
         return _BUCKETS[-1]
 
+    @staticmethod
+    def decode_bucket(n: int) -> int:
+        """row capacity of the merged decode plan for n crops: multiples of 128 (the unused tail rows are computed and ignored)."""
+        return max(128, (n + 127) // 128 * 128)
+
+    @torch.inference_mode()
+    def decode_plans(self, B, R, max_new) -> _DecodePlans:
+        key = ("dec", B, R, max_new)
+        if key not in self._plans:
+            with torch.cuda.device(self.device):
+                self._plans[key] = _DecodePlans(self, B, R, max_new)
+        else:
+            self._plans[key] = self._plans.pop(key)
+        return self._plans[key]
+
     @torch.inference_mode()
     def plans(self, B, R, max_new) -> _CaptionPlans:
         key = (B, R, max_new)
@@ -500,6 +570,18 @@ class Florence2Captioner:
         with torch.cuda.device(self.device):
             self._plans[key] = _CaptionPlans(self, B, R, max_new)
         return self._plans[key]
+
+    # ---- merged decode (several micro-batches): encode only, cross-KV into rows [row0, row0 + n) of the decode plan
+    def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int):
+        (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(self.stream)
+        for src, dst in zip(cp.cross_kv, dec.cross_kv):
+            dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)
+
+    def _decode_merged(self, dec: _DecodePlans, n: int, max_new: int) -> torch.Tensor:
+        run = dec.step_plan.replay if self.use_graph else dec.step_plan.run
+        for _ in range(max_new):
+            run(self.stream)
+        return dec.ids[:n].clone()                 # stream-ordered snapshot (read back by the caller)
 
     # ---- decode loop shared by both entry points
     def _run(self, cp: _CaptionPlans, n: int, max_new: int, defer: bool = False) -> torch.Tensor:

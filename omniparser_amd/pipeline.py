@@ -279,12 +279,20 @@ class ScreenParser:
                 b, k = L.resample_coeffs(64, R, 1)
                 cap._bic = (torch.from_numpy(b).to(cap.device), torch.from_numpy(k).to(cap.device), k.shape[1])
         esz = 4 if cap.dtype == L.F32 else 2
+        # more than one micro-batch: the encode side runs per micro-batch, the 20 decode steps ONCE over all crops
+        # (florence.py::_DecodePlans); OMNI_MERGED_DECODE=0 = every micro-batch decodes on its own (A/B knob)
+        merged = len(flat) > self.batch_size and os.environ.get("OMNI_MERGED_DECODE", "1") != "0"
+        dec = cap.decode_plans(cap.decode_bucket(len(flat)), R, max_new_tokens) if merged else None
+        if merged:
+            with torch.cuda.stream(cap.stream):
+                dec.reset()
         for s in range(0, len(flat), self.batch_size):
             chunk = flat[s:s + self.batch_size]
             n = len(chunk)
             cp = cap.plans(cap.bucket(n), R, max_new_tokens)
             with torch.cuda.stream(cap.stream):
-                cp.reset()
+                if not merged:
+                    cp.reset()
                 c64 = torch.empty((n, 64, 64, 3), dtype=torch.uint8, device=cap.device)
                 tmp = torch.empty((n, 64, R, 3), dtype=torch.uint8, device=cap.device) if R != 64 else None
                 bb, kk, ks = cap._bic if R != 64 else (None, None, 0)
@@ -307,7 +315,13 @@ class ScreenParser:
                         f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
                     L.launch(op, cap.stream)
                     o = e
-                ids_all.append(cap._run(cp, n, max_new_tokens, defer=True))   # keep the GPU fed: no sync between micro-batches
+                if merged:
+                    cap._encode_into(cp, n, dec, s)
+                else:
+                    ids_all.append(cap._run(cp, n, max_new_tokens, defer=True))   # keep the GPU fed: no sync between micro-batches
+        if merged:
+            with torch.cuda.stream(cap.stream):
+                ids_all.append(cap._decode_merged(dec, len(flat), max_new_tokens))
         return (list(frames), flat, ids_all)
 
     @torch.inference_mode()

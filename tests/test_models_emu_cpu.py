@@ -137,3 +137,28 @@ def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):
         assert [[r.tolist() for r in f] for f in ids_g] == [[r.tolist() for r in f] for f in ids_w]
     assert sum(len(c) for b in crops_want for c in b) >= 12
     assert len({tuple(r.tolist()) for _, ids in want for f in ids for r in f}) >= 10        # the fingerprints tell crops apart
+
+
+def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
+    """ScreenParser.caption over more crops than one micro-batch holds: encode per micro-batch, cross-attention K / V copied into ONE
+    decode plan, 20 (here 2) steps over all rows at once (florence.py::_DecodePlans) — the same ids as decoding every micro-batch on its
+    own (OMNI_MERGED_DECODE=0)."""
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_screenshot
+    from tools.make_weights import ensure_caption_checkpoint
+    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    monkeypatch.setattr(Florence2Captioner, "decode_bucket", staticmethod(lambda n: 8))       # a 128-row lm_head step costs the emulation minutes
+    frame = torch.from_numpy(synthetic_screenshot(3, 640, 480))
+    rects = [[[10, 20, 60, 70], [300, 200, 340, 260], [500, 100, 620, 140]], [[40, 40, 90, 80], [200, 300, 280, 360]]]
+    got = {}
+    for mode in ("1", "0"):
+        monkeypatch.setenv("OMNI_MERGED_DECODE", mode)
+        sp = ScreenParser(None, cap, batch_size=2)
+        sp.max_new_tokens = 2
+        out = sp.caption([frame, frame], rects)
+        got[mode] = [[row.tolist() for _, row in f] for f in out]
+    assert any(k[0] == "dec" for k in cap._plans)                                          # the merged path ran
+    assert [len(f) for f in got["1"]] == [3, 2]
+    strip = lambda rows: [[t for t in r if t != cap.w.pad] for r in rows]
+    assert [strip(f) for f in got["1"]] == [strip(f) for f in got["0"]]
