@@ -270,6 +270,12 @@ class CModel:
                                            bx.ctypes.data_as(POINTER(c_int32)), bx.shape[0], ids.ctypes.data_as(POINTER(c_int32))))
         return ids
 
+    def tensor(self, name):
+        """(device pointer, nbytes) of a named tensor of the bundle (omni_model_tensor)."""
+        p, n = c_void_p(), ctypes.c_longlong()
+        check(lib().omni_model_tensor(self._h, name.encode(), ctypes.byref(p), ctypes.byref(n)))
+        return p.value, n.value
+
     def close(self):
         if self._h:
             lib().omni_model_destroy(self._h)

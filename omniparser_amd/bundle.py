@@ -176,7 +176,9 @@ def export_captioner(cap, path, capacity=8, max_new_tokens=20):
     c64 = pb.raw((capacity, 64, 64, 3), torch.uint8)
     t = lambda x: (x, 0, x.numel() * x.element_size())
     named = {"x_in": t(cp.x_in.t), "ids": t(cp.ids), "finished": t(cp.finished), "step": t(cp.step), "lut": t(lut), "boxes": t(boxes),
-             "c64": t(c64)}
+             "c64": t(c64),
+             # read-only taps for hosts that want the intermediate results (omni_model_tensor): DaViT output, encoder output, last logits
+             "vision_out": t(cp.vision_out.t), "enc_out": t(cp.enc_out.t), "logits": t(cp.logits.t)}
     ks = 0
     if R != 64:
         b, k = L.resample_coeffs(64, R, 1)

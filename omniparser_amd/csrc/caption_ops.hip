@@ -1710,6 +1710,9 @@ __global__ __launch_bounds__(256) void crop_bilinear64_kernel(CropArgs a) {
   if (idx >= 64 * 64) return;
   int dy = idx >> 6, dx = idx & 63;
   int x0 = a.boxes[crop * 4 + 0], y0 = a.boxes[crop * 4 + 1], x1 = a.boxes[crop * 4 + 2], y1 = a.boxes[crop * 4 + 3];
+  // numpy slicing image_source[ymin:ymax, xmin:xmax] (ref:util/utils.py:99) clips the rectangle to the image; a rectangle that is
+  // empty after clipping (the reference's cv2.resize raises on it) gives a black crop — the kernel never reads outside the frame
+  x0 = min(max(x0, 0), a.W); x1 = min(max(x1, 0), a.W); y0 = min(max(y0, 0), a.H); y1 = min(max(y1, 0), a.H);
   int sw = x1 - x0, sh = y1 - y0;
   unsigned char* dst = a.c64 + ((long long)crop * 4096 + idx) * 3;
   if (sw <= 0 || sh <= 0) { dst[0] = dst[1] = dst[2] = 0; return; }

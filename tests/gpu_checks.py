@@ -873,7 +873,8 @@ def check_caption_ops(dtype=L.F32, seed=0):
     # crop_resize at both resolutions (exact vs the oracle restatement + real Pillow)
     from omniparser_amd.synth import synthetic_screenshot
     img = torch.from_numpy(synthetic_screenshot(3, 640, 360))
-    boxes = torch.tensor([[10, 20, 74, 84], [100, 50, 228, 178], [300, 10, 333, 47], [0, 0, 640, 360], [5, 5, 13, 9]], dtype=torch.int32)
+    boxes = torch.tensor([[10, 20, 74, 84], [100, 50, 228, 178], [300, 10, 333, 47], [0, 0, 640, 360], [5, 5, 13, 9],
+                          [600, 340, 700, 400]], dtype=torch.int32)      # the last one leaves the frame: numpy slicing clips it (ref:util/utils.py:99)
     lut = torch.from_numpy((np.arange(256).astype(np.float64) * (1 / 255)).astype(np.float32))
     for Rr in (64, 96):
         n = boxes.shape[0]

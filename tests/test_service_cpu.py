@@ -54,6 +54,9 @@ class _Proc:
 class _Screen(ScreenParser):
     """Real glue + real batch bookkeeping; device stages replaced by the same stubs the single-image path uses."""
     calls = 0
+    def __init__(self, *a, **k):
+        super().__init__(*a, **k)
+        self.device_glue = False            # the stub detector has no plan to append the hand-off kernel to: host twin
     def detect(self, frames, pad_to=None):
         type(self).calls += 1
         return [_boxes_for(f.numpy()) for f in frames]
