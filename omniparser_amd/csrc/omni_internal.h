@@ -31,6 +31,13 @@ void omni_set_error(const char* fmt, ...);
 #define OMNI_WAIT_VMCNT(n) asm volatile("s_waitcnt vmcnt(%0)" ::"n"(n) : "memory")
 #endif
 
+// this wave's LDS reads have returned (placed in front of a barrier that releases the buffer they read to other waves' LDS-DMA)
+#ifdef OMNI_HOST_EMU
+#define OMNI_WAIT_LGKM0() ((void)0)
+#else
+#define OMNI_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
+#endif
+
 // dynamically sized LDS array of a kernel (size = the launch's shared-memory argument)
 #ifndef OMNI_DYN_LDS
 #define OMNI_DYN_LDS(type, name) extern __shared__ type name[]

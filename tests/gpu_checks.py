@@ -123,7 +123,7 @@ GEMM_DMA_CASES = [
 ]
 
 
-def check_gemm_dma(seed=0, cases=None, tiles=(None, "256x128", "128x128")):
+def check_gemm_dma(seed=0, cases=None, tiles=(None, "256x128", "128x128", "256x256w4", "256x128k16")):
     """csrc/gemm_dma.hip through OMNI_OP_CONV i20 = 2 vs an f64 matmul of the SAME (decoded) operands, every tile
     configuration; format-B outputs are decoded with the test interpreter's reader.  Also checks the producers:
     split_convert (in place) and LayerNorm's split / dual outputs against the interpreter's encoder (bitwise)."""

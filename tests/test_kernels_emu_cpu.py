@@ -24,6 +24,8 @@ SMALL_GEMM_DMA = [
     (260, 128, 512, 128, 0, 512, 0, False, L.ACT_GELU, True),
     (513, 32, 256, 64, 32, 512, 256, False, L.ACT_NONE, False),
     (5, 512, 256, 512, 0, 256, 0, False, L.ACT_NONE, False),
+    (70, 64, 128, 64, 0, 128, 0, False, L.ACT_NONE, False),        # two K slices: prologue + drain only
+    (70, 96, 256, 96, 0, 256, 0, True, L.ACT_NONE, False),          # three K slices
 ]
 
 
@@ -49,7 +51,7 @@ def test_conv_igemm_exact_f32_path(emu, monkeypatch):
 def test_gemm_dma_presplit_every_tile(emu):
     import gpu_checks as G
     r = G.check_gemm_dma(cases=SMALL_GEMM_DMA)
-    assert r["cases"] == 3 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
+    assert r["cases"] == 5 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
 
 
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])

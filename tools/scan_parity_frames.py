@@ -23,7 +23,15 @@ CASES = {1.0: [(s, 640, 1920, 1080) for s in range(8)],
 
 
 def main():
-    widths = [float(a) for a in sys.argv[1:]] or [0.25, 0.5, 1.0]
+    # `--seeds A:B` scans full-HD frames A..B-1 at 640x640 for the widths given (choosing the bench's tie-free frames)
+    args = sys.argv[1:]
+    if "--seeds" in args:
+        k = args.index("--seeds")
+        lo, hi = (int(v) for v in args[k + 1].split(":"))
+        del args[k:k + 2]
+        for w in (float(a) for a in args) if args else (1.0,):
+            CASES[w] = [(s, 640, 1920, 1080) for s in range(lo, hi)]
+    widths = [float(a) for a in args] or [0.25, 0.5, 1.0]
     thr = math.log(0.05 / 0.95)
     print("| width | seed | frame | net input | boxes | candidates | noise f32-f64 | thr margin | near ties | score ties | IoU margin | score gap |")
     print("|---|---|---|---|---|---|---|---|---|---|---|---|")
