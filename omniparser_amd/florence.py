@@ -225,6 +225,7 @@ class _DecodePlans(_StepPlans):
         self.cross_kv = [pk.alloc(B, S, 1, 2 * w.d_model) for _ in range(w.dec_layers)]
         self._keep = pk.keep
         self._build_step(cap, B, max_new, S, self.cross_kv)
+        self.free_evt = None       # recorded behind the decode that last used this plan on another stream (pipelined batches)
         if dev.type == "cuda":
             torch.cuda.synchronize(dev)
         if cap.use_graph:
@@ -481,6 +482,7 @@ class _CaptionPlans(_StepPlans):
             kv = pb.alloc(B, S, 1, 2 * D)
             linear(None, xin, kv, keys=[pre + "k_proj", pre + "v_proj"])
             self.cross_kv.append(kv)
+        self.free_evt = None        # recorded behind the last use of this plan's buffers when that was on another stream (parse_stream)
         self.n_encode_ops = len(pb.ops)
         self.encode_flops = pb.flops
         self.encode_plan = pb.build()
@@ -549,8 +551,10 @@ class Florence2Captioner:
         return max(128, (n + 127) // 128 * 128)
 
     @torch.inference_mode()
-    def decode_plans(self, B, R, max_new) -> _DecodePlans:
-        key = ("dec", B, R, max_new)
+    def decode_plans(self, B, R, max_new, slot=0) -> _DecodePlans:
+        """slot: the pipelined stream (pipeline.py::parse_stream) decodes batch i on its own HIP stream while batch i+1 encodes, so it
+        alternates between two decode plans (8 GB of cross-attention K/V each at 384 rows, 768x768 crops)."""
+        key = ("dec", B, R, max_new) if slot == 0 else ("dec", B, R, max_new, slot)
         if key not in self._plans:
             with torch.cuda.device(self.device):
                 self._plans[key] = _DecodePlans(self, B, R, max_new)
@@ -559,29 +563,50 @@ class Florence2Captioner:
         return self._plans[key]
 
     @torch.inference_mode()
-    def plans(self, B, R, max_new) -> _CaptionPlans:
-        key = (B, R, max_new)
+    def plans(self, B, R, max_new, slot=0) -> _CaptionPlans:
+        """slot 1 = a second, independent set of buffers of the same capacity: the pipelined stream (pipeline.py::parse_stream) keeps two
+        128-crop micro-batches in flight on two HIP streams (60 GB of activations each at 768x768)."""
+        key = (B, R, max_new) if slot == 0 else (B, R, max_new, slot)
         if key in self._plans:
             self._plans[key] = self._plans.pop(key)
             return self._plans[key]
         while len(self._plans) >= int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "6")):   # LRU bound on activation pools
-            self.stream.synchronize()                       # deferred read-backs may still be running on the evicted plan's buffers
+            torch.cuda.synchronize(self.device)             # work of any of the captioner's streams may still use the evicted plan's buffers
             self._plans.pop(next(iter(self._plans)))
         with torch.cuda.device(self.device):
             self._plans[key] = _CaptionPlans(self, B, R, max_new)
         return self._plans[key]
 
     # ---- merged decode (several micro-batches): encode only, cross-KV into rows [row0, row0 + n) of the decode plan
-    def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int):
-        (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(self.stream)
+    def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int, stream=None):
+        """encode on `stream` (default: the captioner's first stream; the caller made it current)."""
+        (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream or self.stream)
         for src, dst in zip(cp.cross_kv, dec.cross_kv):
             dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)
 
-    def _decode_merged(self, dec: _DecodePlans, n: int, max_new: int) -> torch.Tensor:
+    def _decode_merged(self, dec: _DecodePlans, n: int, max_new: int, stream=None) -> torch.Tensor:
+        """the 20 decode steps over all rows of `dec` on `stream` (default: the captioner's stream; the caller made it current)."""
+        stream = stream or self.stream
         run = dec.step_plan.replay if self.use_graph else dec.step_plan.run
         for _ in range(max_new):
-            run(self.stream)
+            run(stream)
         return dec.ids[:n].clone()                 # stream-ordered snapshot (read back by the caller)
+
+    @property
+    def stream2(self):
+        """second encode lane of the pipelined stream: while one 128-crop micro-batch is in its MFMA-bound GEMMs the other one's
+        HBM-bound kernels (depthwise conv + LayerNorm, attention, short-K GEMMs) fill the wave slots the GEMM blocks leave free."""
+        if getattr(self, "_stream2", None) is None:
+            self._stream2 = torch.cuda.Stream(device=self.device)
+        return self._stream2
+
+    @property
+    def dec_stream(self):
+        """second HIP stream of the captioner: decode steps of batch i (launch-bound GEMMs over a few hundred rows + the HBM-bound
+        cross-attention) overlap the MFMA-bound encode of batch i+1 (pipeline.py::parse_stream)."""
+        if getattr(self, "_dec_stream", None) is None:
+            self._dec_stream = torch.cuda.Stream(device=self.device)
+        return self._dec_stream
 
     # ---- decode loop shared by both entry points
     def _run(self, cp: _CaptionPlans, n: int, max_new: int, defer: bool = False) -> torch.Tensor:

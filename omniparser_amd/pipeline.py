@@ -7,6 +7,7 @@ caption micro-batches (ref batch_size=128) -> on-device greedy decode.  Results 
 `get_som_labeled_img(...)[2]` call (same functions underneath); only the packing differs.
 """
 import os
+from types import SimpleNamespace
 from typing import List, Optional, Sequence
 
 import numpy as np
@@ -83,6 +84,7 @@ class ScreenParser:
         self.box_threshold, self.iou_threshold, self.nms_iou = box_threshold, iou_threshold, nms_iou
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
         self.max_new_tokens = 20          # ref:util/utils.py:125 generate(max_new_tokens=20)
+        self.encode_lanes = 2             # parse_stream: caption micro-batches in flight at once (HIP streams; 1 = one after the other)
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
@@ -189,7 +191,10 @@ class ScreenParser:
                 for b, t in zip(ocr_r, ocr_text) if U.int_box_area(b, w, h) > 0]
 
     @torch.inference_mode()
-    def detect_glue(self, frames, ocr, pad_to=None):
+    def detect_glue(self, frames, ocr, pad_to=None, snapshot=False):
+        """snapshot: the tables the rest of the batch reads (detector outputs, element table, donor masks, crop rectangles: ~0.5 MB)
+        are copied behind the graph on the detector's stream and returned instead of the plan's own buffers, so the NEXT batch's
+        detector pass may overwrite those while this batch is still being captioned (parse_stream)."""
         ih, iw = frames[0].shape[:2]
         det = self.det
         dp = det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
@@ -223,8 +228,13 @@ class ScreenParser:
             gs.ocr.copy_(gs.h_ocr)
             gs.meta.copy_(gs.h_meta)
             gs.launch(det)                                        # detector + hand-off: one graph
-            counts = gs.counts.cpu()                              # the one synchronising read-back: 4 ints per frame
-        return dp, gs, ocr_els, counts
+            tables = (dp, gs)
+            if snapshot:
+                snap = SimpleNamespace(out_boxes=dp.out_boxes.clone(), out_count=dp.out_count.clone(), elems=gs.elems.clone(),
+                                       donors=gs.donors.clone(), crops=gs.crops.clone())
+                tables = (snap, snap)
+            counts = gs.counts.to("cpu", copy=True)               # the one synchronising read-back: 4 ints per frame
+        return tables[0], tables[1], ocr_els, counts
 
     @torch.inference_mode()
     def assemble(self, dp, gs, ocr_els, counts, iw, ih, n_frames):
@@ -262,9 +272,12 @@ class ScreenParser:
         return self.caption_finish(self.caption_launch(frames, crops_per_frame, max_new_tokens, crops_dev))
 
     @torch.inference_mode()
-    def caption_launch(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=None, crops_dev: Optional[torch.Tensor] = None):
+    def caption_launch(self, frames: Sequence[torch.Tensor], crops_per_frame, max_new_tokens=None, crops_dev: Optional[torch.Tensor] = None,
+                       overlap=False):
         """queue the crop / encode / decode work of every micro-batch on the captioner's stream; nothing is read back.  The handle
-        keeps the frames alive until `caption_finish`."""
+        keeps the frames alive until `caption_finish`.  overlap (parse_stream): micro-batches alternate between `self.encode_lanes`
+        HIP streams, and the merged decode runs on a further stream on one of two alternating decode plans, so the next batch's
+        encode does not wait for it."""
         cap = self.cap
         R = cap.resolution
         max_new_tokens = max_new_tokens or self.max_new_tokens
@@ -282,15 +295,30 @@ class ScreenParser:
         # more than one micro-batch: the encode side runs per micro-batch, the 20 decode steps ONCE over all crops
         # (florence.py::_DecodePlans); OMNI_MERGED_DECODE=0 = every micro-batch decodes on its own (A/B knob)
         merged = len(flat) > self.batch_size and os.environ.get("OMNI_MERGED_DECODE", "1") != "0"
-        dec = cap.decode_plans(cap.decode_bucket(len(flat)), R, max_new_tokens) if merged else None
-        if merged:
+        # overlap (parse_stream): micro-batches alternate between two encode lanes (HIP streams); 128-row plans exist once per lane, the
+        # smaller capacities once — a plan's `free_evt` orders its next use, on whichever lane, behind its last one
+        lanes = [cap.stream, cap.stream2][:max(1, self.encode_lanes)] if overlap else [cap.stream]
+        if overlap and merged:
+            self._dec_slot = 1 - getattr(self, "_dec_slot", 1)
+        dec = cap.decode_plans(cap.decode_bucket(len(flat)), R, max_new_tokens, slot=self._dec_slot if overlap else 0) if merged else None
+        if merged and not overlap:
             with torch.cuda.stream(cap.stream):
                 dec.reset()
-        for s in range(0, len(flat), self.batch_size):
+        used = []
+        for mbi, s in enumerate(range(0, len(flat), self.batch_size)):
             chunk = flat[s:s + self.batch_size]
             n = len(chunk)
-            cp = cap.plans(cap.bucket(n), R, max_new_tokens)
-            with torch.cuda.stream(cap.stream):
+            lane = 0
+            if overlap and merged:
+                lane = self._mb_count = (getattr(self, "_mb_count", -1) + 1) % len(lanes)
+            stream = lanes[lane]
+            bucket = cap.bucket(n)
+            cp = cap.plans(bucket, R, max_new_tokens, slot=lane if bucket == 128 else 0)
+            with torch.cuda.stream(stream):
+                if cp.free_evt is not None:
+                    stream.wait_event(cp.free_evt)
+                if merged and dec.free_evt is not None and stream not in used:
+                    stream.wait_event(dec.free_evt)      # the decode two batches ago read this decode plan's cross-attention K/V
                 if not merged:
                     cp.reset()
                 c64 = torch.empty((n, 64, 64, 3), dtype=torch.uint8, device=cap.device)
@@ -313,24 +341,38 @@ class ScreenParser:
                            kk.data_ptr() if kk is not None else None, cap._lut.data_ptr()],
                         i={0: e - o, 1: H, 2: W, 3: R, 4: ks, 13: cp.x_in.ld},
                         f={0: CLIP_MEAN[0], 1: CLIP_MEAN[1], 2: CLIP_MEAN[2], 3: CLIP_STD[0], 4: CLIP_STD[1], 5: CLIP_STD[2]})
-                    L.launch(op, cap.stream)
+                    L.launch(op, stream)
                     o = e
                 if merged:
-                    cap._encode_into(cp, n, dec, s)
+                    cap._encode_into(cp, n, dec, s, stream)
                 else:
                     ids_all.append(cap._run(cp, n, max_new_tokens, defer=True))   # keep the GPU fed: no sync between micro-batches
-        if merged:
+                if overlap:
+                    cp.free_evt = stream.record_event()
+            if stream not in used:
+                used.append(stream)
+        ids_stream = cap.stream
+        if merged and not overlap:
             with torch.cuda.stream(cap.stream):
                 ids_all.append(cap._decode_merged(dec, len(flat), max_new_tokens))
-        return (list(frames), flat, ids_all)
+        elif merged:
+            ids_stream = cap.dec_stream
+            encoded = [st.record_event() for st in used]
+            with torch.cuda.stream(ids_stream):
+                for ev in encoded:
+                    ids_stream.wait_event(ev)
+                dec.reset()
+                ids_all.append(cap._decode_merged(dec, len(flat), max_new_tokens, ids_stream))
+                dec.free_evt = ids_stream.record_event()
+        return (list(frames), flat, ids_all, ids_stream)
 
     @torch.inference_mode()
     def caption_finish(self, handle):
-        frames, flat, ids_all = handle
+        frames, flat, ids_all, ids_stream = handle
         cap = self.cap
-        # single read-back point.  The snapshots were produced on cap.stream (a non-blocking stream: the default stream does
-        # not order against it), so the copies are issued ON that stream — stream order alone makes them see the finished ids
-        with torch.cuda.stream(cap.stream):
+        # single read-back point.  The snapshots were produced on one of the captioner's streams (non-blocking streams: the default
+        # stream does not order against them), so the copies are issued ON that stream — stream order alone makes them see the finished ids
+        with torch.cuda.stream(ids_stream):
             ids_all = [t.cpu() for t in ids_all]
         ids_all = [cap._finish_ids(t.long()) for t in ids_all]
         out = [[] for _ in frames]
@@ -359,8 +401,7 @@ class ScreenParser:
         `parse_batch`.  (Host hand-off only: with OMNI_DEVICE_GLUE the crop table of a batch lives in per-plan device buffers.)"""
         from concurrent.futures import ThreadPoolExecutor
         if self.device_glue:
-            for frames, ocr in batches:
-                yield self.parse_batch(frames, ocr, return_ids=return_ids, pad_to=pad_to)
+            yield from self._parse_stream_device(batches, return_ids, pad_to)
             return
 
         def stage_a(frames, ocr):
@@ -378,13 +419,7 @@ class ScreenParser:
             handle, elems_all, crops_all, nbox = pending
             with torch.inference_mode(), self.cap._lock:
                 caps = self.caption_finish(handle)
-            ids_out = []
-            for el, cl in zip(elems_all, caps):
-                q = list(cl)
-                for e in el:
-                    if e["content"] is None and q:
-                        e["content"] = q.pop(0)[0]
-                ids_out.append([r for _, r in cl])
+            ids_out = self._fill_captions(elems_all, caps)
             self.stats = {"crops": [len(c) for c in crops_all], "boxes": nbox}
             self.last_crops = crops_all
             return (elems_all, ids_out) if return_ids else elems_all
@@ -407,6 +442,61 @@ class ScreenParser:
                 pending = (handle, elems_all, crops_all, nbox)
             yield finish(pending)
 
+    def _parse_stream_device(self, batches, return_ids, pad_to):
+        """parse_stream with the device hand-off (the default): four HIP streams, one host thread.  Batch i+1's detector + hand-off
+        graph runs on the detector's stream while batch i encodes; its tables are snapshotted (`detect_glue`) so nothing of batch i
+        reads the detector plan's buffers afterwards; caption micro-batches alternate between two encode streams (the HBM-bound
+        kernels of one fill what the MFMA-bound GEMMs of the other leave idle); batch i's 20 decode steps run on a fourth stream, on
+        one of two decode plans, while batch i+1 encodes.  Same kernels on the same data per batch as `parse_batch`."""
+        def finish(p):
+            handle, snap, ocr_els, counts, iw, ih, n_frames, n_crops = p
+            with torch.inference_mode(), self.cap._lock:
+                caps = self.caption_finish(handle)
+                elems_all = self.assemble(snap, snap, ocr_els, counts, iw, ih, n_frames)
+            ids_out = self._fill_captions(elems_all, caps)
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
+            self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
+            return (elems_all, ids_out) if return_ids else elems_all
+
+        try:
+            yield from self._stream_loop(batches, return_ids, pad_to, finish)
+        finally:
+            torch.cuda.synchronize(self.cap.device)      # an abandoned generator leaves no work behind on the side streams
+
+    def _stream_loop(self, batches, return_ids, pad_to, finish):
+        pending = None
+        for frames, ocr in batches:
+            ih, iw = frames[0].shape[:2]
+            tiled = self.tile_large and (iw > 1952 or ih > 1112)
+            with self.det._lock:
+                handed = None if tiled else self.detect_glue(frames, ocr, pad_to, snapshot=True)
+            if handed is None:                       # beyond the hand-off kernel's capacities / tiled: drain, then the ordinary path
+                if pending is not None:
+                    yield finish(pending)
+                    pending = None
+                yield self.parse_batch(frames, ocr, return_ids=return_ids, pad_to=pad_to)
+                continue
+            snap, _, ocr_els, counts = handed
+            n_crops = [int(counts[f, 1]) for f in range(len(frames))]
+            with torch.inference_mode(), self.cap._lock:
+                handle = self.caption_launch(frames, n_crops, crops_dev=snap.crops, overlap=True)
+            if pending is not None:
+                yield finish(pending)
+            pending = (handle, snap, ocr_els, counts, iw, ih, len(frames), n_crops)
+        if pending is not None:
+            yield finish(pending)
+
+    @staticmethod
+    def _fill_captions(elems_all, caps):
+        ids_out = []
+        for el, cl in zip(elems_all, caps):
+            q = list(cl)
+            for e in el:
+                if e["content"] is None and q:
+                    e["content"] = q.pop(0)[0]
+            ids_out.append([r for _, r in cl])
+        return ids_out
+
     def _parse_batch_locked(self, frames, ocr, return_ids, iw, ih, pad_to=None):
         tiled = self.tile_large and (iw > 1952 or ih > 1112)
         handed = self.detect_glue(frames, ocr, pad_to) if (self.device_glue and not tiled) else None
@@ -416,13 +506,7 @@ class ScreenParser:
             # crop rectangles were produced on the detector's stream, which the counts read-back above has drained: no event needed
             caps = self.caption(frames, n_crops, crops_dev=gs.crops)
             elems_all = self.assemble(dp, gs, ocr_els, counts, iw, ih, len(frames))
-            ids_out = []
-            for el, cl in zip(elems_all, caps):
-                q = list(cl)
-                for e in el:
-                    if e["content"] is None and q:
-                        e["content"] = q.pop(0)[0]
-                ids_out.append([r for _, r in cl])
+            ids_out = self._fill_captions(elems_all, caps)
             self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()]}
             self.last_crops = [gs.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
@@ -436,13 +520,7 @@ class ScreenParser:
             el, cr = self.glue(xy, iw, ih, boxes, texts)
             elems_all.append(el); crops_all.append(cr)
         caps = self.caption(frames, crops_all)
-        ids_out = []
-        for el, cl in zip(elems_all, caps):
-            q = list(cl)
-            for e in el:
-                if e["content"] is None and q:
-                    e["content"] = q.pop(0)[0]
-            ids_out.append([r for _, r in cl])
+        ids_out = self._fill_captions(elems_all, caps)
         self.stats = {"crops": [len(c) for c in crops_all], "boxes": [len(b) for b in det_boxes]}
         self.last_crops = crops_all            # integer crop boxes per frame, in caption order (parity tests read them)
         return (elems_all, ids_out) if return_ids else elems_all

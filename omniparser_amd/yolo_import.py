@@ -264,9 +264,14 @@ def verify_against_blob(blob, run_network, nc: int, size: int = 64, tol: float =
     g = torch.Generator().manual_seed(1234)
     coarse = torch.rand(1, 3, size // 8, size // 8, generator=g)                 # blocky, GUI-like probe (flat 8x8 patches)
     x = coarse.repeat_interleave(8, 2).repeat_interleave(8, 3).contiguous()
-    with torch.inference_mode():
-        ref = blob(x)
-    ref = list(ref)
+    try:
+        # the reference always runs the blob with the TorchScript optimiser off (ref:util/yolov9.py:120-121)
+        with torch.inference_mode(), torch.jit.optimized_execution(False):
+            ref = list(blob(x))
+    except BlobImportError:
+        raise
+    except Exception as e:      # noqa: BLE001 — a blob that cannot run a 64x64 probe is an import failure, not a constructor crash
+        raise BlobImportError(f"the blob failed on the {size}x{size} probe input: {type(e).__name__}: {e}") from e
     if len(ref) < 6:
         raise BlobImportError(f"the blob returned {len(ref)} tensors; ref:util/yolov9.py:92-96 consumes 6 ([cls, dist] per stride)")
     got = run_network(x)

@@ -15,7 +15,7 @@ def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
     import gpu_checks as G
     from tools.make_weights import EXACT_FRAMES
     out, det = G.check_detector(width=0.25, image_seeds=EXACT_FRAMES[(0.25, 320)][:1], imgsz=320, iw=640, ih=480)
-    assert det.import_error is not None and det.import_error < 1e-3           # load-time proof of the imported blob ran on the kernels
+    assert det.import_rel_err is not None and det.import_rel_err < 1e-3           # load-time proof of the imported blob ran on the kernels
     G.assert_detector_frame(out["images"][0], exact=True)
     assert out["ops"] > 250
 
@@ -137,6 +137,64 @@ def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):
         assert [[r.tolist() for r in f] for f in ids_g] == [[r.tolist() for r in f] for f in ids_w]
     assert sum(len(c) for b in crops_want for c in b) >= 12
     assert len({tuple(r.tolist()) for _, ids in want for f in ids for r in f}) >= 10        # the fingerprints tell crops apart
+
+
+def test_parse_stream_device_handoff_equals_parse_batch(emu, monkeypatch):
+    """parse_stream with the device hand-off (the default): detector tables snapshotted per batch, merged decode on the second
+    stream over two alternating decode plans — batch by batch what parse_batch returns.  Real detector, hand-off and crop kernels
+    on the emulation; encode / decode replaced by a fingerprint of each crop's pixel tensor carried through the decode plan's rows
+    (so a wrong slot, a stale snapshot or an overwritten crop table would show)."""
+    from types import SimpleNamespace
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob, ensure_caption_checkpoint
+    monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
+    monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
+    det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
+    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    slots_used = []
+
+    def fake_plans(B, R, max_new, slot=0):
+        key = ("fake", slot)
+        if key not in cap._plans:
+            cap._plans[key] = SimpleNamespace(fp=torch.zeros(256, 3, dtype=torch.int32), free_evt=None, reset=lambda: None, slot=slot)
+        slots_used.append(slot)
+        return cap._plans[key]
+
+    def enc_into(cp, n, dec, row0, stream=None):
+        x = cp.x_in.t[:n, :, :, :3].double()
+        key = (x.sum((1, 2, 3)) * 977.0 + x[:, ::7, ::5].sum((1, 2, 3)) * 131.0).abs()
+        dec.fp[row0:row0 + n] = torch.stack([torch.zeros(n), 100 + (key.long() % 40000), torch.full((n,), 2.0)], 1).int()
+
+    def dec_merged(dec, n, max_new, stream=None):
+        out = dec.fp[:n].clone()
+        dec.fp.fill_(7)                      # whoever reads this plan after its decode sees garbage
+        return out
+    monkeypatch.setattr(cap, "decode_plans", fake_plans)
+    monkeypatch.setattr(cap, "_encode_into", enc_into)
+    monkeypatch.setattr(cap, "_decode_merged", dec_merged)
+    sp = ScreenParser(det, cap, box_threshold=0.5, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=4)
+    assert sp.device_glue
+    batches = [([torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in seeds], [synthetic_ocr(s, 640, 480, 10) for s in seeds])
+               for seeds in ((0, 1), (2,), (3, 0), (1, 2))]
+    want, crops_want = [], []
+    for f, o in batches:
+        want.append(sp.parse_batch(f, o, return_ids=True, pad_to=2))
+        crops_want.append(sp.last_crops)
+    assert set(slots_used) == {0}
+    del slots_used[:]
+    got, crops_got = [], []
+    for res in sp.parse_stream(iter(batches), return_ids=True, pad_to=2):
+        got.append(res)
+        crops_got.append(sp.last_crops)
+    assert len(got) == 4 and crops_got == crops_want
+    assert len(slots_used) >= 3 and all(a != b for a, b in zip(slots_used, slots_used[1:])), slots_used   # merged batches alternate plans
+    for (el_w, ids_w), (el_g, ids_g) in zip(want, got):
+        assert el_g == el_w
+        assert [[r.tolist() for r in f] for f in ids_g] == [[r.tolist() for r in f] for f in ids_w]
+    assert len({tuple(r.tolist()) for _, ids in want for f in ids for r in f}) >= 10
 
 
 def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
