@@ -218,8 +218,7 @@ def main():
             "conf": CONF, "nms_iou": NMS_IOU, "overlap_iou": OVERLAP_IOU, "max_det": MAX_DET,
             "parallelism": f"replicas x{world}, round-robin shards of steps, 1 all_gather/job",
             "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
-            "gemm_tile_order": ("xcd row blocks + N partition (L2-resident weight slabs)"
-                                if os.environ.get("OMNI_XCD_NSPLIT", "1") != "0" else "xcd row blocks (round-1 order)"),
+            "gemm_tile_order": "xcd row blocks + N partition (L2-resident weight slabs)",
             "gemm_path": ("split-f16 x3 MFMA (f32-class accuracy): pre-split LDS-DMA GEMM for the captioner's linear layers, "
                           "register-staged split kernel for convs / decoder steps" if args.precision == "f32" and
                           os.environ.get("OMNI_CONV_SPLIT", "1") == "1" else

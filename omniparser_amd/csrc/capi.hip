@@ -115,12 +115,6 @@ extern "C" int omni_plan_capture(omni_plan_t* plan, void* stream) {
   if (rc) { if (g) hipGraphDestroy(g); return rc; }
   if (e != hipSuccess) { omni_set_error("hipStreamEndCapture: %s", hipGetErrorString(e)); return OMNI_E_HIP; }
   plan->graph = g;
-  if (const char* dot = getenv("OMNI_GRAPH_DOT")) {     // debugging aid: dump the captured graph (node kinds, edges) as graphviz
-    static int serial = 0;
-    char path[512];
-    snprintf(path, sizeof(path), "%s.%d.dot", dot, serial++);
-    hipGraphDebugDotPrint(plan->graph, path, 0);
-  }
   OMNI_HIP_CHECK(hipGraphInstantiate(&plan->exec, plan->graph, nullptr, nullptr, 0));
   return OMNI_OK;
 }

@@ -18,6 +18,7 @@
 // All softmax / LayerNorm statistics are f32; f16 tensors are converted on load.
 #include "omni_internal.h"
 #include <stdlib.h>
+#include <string.h>
 
 #pragma clang fp contract(off)
 
@@ -1021,6 +1022,174 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
   }
 }
 
+
+// [A/B, temporary] the window-attention kernel as of profiles/r3_s3_caption_per_op.txt (scattered 4-byte output stores, 64-bit row
+// addressing): OMNI_AB=win_s3 selects it.
+__global__ __launch_bounds__(192) void window_attn_mfma_f32_s3_kernel(AttnArgs a) {
+  constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
+  unsigned char* Kh = lds;
+  unsigned char* Kl = lds + NKP * KROW;
+  unsigned char* Vh = lds + 2 * NKP * KROW;
+  unsigned char* Vl = Vh + D * VROW;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const float* Qp = (const float*)a.q; const float* Kp = (const float*)a.k; const float* Vp = (const float*)a.v;
+  // window origin (uniform): token row of window-local index i = base + (i / 12) * W + i % 12 unless it falls outside the image
+  const int wpi = a.wy * a.wx;
+  const int b = g / wpi, wrem = g - b * wpi;
+  const int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
+  const int r0 = wyi * 12, c0 = wxi * 12;
+  auto row_of = [&](int i) -> long long {
+    const int r = r0 + i / 12, c = c0 + i % 12;
+    return (r >= a.H || c >= a.W) ? -1ll : ((long long)b * a.H + r) * a.W + c;
+  };
+  const int qc = lane & 15, grp = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- 1. all global loads of the block
+  f32x4 qraw[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const long long qrow = row_of((wave + 3 * t) * 16 + qc);
+    const float* qp = Qp + (qrow >= 0 ? qrow : 0) * a.ldq + a.qoff + h * D + grp * 8;
+    qraw[t][0] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp) : z4;
+    qraw[t][1] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp + 4) : z4;
+  }
+  f32x4 kraw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {                       // item e = (key, 4-channel group): 144 * 8 = 6 * 192
+    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
+    const long long row = row_of(key);
+    if (row >= 0) kraw[j] = *reinterpret_cast<const f32x4*>(Kp + row * a.ldk + a.koff + h * D + d0);
+    else kraw[j] = a.kbias ? f32x4{a.kbias[h * D + d0], a.kbias[h * D + d0 + 1], a.kbias[h * D + d0 + 2], a.kbias[h * D + d0 + 3]} : z4;
+  }
+  f32x4 vraw[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {                       // item e = (key quad, 4-channel group): 36 * 8 = 288 = 192 + 96
+    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
+    if (e < 288) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const long long row = row_of(kq * 4 + u);
+        if (row >= 0) vraw[j][u] = *reinterpret_cast<const f32x4*>(Vp + row * a.ldv + a.voff + h * D + d0);
+        else vraw[j][u] = a.vbias ? f32x4{a.vbias[h * D + d0], a.vbias[h * D + d0 + 1], a.vbias[h * D + d0 + 2], a.vbias[h * D + d0 + 3]} : z4;
+      }
+    }
+  }
+  // ---- 2. LDS image: K rows (hi | lo), V^T rows (hi | lo), keys 144..159 zero
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
+    uint2 kh, kl;
+    split4v(kraw[j], kh, kl);
+    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = kh;
+    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = kl;
+  }
+  if (tid < 128) {                                    // padding keys 144..159: 16 keys x 8 channel groups
+    const int key = 144 + (tid >> 3), d0 = (tid & 7) * 4;
+    const uint2 zh = {0u, 0u};
+    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = zh;
+    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = zh;
+  } else {                                            // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
+    const int r = tid - 128;                          // 0..63: (hi | lo, d)
+    unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(p) = z;
+    *reinterpret_cast<u32x4*>(p + 16) = z;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
+    if (e < 288) {
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
+        uint2 vh, vl;
+        split4v(f32x4{vraw[j][0][dd], vraw[j][1][dd], vraw[j][2][dd], vraw[j][3][dd]}, vh, vl);
+        *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + kq * 8) = vh;
+        *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + kq * 8) = vl;
+      }
+    }
+  }
+  __syncthreads();
+
+  const float inv2048 = 1.0f / 2048.0f;
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const int qt = wave + 3 * t;
+    u32x4 qhu, qlu;                                   // Q fragment (8 halves each), pre-multiplied by the softmax scale
+    {
+      const f32x4 q0 = qraw[t][0] * a.scale, q1 = qraw[t][1] * a.scale;
+      uint2 h0, l0, h1, l1;
+      split4v(q0, h0, l0);
+      split4v(q1, h1, l1);
+      qhu = u32x4{h0.x, h0.y, h1.x, h1.y};
+      qlu = u32x4{l0.x, l0.y, l1.x, l1.y};
+    }
+    const h16x8 qh = __builtin_bit_cast(h16x8, qhu), ql = __builtin_bit_cast(h16x8, qlu);
+    float sc[40];
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 10; ++kt) {
+      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
+      h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+      h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
+      f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
+      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
+#pragma unroll
+      for (int r = 0; r < 4; ++r) {
+        const int key = kt * 16 + grp * 4 + r;
+        float sv = __builtin_fmaf(accC[r], inv2048, accM[r]);
+        sv = key < 144 ? sv : -INFINITY;
+        sc[kt * 4 + r] = sv;
+        mx = fmaxf(mx, sv);
+      }
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    float sum = 0.0f;
+#pragma unroll
+    for (int e = 0; e < 40; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);
+    f32x4 oM[2], oC[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      uint2 h0, l0, h1, l1;
+      split4v(f32x4{sc[8 * j + 0], sc[8 * j + 1], sc[8 * j + 2], sc[8 * j + 3]}, h0, l0);
+      split4v(f32x4{sc[8 * j + 4], sc[8 * j + 5], sc[8 * j + 6], sc[8 * j + 7]}, h1, l1);
+      const h16x8 ph = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+      const h16x8 pl = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 32);
+        const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 32);
+        const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+        const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
+        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
+      }
+    }
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ql_ = grp * 4 + r;
+      const float rs = __shfl(sum, ql_);
+      const long long orow = row_of(qt * 16 + ql_);
+      if (orow >= 0) {
+        const float inv = 1.0f / rs;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt)
+          store_out<float>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, __builtin_fmaf(oC[dt][r], inv2048, oM[dt][r]) * inv, a.osplit);
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ plain MHA on MFMA (BART encoder)
 // softmax(q k^T * scale) v for head_dim 64 and any key count (hf:models/bart/modeling_bart.py:143-257), flash-style:
 // keys are walked in blocks of 32 with an online softmax; both contractions use split-f16 MFMA exactly as in
@@ -1354,6 +1523,7 @@ __global__ __launch_bounds__(256) void chan_softmax_kernel(ChanArgs a) {
   for (int e = 0; e < 4; ++e) p0[i * 32 + j0 + e] = sa[i][j0 + e];     // A over the chunk-0 partial of this (image, group)
 }
 
+// [A/B, temporary] VALU apply, one token per lane (OMNI_AB=chan_valu)
 __global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
   __shared__ __attribute__((aligned(16))) float sa[32][36];
   const int g = blockIdx.y, b = blockIdx.z;
@@ -1396,9 +1566,8 @@ __global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
   }
 }
 
-// apply on the matrix cores (default for f32 plans; chan_apply_v4_kernel above stays as the OMNI_CHAN_ATTN=2 A/B reference): the VALU
-// kernel reads the 32x32 attention matrix from LDS as broadcast 16-byte reads — 256 KB of LDS traffic per 64 tokens, which bounds it
-// at ~3 TB/s (measured 2.0: 3.3 % of the step).  Here out^T[i][n] = sum_j A[i][j] v[n][j] is v_mfma_f32_32x32x2_f32 (exact f32
+// apply on the matrix cores (f32 plans).  A VALU apply kernel (one token per lane) reads the 32x32 attention matrix from LDS as
+// broadcast 16-byte reads — 256 KB of LDS traffic per 64 tokens, which bounds it at ~3 TB/s (measured 2.0: 3.3 % of the step).  Here out^T[i][n] = sum_j A[i][j] v[n][j] is v_mfma_f32_32x32x2_f32 (exact f32
 // products): A is the row operand, held in 16 registers per lane for the whole block; v goes from global memory straight into the
 // column operand (lane = (token lane & 31, j parity lane >> 5), one dword per lane per step: the 16 loads of a 32-token tile walk the
 // same 32 cache lines); a lane ends up with 4 x 4 consecutive output channels of ONE token -> 16-byte stores / format-B halves.
@@ -1805,9 +1974,8 @@ int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
   a.total = (long long)a.B * a.H * a.W * a.C;
   const int V = op->dtype == OMNI_F32 ? 4 : 8;
   const DwStripGrid g = dwconv3_strip_grid(a, V);
-  const char* e = getenv("OMNI_DWCONV_STRIP");
   int rc;
-  if (g.ok && !(e && atoi(e) == 0)) {
+  if (g.ok) {
     rc = by_dtype(op->dtype, "dwconv3",
         [&] { hipLaunchKernelGGL(dwconv3_strip_kernel<float>, dim3(g.gx, g.gy, g.gz), dim3(256), 0, s, a, g.cv_log2); },
         [&] { hipLaunchKernelGGL(dwconv3_strip_kernel<half_t>, dim3(g.gx, g.gy, g.gz), dim3(256), 0, s, a, g.cv_log2); });
@@ -1832,8 +2000,7 @@ int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(!a.osplit || (op->dtype == OMNI_F32 && a.C % 16 == 0), "dwconv3_ln: split output needs an f32 plan and C %% 16 == 0");
   OMNI_REQUIRE(a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0 && a.C <= 1024 && a.C % V == 0, "dwconv3_ln: bad shape (C <= 1024, C %% %d == 0)", V);
   a.pixels = (long long)a.B * a.H * a.W;
-  static const bool use_strip = !(getenv("OMNI_DWLN_STRIP") && atoi(getenv("OMNI_DWLN_STRIP")) == 0);
-  if (op->dtype == OMNI_F32 && use_strip && (a.C == 128 || a.C == 256 || a.C == 512) && (long long)a.B * a.H * a.W < (1ll << 31)) {
+  if (op->dtype == OMNI_F32 && (a.C == 128 || a.C == 256 || a.C == 512) && (long long)a.B * a.H * a.W < (1ll << 31)) {
     if (a.C == 128) launch_dwln_strip<1, 32>(a, s);
     else if (a.C == 256) launch_dwln_strip<1, 64>(a, s);
     else launch_dwln_strip<2, 64>(a, s);
@@ -1891,23 +2058,16 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
     OMNI_REQUIRE(a.groups % (a.wy * a.wx) == 0, "attn_rows: groups must be B * windows");
   } else { a.wy = a.wx = 0; }
   int rc;
-  static const bool use_mfma = !(getenv("OMNI_ATTN_MFMA") && atoi(getenv("OMNI_ATTN_MFMA")) == 0);
-  OMNI_REQUIRE(!a.osplit || (use_mfma && ((a.mode == 1 && D == 32) || (a.mode == 0 && D == 64))), "attn_rows: split output exists on the MFMA kernels only");
-  if (a.mode == 1 && D == 32 && use_mfma) {       // 12x12 window attention on the matrix cores (split-f16)
+  OMNI_REQUIRE(!a.osplit || (a.mode == 1 && D == 32) || (a.mode == 0 && D == 64), "attn_rows: split output exists on the MFMA kernels only");
+  if (a.mode == 1 && D == 32) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
-    const char* wv = getenv("OMNI_WINDOW_ATTN");     // 1 = the round-2 kernel (A/B knob, read per launch; captured graphs keep theirs)
-    const bool v2 = !(wv && atoi(wv) == 1);
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { if (v2 && a.H % 12 == 0 && a.W % 12 == 0) hipLaunchKernelGGL(window_attn_mfma_f32_kernel<false>, grid, dim3(192), 0, s, a);
-            else if (v2) hipLaunchKernelGGL(window_attn_mfma_f32_kernel<true>, grid, dim3(192), 0, s, a);
-            else hipLaunchKernelGGL((window_attn_mfma_kernel<float>), grid, dim3(192), 0, s, a); },
+      [&] { const char* ab = getenv("OMNI_AB");     // [A/B, temporary]
+            if (ab && strstr(ab, "win_s3")) hipLaunchKernelGGL(window_attn_mfma_f32_s3_kernel, grid, dim3(192), 0, s, a);
+            else if (a.H % 12 == 0 && a.W % 12 == 0) hipLaunchKernelGGL(window_attn_mfma_f32_kernel<false>, grid, dim3(192), 0, s, a);
+            else hipLaunchKernelGGL(window_attn_mfma_f32_kernel<true>, grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
-  } else if (a.mode == 1 && D == 32) {    // VALU fallback path (OMNI_ATTN_MFMA=0): 144 queries in one 192-thread workgroup
-    dim3 grid(1, a.heads, a.groups);
-    rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<float, 32, 192>), grid, dim3(192), 0, s, a); },
-      [&] { hipLaunchKernelGGL((attn_rows_kernel<half_t, 32, 192>), grid, dim3(192), 0, s, a); });
-  } else if (a.mode == 0 && D == 64 && use_mfma) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
+  } else if (a.mode == 0 && D == 64) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
     rc = by_dtype(op->dtype, "attn_rows",
       [&] { hipLaunchKernelGGL((mha_mfma_kernel<float>), grid, dim3(256), 0, s, a); },
@@ -1936,12 +2096,12 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   a.scale = 1.0f / sqrtf((float)a.N);
   if (op->f[0] != 0.0f) a.scale = op->f[0];
   dim3 g1(a.chunks, a.G, a.B), g2((a.N + 255) / 256, a.G, a.B);
-  const char* cv = getenv("OMNI_CHAN_ATTN");               // 1 = the round-2 kernel pair (A/B knob, read per launch)
-  if (op->dtype == OMNI_F32 && !(cv && atoi(cv) == 1) && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
+  if (op->dtype == OMNI_F32 && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
     hipLaunchKernelGGL(chan_scores_mfma_kernel, g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(chan_softmax_kernel, dim3(a.G, a.B), dim3(256), 0, s, a);
-    if (cv && atoi(cv) == 2) hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);       // VALU apply (A/B)
-    else hipLaunchKernelGGL(chan_apply_mfma_kernel, g2, dim3(256), 0, s, a);
+    { const char* ab = getenv("OMNI_AB");            // [A/B, temporary]
+      if (ab && strstr(ab, "chan_valu")) hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
+      else hipLaunchKernelGGL(chan_apply_mfma_kernel, g2, dim3(256), 0, s, a); }
     OMNI_HIP_CHECK(hipGetLastError());
     return OMNI_OK;
   }
@@ -1966,9 +2126,7 @@ static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.q && a.kc && a.vc && a.o && B > 0 && a.heads > 0 && a.C == a.heads * 64, "attn_decode: bad arguments (head_dim 64)");
   OMNI_REQUIRE(a.nk_fixed > 0 || (a.knew && a.vnew && a.step), "attn_decode: self-attention needs new k/v and the step counter");
   int nk_max = a.nk_fixed > 0 ? a.nk_fixed : a.cap;
-  const char* dv = getenv("OMNI_DECODE_ATTN");             // 1 = the round-2 kernel for cross-attention too (A/B knob, read per launch)
-  const int variant = dv ? atoi(dv) : 0;
-  if (variant != 1 && a.nk_fixed > 0 && op->dtype == OMNI_F32 && a.ldc % 4 == 0 && a.ldq % 4 == 0 && a.qoff % 4 == 0) {
+  if (a.nk_fixed > 0 && op->dtype == OMNI_F32 && a.ldc % 4 == 0 && a.ldq % 4 == 0 && a.qoff % 4 == 0) {
     // cross-attention over the fixed encoder keys: four waves per (row, head), four keys per load instruction
     const size_t lds = (size_t)(((a.nk_fixed + 3) & ~3) + 8 + 256) * 4;
     hipLaunchKernelGGL(attn_decode_cross_kernel, dim3(a.heads, B), dim3(256), lds, s, a);

@@ -580,10 +580,6 @@ void launch_split(ConvArgs& a, hipStream_t s) {
   }
   a.kt_per_split = (a.ktiles + a.splits - 1) / a.splits;
   a.splits = (a.ktiles + a.kt_per_split - 1) / a.kt_per_split;
-  if (const char* e = getenv("OMNI_SPLIT_TILE")) {        // tuning knob
-    if (bm == 128 && !strcmp(e, "128x64")) bn = 64;
-    if (bm == 128 && !strcmp(e, "128x128") && a.Cout > 64) bn = 128;
-  }
   if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
   else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);
   else launch_split_cfg<64, 64>(a, s);
@@ -630,9 +626,7 @@ ConvCfg choose_cfg(const ConvArgs& a) {
   if (blocks(c.bm, c.bn) < 1024) c.bm = 64;
   // 128-row tiles: 64-byte K slices keep LDS at 40 KB -> 3 workgroups per CU (measured +8..25 % over 128-byte
   // slices at 2 per CU); 64x64 tiles keep 128-byte slices (fewer barriers, LDS is not the limiter there)
-  int rb_env = 0;
-  if (const char* e = getenv("OMNI_CONV_RB")) rb_env = atoi(e);
-  if ((c.bm == 128 && rb_env != 128) || rb_env == 64) {
+  if (c.bm == 128) {
     if (c.rb == 128) {
       c.rb = 64;
       bke = (c.rb / 16) * V;

@@ -39,12 +39,8 @@ __host__ inline unsigned tile_grid(int mtiles, int ntiles, int xcd_order, int xc
 // N-partition choice: smallest xcd_n in {2, 4, 8} dividing ntiles whose per-XCD weight slab fits the L2 budget;
 // 1 (row-block mapping) when the whole matrix already fits or no divisor achieves residency.
 __host__ inline int choose_xcd_n(int ntiles, long long weight_bytes) {
-  // read per launch (like the other tuning knobs) so one process can A/B the orders; captured graphs keep theirs
-  const char* e = getenv("OMNI_XCD_NSPLIT");
-  const bool enabled = !(e && atoi(e) == 0);
-  long long budget = 2ll << 20;                  // half of the 4 MiB L2 (tools/l2_sim.py; OMNI_XCD_L2_BUDGET_KB overrides)
-  if (const char* b = getenv("OMNI_XCD_L2_BUDGET_KB")) { long long kb = atoll(b); if (kb > 0) budget = kb << 10; }
-  if (!enabled || weight_bytes <= budget) return 1;
+  const long long budget = 2ll << 20;            // half of the 4 MiB L2 (tools/l2_sim.py)
+  if (weight_bytes <= budget) return 1;
   for (int xn = 2; xn <= 8; xn *= 2)
     if (ntiles % xn == 0 && weight_bytes / xn <= budget) return xn;
   return 1;

@@ -132,11 +132,13 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 // K-loop schedule: the DMA pieces of the slice NSTAGE-1 ahead are spread over the units, ds_reads / DMA pieces interleaved one per
 // MFMA (sched_group_barrier).  The alternative schedule (all DMA pieces right after the barrier: 1-6 % slower) and the ablation
 // variants that led here are recorded in profiles/r2_gemm_diag.md; they are not compiled into the library.
-// SCHED 1 (default for the 256x256 tile since round 3; OMNI_GEMM_SCHED=0 = pieces spread over all units, tools/gemm_bench.py A/B): the
-// DMA pieces of the next slice are issued in the FIRST half of the units, so that the last piece has at least half a slice to land
-// before the wait at the top of the next slice: +2-5 % on the K >= 512 shapes (profiles/r3_s3_gemm_bench.txt).
+// SCHED 1 (the 256x256 tile; SCHED 0 = pieces spread over all units, the smaller tiles): the DMA pieces of the next slice are issued
+// in the FIRST half of the units, so that the last piece has at least half a slice to land before the wait at the top of the next
+// slice: +2-5 % on the K >= 512 shapes (profiles/r3_s3_gemm_bench.txt).  Measured and NOT kept (within +-5 % of this kernel, removed
+// from the library after commit f6047af; profiles/r3_s7_gemm_bench_sched2_w4.txt, r3_s8_gemm_bench_k16.txt): the barrier in front of
+// the last unit of a slice, a 4-wave 256x256 tile, a 4-wave 256x128 tile with 16-wide K slices and two blocks per CU.
 template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0>
-__global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4) ? 1 : 2) void gemm_dma_kernel(GemmArgs a) {
+__global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
   constexpr int TM = BM / (32 * WM), TN = BN / (32 * WN);     // 32x32 MFMA tiles per wave (tokens x channels)
@@ -247,65 +249,6 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
   };
 
   const int nk = a.nk;
-  if constexpr (SCHED == 2) {
-    // ---- SCHED 2: the per-slice barrier sits in FRONT OF THE LAST UNIT of a slice, not between slices.  At that point every fragment
-    // of slice kt is in registers, so one rendezvous says both "slice kt + 1 has landed for everybody" and "nobody reads stage kt any
-    // more": the last unit's 12 MFMAs then cover the ds_reads of slice kt + 1's first fragments and the DMA issue of slice kt + 2 into
-    // the stage just released.  With the barrier BETWEEN slices (SCHED 0 / 1) all 8 waves leave it with empty fragment registers and
-    // queue 64 ds_read_b128 on the LDS at once (~500 cycles until the last wave can start its MFMAs, of ~3 000 per slice).
-    static_assert(SCHED != 2 || NSTAGE == 2, "SCHED 2 is written for the two-stage ring");
-    issue(0, 0);
-    if (nk > 1) { issue(1, 1); OMNI_WAIT_VMCNT(DPS); } else { OMNI_WAIT_VMCNT(0); }
-    __builtin_amdgcn_s_barrier();
-    AF af[2];
-    WF wf[2];
-    loadW(lds, 0, wf[0]);
-    loadA(lds, 0, 0, af[0]);
-    int stage = 0;
-    // NEXT: slice kt + 1 exists (barrier + prefetch of its first fragments); MORE: slice kt + 2 exists (its DMA is issued)
-    constexpr int LASTDS = 2 * TN + 4;                                     // ds_reads of the first fragments of a slice
-    constexpr int LASTPP = (DPS + (NM - LASTDS) - 1) / (NM - LASTDS);      // DMA pieces per remaining MFMA slot of the last unit
-    auto slice2 = [&](int kt, auto next_tag, auto more_tag) {
-      constexpr bool NEXT = decltype(next_tag)::value, MORE = decltype(more_tag)::value;
-      const unsigned char* st = lds + stage * STAGE;
-      const unsigned char* sn = lds + (stage ^ 1) * STAGE;
-#pragma unroll
-      for (int u = 0; u < NU; ++u) {
-        const int g = u / NP, ip = u % NP;
-        int nds = 0, npc = 0;
-        if (u + 1 < NU) {
-          const int g2 = (u + 1) / NP, ip2 = (u + 1) % NP;
-          if (g2 != g) { loadW(st, g2, wf[g2 & 1]); nds += 2 * TN; }
-          loadA(st, g2, ip2, af[(u + 1) & 1]);
-          nds += 4;
-        } else if constexpr (NEXT) {
-          OMNI_WAIT_LGKM0();                       // my reads of stage kt have returned ...
-          OMNI_WAIT_VMCNT(0);                      // ... and my pieces of slice kt + 1 have landed
-          __builtin_amdgcn_s_barrier();
-          __builtin_amdgcn_sched_barrier(0);
-          loadW(sn, 0, wf[0]);
-          loadA(sn, 0, 0, af[0]);
-          nds = 2 * TN + 4;
-          if constexpr (MORE) { issue(kt + 2, stage); npc = DPS; }
-        }
-        mma(af[u & 1], wf[g & 1], ip);
-#pragma unroll
-        for (int k = 0; k < NM; ++k) {
-          __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-          // program order is ds_reads, then DMA pieces (the compiler cannot tell the stages apart, so LDS reads and LDS-DMA writes
-          // keep their order): one ds_read behind each of the first MFMAs, then the DMA pieces spread over the remaining ones
-          if (k < nds) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-          else if (npc) __builtin_amdgcn_sched_group_barrier(0x20, LASTPP, 0);
-        }
-        __builtin_amdgcn_sched_barrier(0);
-      }
-      stage ^= 1;
-    };
-    int kt = 0;
-    for (; kt + 2 < nk; ++kt) slice2(kt, std::true_type{}, std::true_type{});
-    for (; kt + 1 < nk; ++kt) slice2(kt, std::true_type{}, std::false_type{});
-    for (; kt < nk; ++kt) slice2(kt, std::false_type{}, std::false_type{});
-  } else {
 #pragma unroll
   for (int s = 0; s < NSTAGE - 1; ++s)
     if (s < nk) issue(s, s);
@@ -361,179 +304,8 @@ __global__ __launch_bounds__(WM * WN * 64, (BM * BN == 256 * 256 && WM * WN == 4
   int kt = 0;
   for (; kt + NSTAGE - 1 < nk; ++kt) slice(kt, std::true_type{});
   for (; kt < nk; ++kt) slice(kt, std::false_type{});
-  }
 
   // ---- epilogue (gemm_epilogue above): bias / activation / 2^-k in registers, rows transposed through the idle LDS ring
-  gemm_epilogue<BM, BN, WM, WN, TM, TN, NSTAGE * STAGE, ACT, OSPLIT, RES>(acc, a, lds, m0, n0, wave, lane);
-#endif
-}
-
-// ---- 256 x 128 tile, FOUR waves (128 tokens x 64 channels each, the wave tile of the kernel above), 16-wide K slices, three-stage
-// ring = 72 KB of LDS and <= 256 registers: TWO blocks per CU.  Why: with one 8-wave block per CU every wave of the CU is in the
-// same phase — prologue (first DMA latency), K loop, epilogue (GELU / split / transposition / stores: ~20 % of a K = 512 tile) — and
-// the matrix pipes idle outside the K loop (K = 512 layers ran at 270-300 TF/s where K = 2048 reached 335, profiles/r3_s7_*).  Two
-// independent blocks per CU overlap one block's prologue / epilogue / barrier skew with the other's MFMAs.  LDS rows are 64 bytes (one
-// 16-wide K group: 16 hi | 16 lo halves), a DMA piece is 16 rows, the 16-byte chunk index is XOR-swizzled with (row >> 2) & 3 (same
-// involution on the DMA source address and the fragment read address; a 16-lane ds_read_b128 group then covers all 64 banks once).
-// The barrier sits in front of the LAST unit of a slice (all fragments of slice kt in registers): it says "slice kt + 1 landed for
-// everybody" and "nobody reads slot kt any more"; the last unit's MFMAs cover the fragment reads of slice kt + 1 and the DMA issue of
-// slice kt + 3 into the slot just released.
-template <int ACT, bool OSPLIT, bool RES>
-__global__ __launch_bounds__(256, 2) void gemm_dma_k16_kernel(GemmArgs a) {
-#if defined(__HIP_DEVICE_COMPILE__)
-  constexpr int BM = 256, BN = 128, WM = 2, WN = 2, NW = 4, NSTAGE = 3, TM = 4, TN = 2;
-  constexpr int ROWB = 64, STAGE = (BM + BN) * ROWB;
-  constexpr int A_DMA = BM / (16 * NW), B_DMA = BN / (16 * NW), DPS = A_DMA + B_DMA;
-  constexpr int NM = 6 * TN;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave / WN, wn = wave % WN;
-  int mt, nt;
-  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
-  const int m0 = __builtin_amdgcn_readfirstlane(mt) * BM, n0 = __builtin_amdgcn_readfirstlane(nt) * BN;
-
-  // LDS-DMA: piece p = 16 rows x 64 B; lane l lands at row 16p + l/4, physical chunk l%4, and fetches logical chunk (l%4) ^ ((row >> 2) & 3)
-  const int rsub = lane >> 2, lchunk = (lane & 3) ^ ((lane >> 4) & 3);
-  unsigned voffA[A_DMA], voffB[B_DMA];
-#pragma unroll
-  for (int i = 0; i < A_DMA; ++i) {
-    const int rl = (wave * A_DMA + i) * 16 + rsub;
-    voffA[i] = (unsigned)min(rl, a.M - 1 - m0) * (unsigned)(a.ldi * 4) + (unsigned)(lchunk * 16);
-  }
-#pragma unroll
-  for (int i = 0; i < B_DMA; ++i) {
-    const int rl = (wave * B_DMA + i) * 16 + rsub;
-    voffB[i] = (unsigned)min(rl, a.N - 1 - n0) * (unsigned)(a.K * 4) + (unsigned)(lchunk * 16);
-  }
-  const __amdgpu_buffer_rsrc_t rsrcA =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.x + ((long long)m0 * a.ldi + a.in_coff) * 4), 0, 0x7fffffff, 0x00020000);
-  const __amdgpu_buffer_rsrc_t rsrcB =
-      __builtin_amdgcn_make_buffer_rsrc((void*)(a.w + (long long)n0 * a.K * 4), 0, 0x7fffffff, 0x00020000);
-  auto issue = [&](int kt, int slot) {
-    const int so = kt * ROWB;
-#pragma unroll
-    for (int i = 0; i < A_DMA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(lds + slot * STAGE + (wave * A_DMA + i) * 1024), 16, voffA[i], so, 0, 0);
-#pragma unroll
-    for (int i = 0; i < B_DMA; ++i)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(lds + slot * STAGE + BM * ROWB + (wave * B_DMA + i) * 1024), 16, voffB[i], so, 0, 0);
-  };
-  // fragment reads: lane -> row lane & 31, k half lane >> 5; logical chunk of part p (0 hi, 1 lo) = 2p + half
-  const int swz = (lane >> 2) & 3, hsel = lane >> 5;
-  int offA[2], offW[2];
-#pragma unroll
-  for (int p = 0; p < 2; ++p) {
-    const int c = ((2 * p + hsel) ^ swz) * 16;
-    offA[p] = (wm * (BM / WM) + (lane & 31)) * ROWB + c;
-    offW[p] = BM * ROWB + (wn * (BN / WN) + (lane & 31)) * ROWB + c;
-  }
-  struct AF { f16x8 h[2], l[2]; };
-  struct WF { f16x8 h[TN], l[TN]; };
-  auto loadA = [&](const unsigned char* st, int ip, AF& f) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t) {
-      f.h[t] = *reinterpret_cast<const f16x8*>(st + offA[0] + (ip * 2 + t) * (32 * ROWB));
-      f.l[t] = *reinterpret_cast<const f16x8*>(st + offA[1] + (ip * 2 + t) * (32 * ROWB));
-    }
-  };
-  auto loadW = [&](const unsigned char* st, WF& f) {
-#pragma unroll
-    for (int j = 0; j < TN; ++j) {
-      f.h[j] = *reinterpret_cast<const f16x8*>(st + offW[0] + j * (32 * ROWB));
-      f.l[j] = *reinterpret_cast<const f16x8*>(st + offW[1] + j * (32 * ROWB));
-    }
-  };
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
-  auto mma = [&](const AF& af, const WF& wf, int ip) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.l[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int j = 0; j < TN; ++j)
-        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.l[t], acc[ip * 2 + t][j], 0, 0, 0);
-  };
-
-  const int nk = a.K / 16;                         // >= 2 (K % 32 == 0)
-  issue(0, 0);
-  issue(1, 1);
-  if (nk > 2) { issue(2, 2); OMNI_WAIT_VMCNT(2 * DPS); } else { OMNI_WAIT_VMCNT(DPS); }
-  __builtin_amdgcn_s_barrier();
-  AF af[2];
-  WF wf[2];
-  loadW(lds, wf[0]);
-  loadA(lds, 0, af[0]);
-  int slot = 0;                                    // ring slot of slice kt
-  // one slice.  PAR: which W fragment buffer holds slice kt.  LV: how far the stream reaches — 3: slice kt + 3 exists (issued here),
-  // 2: kt + 2 is the last, 1: kt + 1 is the last, 0: this is the last slice (no barrier, nothing to prefetch)
-  auto slice = [&](int kt, auto par_tag, auto lv_tag) {
-    constexpr int PAR = decltype(par_tag)::value, LV = decltype(lv_tag)::value;
-    const unsigned char* st = lds + slot * STAGE;
-    const int nslot = slot + 1 == NSTAGE ? 0 : slot + 1;
-    const unsigned char* sn = lds + nslot * STAGE;
-    // unit 0: token tiles 0, 1; the A fragments of tiles 2, 3 arrive under its MFMAs
-    loadA(st, 1, af[1]);
-    mma(af[0], wf[PAR], 0);
-#pragma unroll
-    for (int k = 0; k < NM; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-      if (k < 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    // unit 1: token tiles 2, 3
-    if constexpr (LV >= 1) {
-      OMNI_WAIT_LGKM0();                           // my reads of slot kt have returned ...
-      if constexpr (LV >= 2) OMNI_WAIT_VMCNT(DPS); // ... and my pieces of slice kt + 1 have landed (slice kt + 2 may stay in flight)
-      else OMNI_WAIT_VMCNT(0);
-      __builtin_amdgcn_s_barrier();
-      __builtin_amdgcn_sched_barrier(0);
-      loadW(sn, wf[PAR ^ 1]);
-      loadA(sn, 0, af[0]);
-      if constexpr (LV >= 3) issue(kt + 3, slot);
-    }
-    mma(af[1], wf[PAR], 1);
-#pragma unroll
-    for (int k = 0; k < NM; ++k) {
-      __builtin_amdgcn_sched_group_barrier(0x8, 1, 0);
-      if constexpr (LV >= 1) {
-        if (k < 2 * TN + 4) __builtin_amdgcn_sched_group_barrier(0x100, 1, 0);
-        else if (LV >= 3) __builtin_amdgcn_sched_group_barrier(0x20, (DPS + NM - (2 * TN + 4) - 1) / (NM - (2 * TN + 4)), 0);
-      }
-    }
-    __builtin_amdgcn_sched_barrier(0);
-    slot = nslot;
-  };
-  using I0 = std::integral_constant<int, 0>; using I1 = std::integral_constant<int, 1>;
-  using I2 = std::integral_constant<int, 2>; using I3 = std::integral_constant<int, 3>;
-  // nk is even (K % 32 == 0): slices go in pairs, the W fragment buffers alternate inside a pair.  Straight-line tail: after the steady
-  // state 2 or 4 slices are left.
-  int kt = 0;
-  for (; kt + 4 < nk; kt += 2) {
-    slice(kt, I0{}, I3{});
-    slice(kt + 1, I1{}, I3{});
-  }
-  if (nk - kt == 4) {
-    slice(kt, I0{}, I3{});
-    slice(kt + 1, I1{}, I2{});
-    kt += 2;
-  }
-  slice(kt, I0{}, I1{});
-  slice(kt + 1, I1{}, I0{});
   gemm_epilogue<BM, BN, WM, WN, TM, TN, NSTAGE * STAGE, ACT, OSPLIT, RES>(acc, a, lds, m0, n0, wave, lane);
 #endif
 }
@@ -564,25 +336,6 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
   *reinterpret_cast<u32x4*>(dst + 48) = u32x4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
 }
 
-int launch_k16(GemmArgs& a, int act, int osplit, hipStream_t s) {
-  a.mtiles = (a.M + 255) / 256;
-  a.ntiles = a.N / 128;
-  a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
-  a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
-  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(256);
-  const bool res = a.res != nullptr;
-  if (act == OMNI_ACT_NONE && !osplit && !res) hipLaunchKernelGGL((gemm_dma_k16_kernel<OMNI_ACT_NONE, false, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_NONE && !osplit && res) hipLaunchKernelGGL((gemm_dma_k16_kernel<OMNI_ACT_NONE, false, true>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_NONE && osplit && !res) hipLaunchKernelGGL((gemm_dma_k16_kernel<OMNI_ACT_NONE, true, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_GELU && osplit && !res) hipLaunchKernelGGL((gemm_dma_k16_kernel<OMNI_ACT_GELU, true, false>), grid, block, 0, s, a);
-  else if (act == OMNI_ACT_GELU && !osplit && !res) hipLaunchKernelGGL((gemm_dma_k16_kernel<OMNI_ACT_GELU, false, false>), grid, block, 0, s, a);
-  else {
-    omni_set_error("gemm_dma: unsupported epilogue (act %d, split out %d, residual %d)", act, osplit, (int)res);
-    return OMNI_E_ARG;
-  }
-  return OMNI_OK;
-}
-
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
@@ -591,19 +344,8 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  int sched = NSTAGE == 2 ? 1 : 0;
-  if constexpr (NSTAGE == 2) { if (const char* e = getenv("OMNI_GEMM_SCHED")) sched = atoi(e) == 0 ? 0 : (atoi(e) == 2 ? 2 : 1); }
-  if (sched == 1 && !(BM == 256 && BN == 256)) sched = 0;
-#define OMNI_GD(ACT_, OS_, RES_)                                                                                         \
-  do {                                                                                                                   \
-    if constexpr (NSTAGE == 2) {                                                                                         \
-      if (sched == 2) { hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 2>), grid, block, 0, s, a); break; } \
-    }                                                                                                                    \
-    if constexpr (BM == 256 && BN == 256) {                                                                              \
-      if (sched == 1) { hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 1>), grid, block, 0, s, a); break; } \
-    }                                                                                                                    \
-    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 0>), grid, block, 0, s, a);            \
-  } while (0)
+  constexpr int SCHED = (BM == 256 && BN == 256) ? 1 : 0;      // front-loaded DMA issue on the 256x256 tile (see gemm_dma_kernel)
+#define OMNI_GD(ACT_, OS_, RES_) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED>), grid, block, 0, s, a)
   if (act == OMNI_ACT_NONE && !osplit && !res) OMNI_GD(OMNI_ACT_NONE, false, false);
   else if (act == OMNI_ACT_NONE && !osplit && res) OMNI_GD(OMNI_ACT_NONE, false, true);
   else if (act == OMNI_ACT_NONE && osplit && !res) OMNI_GD(OMNI_ACT_NONE, true, false);
@@ -658,13 +400,9 @@ int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s) {
     if (!strcmp(e, "256x128")) tile = 1;
     else if (!strcmp(e, "128x128")) tile = 2;
     else if (!strcmp(e, "256x256") && a.N % 256 == 0) tile = 0;
-    else if (!strcmp(e, "256x256w4") && a.N % 256 == 0) tile = 3;      // 4 waves, 128x128 per wave, one wave per SIMD
-    else if (!strcmp(e, "256x128k16")) tile = 4;                       // 4 waves, 16-wide K slices, two blocks per CU
   }
   int rc;
   if (tile == 0) rc = launch_tile<256, 256, 2, 4, 2>(a, act, osplit, s);
-  else if (tile == 4) rc = launch_k16(a, act, osplit, s);
-  else if (tile == 3) rc = launch_tile<256, 256, 2, 2, 2>(a, act, osplit, s);
   else if (tile == 1) rc = launch_tile<256, 128, 4, 2, 3>(a, act, osplit, s);
   else rc = launch_tile<128, 128, 2, 2, 2>(a, act, osplit, s);
   if (rc) return rc;

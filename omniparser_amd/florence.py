@@ -321,11 +321,11 @@ class _CaptionPlans(_StepPlans):
             return out
 
         # x + dwconv(x) and the LayerNorm behind it as ONE strip kernel (csrc/caption_ops.hip::dwln_strip_kernel) wherever it exists
-        # (f32 plans, C = 128 / 256 / 512: DaViT stages 0-2); OMNI_FUSE_DWLN=0 keeps the two separate kernels (A/B knob)
-        fuse_env = os.environ.get("OMNI_FUSE_DWLN", "1") == "1"
+        # (f32 plans, C = 128 / 256 / 512: DaViT stages 0-2); Florence2Captioner.fuse_dwln = False keeps the two separate kernels
+        fuse_env = cap.fuse_dwln
         # the attention kernels write their output pre-split for the projection GEMM (no split_convert pass: 22.5 -> 0.3 ms per step on
-        # the MI355X, BENCH_r02 extra.ab_opt_in_kernels); OMNI_ATTN_SPLIT_OUT=0 = f32 output + in-place conversion (A/B knob)
-        attn_split = use_dma and os.environ.get("OMNI_ATTN_SPLIT_OUT", "1") != "0" and os.environ.get("OMNI_ATTN_MFMA", "1") != "0"
+        # the MI355X, BENCH_r02 extra.ab_opt_in_kernels); Florence2Captioner.attn_split_out = False = f32 output + in-place conversion
+        attn_split = use_dma and cap.attn_split_out
 
         def dwconv_ln(conv_key, norm_key, x: View, y1: View, hout: View):
             """x1 = x + dwconv(x); h = LN(x1) — one kernel (the conv result never leaves registers before the statistics)."""
@@ -507,6 +507,9 @@ class _Config(SimpleNamespace):
 class Florence2Captioner:
     """Duck-types the `model` half of the reference's caption_model_processor dict
     (ref:util/utils.py:108-125): `.config.name_or_path`, `.config.model_type`, `.device`, `.generate`."""
+    # plan composition switches (class attributes: the tests build the round-2 composition by overriding them)
+    fuse_dwln = True          # x + dwconv(x) -> LayerNorm as one strip kernel (DaViT stages 0-2)
+    attn_split_out = True     # attention kernels write format B for the projection GEMM themselves
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
         device = L.require_device(device, "Florence2Captioner")
@@ -519,12 +522,12 @@ class Florence2Captioner:
         self.w = FlorenceWeights(model_dir)
         self.config = _Config(name_or_path=str(model_dir) if "florence" in str(model_dir).lower() else f"florence:{model_dir}",
                               model_type="florence2")
-        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0" and os.environ.get("OMNI_HIPGRAPH_CAP", "1") != "0"
+        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"    # read when a plan is built: tools set the attribute to profile eagerly
         self.stream = torch.cuda.Stream(device=device)
         self._wcache = {}
         self._plans = {}
         self.max_new_tokens = 20
-        self.early_exit_every = int(os.environ.get("OMNI_DECODE_POLL", "5"))    # 0 = always run max_new_tokens steps
+        self.early_exit_every = 5        # poll the all-rows-finished flag every N decode steps (0 = always run max_new_tokens steps)
         self._lut = None
         self._lock = threading.RLock()   # plans own their device buffers: one caption batch at a time per model
 

@@ -378,10 +378,10 @@ def annotate(image_source: np.ndarray, boxes: torch.Tensor, logits, phrases, tex
     return frame, label_coordinates
 
 
-def encode_png_b64(frame: np.ndarray) -> str:
-    """ref:util/utils.py:485-488: RGB frame -> PNG -> base64 ascii (OMNI_PNG_LEVEL: zlib effort, 6 = Pillow's default)."""
+def encode_png_b64(frame: np.ndarray, compress_level: int = 6) -> str:
+    """ref:util/utils.py:485-488: RGB frame -> PNG -> base64 ascii (compress_level: zlib effort, 6 = Pillow's default)."""
     buf = io.BytesIO()
-    Image.fromarray(frame).save(buf, format="PNG", compress_level=int(os.environ.get("OMNI_PNG_LEVEL", "6")))
+    Image.fromarray(frame).save(buf, format="PNG", compress_level=compress_level)
     return base64.b64encode(buf.getvalue()).decode("ascii")
 
 
@@ -426,7 +426,7 @@ def png_deflate_device(frame: torch.Tensor, want_b64=True, stream=None):
 
 
 def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, device, text_scale=0.4, text_padding=5, text_thickness=2,
-                           thickness=3, frame_dev: Optional[torch.Tensor] = None):
+                           thickness=3, frame_dev: Optional[torch.Tensor] = None, stored: bool = False):
     """`annotate` + `encode_png_b64` with the raster, the PNG packing and the base64 on the device (OMNI_OVERLAY=device): same
     layout (util/overlay.py::plan_overlay), same pixels as the host raster, stored-deflate PNG; the host uploads the frame and a
     few KB of primitives and reads back ASCII.  -> (base64 str, label_coordinates)."""
@@ -442,7 +442,7 @@ def annotate_encode_device(image_np: np.ndarray, boxes: torch.Tensor, phrases, d
     # in place, no second upload
     frame = frame_dev if frame_dev is not None else torch.from_numpy(np.array(image_np, order="C")).to(device)
     render_device(frame, cmds)
-    if os.environ.get("OMNI_PNG_DEVICE", "deflate") == "stored":
+    if stored:                                         # stored-deflate PNG (pixels + 0.02 %); default: the run-length deflate stream
         _, b64 = png_pack_device(frame)
         text = b64.cpu().numpy().tobytes()
     else:

@@ -162,7 +162,7 @@ class YOLOv9Detector:
         blob = torch.jit.load(str(self.model_path), map_location="cpu").eval()
         self.state_dict = import_state_dict(blob)
         self.dtype = _precision_from_env(precision)
-        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0" and os.environ.get("OMNI_HIPGRAPH_DET", "1") != "0"
+        self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"
         self.stream = torch.cuda.Stream(device=self.device)
         self._wcache = {}
         self._plans = {}

@@ -12,3 +12,12 @@ def test_end_to_end_get_som_labeled_img():
     out = G.check_end_to_end(width=0.5, R=64, image_seed=1)
     assert out["n_gpu"] == out["n_ref"] and out["min_iou"] >= 0.999
     assert out["identical_crops_token_exact"] >= 0.8 * out["captioned"]
+
+
+def test_tiled_4k_end_to_end_captions_token_exact():
+    """BASELINE configs[4]: 3840x2160 -> tiled detection -> ~200 crops in 64-crop micro-batches: elements / crop rectangles = the
+    reference hand-off of the tiled boxes, caption ids of every crop = the CPU oracle's (greedy, token-exact)."""
+    import gpu_checks as G
+    out = G.check_tiled_captions(width=0.5, R=64)
+    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] >= 0.95 * out["crops"], out
+    print(out)

@@ -42,8 +42,8 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     # 0-2; with both switched off (the round-2 composition: separate dwconv / LayerNorm kernels, f32 attention output converted in
     # place) the same features come out — encode pass only
     assert any(op.kind == L.OP_DWCONV3_LN for op in cp.encode_plan.ops)
-    monkeypatch.setenv("OMNI_ATTN_SPLIT_OUT", "0")
-    monkeypatch.setenv("OMNI_FUSE_DWLN", "0")
+    monkeypatch.setattr(Florence2Captioner, "attn_split_out", False)
+    monkeypatch.setattr(Florence2Captioner, "fuse_dwln", False)
     cap2 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     cp2 = cap2.plans(1, 64, max_new)
     assert not any(op.kind == L.OP_DWCONV3_LN for op in cp2.encode_plan.ops)

@@ -42,8 +42,8 @@ def main():
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 768
     rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
     ensure_via_subprocess("caption", seed=0)
-    os.environ["OMNI_HIPGRAPH_CAP"] = "0"
     cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
+    cap.use_graph = False           # eager plans: every op is timed on its own
     cp = cap.plans(B, R, 20)
     g = torch.Generator().manual_seed(0)
     with torch.inference_mode(), torch.cuda.stream(cap.stream):

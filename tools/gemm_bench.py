@@ -1,6 +1,6 @@
 """Micro-benchmark of conv_igemm on the captioner's dominant GEMM shapes (HIP events, per variant).
 
-VARIANTS="f32,split:128x128,dma,dma:256x128,dma:128x128+OMNI_XCD_NSPLIT=0" — kind[:tile] and optional +ENV=value pairs
+VARIANTS="f32,split,dma,dma:256x128,dma:128x128" — kind[:tile] and optional +ENV=value pairs
 applied for that variant only.  kind: f32 (exact f32 MFMA), split (register-staged split-f16), dma (pre-split LDS-DMA GEMM,
 csrc/gemm_dma.hip: input converted to format B before the timed region, as its producer would have written it).  Accuracy is checked on 2048 rows sampled over the whole
 M range (a wrong block -> tile permutation would leave rows unwritten or doubly written)."""
@@ -26,18 +26,18 @@ def main():
     dtype = L.F32 if os.environ.get("OMNI_PRECISION", "f32") == "f32" else L.F16
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     stream = torch.cuda.Stream()
-    for variant in os.environ.get("VARIANTS", "split:128x128,dma,dma:256x128,dma:128x128").split(","):
+    for variant in os.environ.get("VARIANTS", "split,dma,dma:256x128,dma:128x128").split(","):
         os.environ["OMNI_CONV_SPLIT"] = "0" if variant.startswith("f32") else "1"
         variant, *envs = variant.split("+")
-        for k in ("OMNI_XCD_NSPLIT", "OMNI_XCD_L2_BUDGET_KB", "OMNI_GEMM_TILE", "OMNI_SPLIT_TILE", "OMNI_GEMM_SCHED"):
+        for k in ("OMNI_GEMM_TILE",):
             os.environ.pop(k, None)
         for kv in envs:
             k, v = kv.split("=")
             os.environ[k] = v
         parts = variant.split(":")
         dma = parts[0] == "dma"
-        if len(parts) > 1:
-            os.environ["OMNI_GEMM_TILE" if dma else "OMNI_SPLIT_TILE"] = parts[1]
+        if len(parts) > 1 and dma:
+            os.environ["OMNI_GEMM_TILE"] = parts[1]
         print(f"--- variant {variant} {' '.join(envs)}")
         only = [t for t in os.environ.get("SHAPES", "").split(",") if t]
         for name, M, N, K, act, res in SHAPES:

@@ -82,9 +82,8 @@ def main():
                     finite=[bool(np.isfinite(g).all()), bool(np.isfinite(r).all())])
         c.close()
     # python eager
-    os.environ["OMNI_HIPGRAPH_CAP"] = "0"
     cap2 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=R)
-    os.environ.pop("OMNI_HIPGRAPH_CAP", None)
+    cap2.use_graph = False
     pe = cap2.caption_crops(dimg, rects, max_new_tokens=20, batch_size=capn).numpy().astype(np.int32)
     say(what="python eager vs python graph, per row", rows=rows_equal(pe, py[0]), shapes=[list(pe.shape), list(py[0].shape)])
     # margins of the python logits at the last step (how decisive is the arg-max?)
