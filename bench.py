@@ -46,7 +46,11 @@ def parse_args():
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
-    ap.add_argument("--pipeline", action="store_true", help="time the K steps through ScreenParser.parse_stream (steps overlap) instead of K parse_batch calls")
+    ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
+                    help="time K synchronous parse_batch calls instead of the K steps through ScreenParser.parse_stream (the default: "
+                         "detector of step i+1, two encode lanes and the decode of step i overlap; same kernels, same results)")
+    ap.add_argument("--pipeline", dest="pipeline", action="store_true", help=argparse.SUPPRESS)
+    ap.set_defaults(pipeline=True)
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
@@ -274,12 +278,17 @@ def main():
                                                                                      "annotate_bench.py")], {}, 120)
             note("annotate_tail done")
             # BASELINE configs[3] stand-in on this one GPU: mixed-resolution eval stream (tools/stream_bench.py), 64x64 crops
+            keep = ("metric", "value", "unit", "items", "seconds", "caption_res", "device_batch", "rank0_batches", "mean_elements",
+                    "resolution_counts", "data")
             out["extra"]["stream_mixed_resolution_r64"] = child_json(
                 [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stream_bench.py"), "--items", "48",
-                 "--caption-res", "64"], {}, 150,
-                keep=("metric", "value", "unit", "items", "seconds", "caption_res", "device_batch", "rank0_batches", "mean_elements",
-                      "resolution_counts", "data"))
+                 "--caption-res", "64"], {}, 150, keep=keep)
             note("stream_mixed_resolution_r64 done")
+            # the same stream at the parity resolution (768x768 crops): the real kernels of configs[3] on one GPU
+            out["extra"]["stream_mixed_resolution_r768"] = child_json(
+                [sys.executable, os.path.join(os.path.dirname(os.path.abspath(__file__)), "tools", "stream_bench.py"), "--items", "24",
+                 "--caption-res", "768"], {}, 240, keep=keep)
+            note("stream_mixed_resolution_r768 done")
         if world == 1 and not args.no_cpu_baseline:
             guarded("cpu_baseline", lambda: cpu_baseline(args, blob, imgsz, out["config"].get("mean_crops_per_screenshot", 0)))
         faulthandler.cancel_dump_traceback_later()
@@ -320,10 +329,17 @@ def child_json(cmd, env, limit_s, keep=None):
     return d
 
 
+GEMM_KINDS = (1, 24)        # OMNI_OP_CONV (conv / linear) and OMNI_OP_MLP_FUSED (fc1 + GELU + fc2 in one kernel): the MFMA-bound family
+
+
+def gemm_of(by_kind):
+    return sum(by_kind.get(k, 0.0) for k in GEMM_KINDS)
+
+
 KIND_NAMES = {1: "gemm (conv / linear)", 2: "avgpool", 3: "maxpool", 4: "resize_nearest", 5: "letterbox", 6: "detect_decode", 7: "nms",
               8: "dwconv3", 9: "layernorm", 10: "attention (window / mha)", 11: "channel_attention", 12: "proj_prep", 13: "assemble",
               14: "embed_step", 15: "attn_decode", 16: "greedy_step", 17: "crop_resize", 18: "dwconv3+ln", 19: "split_convert", 20: "hand-off",
-              21: "overlay", 22: "png_pack"}
+              21: "overlay", 22: "png_pack", 23: "png_deflate", 24: "mlp_fused (fc1+GELU+fc2, GEMM family)"}
 
 
 def profile_plan(plan, stream, repeat=1):
@@ -333,7 +349,7 @@ def profile_plan(plan, stream, repeat=1):
         ms = plan.profile(stream)
         for op, t in zip(plan.ops, ms):
             by_kind[op.kind] = by_kind.get(op.kind, 0.0) + t
-        n_gemm += sum(1 for op in plan.ops if op.kind == 1)
+        n_gemm += sum(1 for op in plan.ops if op.kind in GEMM_KINDS)
     return by_kind, n_gemm
 
 
@@ -379,9 +395,9 @@ def roofline(args, det, parser, dp, crop_counts, B):
                 cp.reset()
             be, ne = profile_plan(cp.encode_plan, cap.stream)
             add(be, cnt)
-            gemm_ms += cnt * be.get(1, 0.0)
+            gemm_ms += cnt * gemm_of(be)
             launches += cnt * ne
-            part = {"encode_gemm_ms": round(be.get(1, 0.0), 3), "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2),
+            part = {"encode_gemm_ms": round(gemm_of(be), 3), "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2),
                     "step_gflop_per_crop": round(cp.step_flops / cp.B / 1e9, 4), "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
             if not merged:
                 bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20)
@@ -407,7 +423,7 @@ def roofline(args, det, parser, dp, crop_counts, B):
     peak = 2500.0 if (split or args.precision == "f16") else 157.3
     total = sum(fam.values())
     out = {"bound": "mfma",
-           "kernel": ("gemm_dma_kernel (pre-split LDS-DMA GEMM, split-f16 x3 MFMA, f32 accumulate) + conv_split_kernel (convs, decoder steps)"
+           "kernel": ("gemm_dma_kernel (pre-split LDS-DMA GEMM, split-f16 x3 MFMA, f32 accumulate) + mlp_fused_kernel (DaViT stage-0 FFN) + conv_split_kernel (convs, decoder steps)"
                       if split else "conv_igemm_kernel<T,BM,BN,RB,ALIGNED,PW>") + " + splitk_reduce_kernel",
            "achieved": round(achieved, 3), "peak": peak, "unit": "TFLOP/s", "frac": round(achieved / peak, 4), "traffic": None}
     if split:

@@ -188,6 +188,15 @@ enum {
    *  i0 H i1 W i2 capacity of p1 (>= H (3 W + 1) + 5 units + 63) i3 meta words (>= 4 + 2 units) i4 scratch words
    *  (>= 2 H + ceil((capacity - 53) / 4096)) */
   OMNI_OP_PNG_DEFLATE = 23,
+  /* FFN of a DaViT block as one kernel (hf:models/florence2/modeling_florence2.py Florence2VisionMLP inside the residual of
+   * Florence2VisionSpatialBlock / ChannelBlock): y = residual + fc2(GELU(fc1(x))), hidden activations kept in registers
+   * (csrc/gemm_dma.hip::mlp_fused_kernel).  f32 plans, C = 128, hidden = 512 (DaViT stage 0 of Florence-2-base).
+   *  p0 x [rows, ldi] in format B (see OMNI_OP_CONV i20 = 2)   p1 w1 format B [hidden][C], = split(W1 * 2^k1)   p2 b1 f32[hidden]
+   *  p3 residual f32 [rows, ldr]   p4 y f32 [rows, ldo] (may alias the residual)   p6 b2 f32[C]
+   *  p5 w2 format B [C][hidden] = split(W2 * 2^k2) with the hidden axis permuted inside every 16-group to
+   *     {0,1,2,3, 8,9,10,11, 4,5,6,7, 12,13,14,15} (the order in which the first product's accumulators hold it)
+   *  i0*i1 rows i3 C i4 ldi i5 in_coff i12 hidden i13 ldo i14 out_coff i16 ldr i17 res_coff; f1 2^-k1 f2 2^-k2 */
+  OMNI_OP_MLP_FUSED = 24,
   OMNI_OP__COUNT
 };
 

@@ -14,7 +14,7 @@ ACT_NONE, ACT_SILU, ACT_GELU = 0, 1, 2
 OP_CONV, OP_AVGPOOL2, OP_MAXPOOL, OP_RESIZE_NEAREST, OP_LETTERBOX, OP_DETECT_DECODE, OP_NMS = 1, 2, 3, 4, 5, 6, 7
 OP_DWCONV3, OP_LAYERNORM, OP_ATTN_ROWS, OP_CHAN_ATTN, OP_PROJ_PREP, OP_ASSEMBLE = 8, 9, 10, 11, 12, 13
 OP_EMBED_STEP, OP_ATTN_DECODE, OP_GREEDY_STEP, OP_CROP_RESIZE, OP_DWCONV3_LN, OP_SPLIT_CONVERT, OP_GLUE = 14, 15, 16, 17, 18, 19, 20
-OP_OVERLAY, OP_PNG_PACK, OP_PNG_DEFLATE = 21, 22, 23
+OP_OVERLAY, OP_PNG_PACK, OP_PNG_DEFLATE, OP_MLP_FUSED = 21, 22, 23, 24
 CAND_BYTES = 32
 
 EXPORTS = [

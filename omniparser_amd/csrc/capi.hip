@@ -35,6 +35,7 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
   switch (op->kind) {
     case OMNI_OP_CONV: return op->i[20] == 2 ? omni_launch_gemm_dma(op, s) : omni_launch_conv(op, s);
     case OMNI_OP_SPLIT_CONVERT: return omni_launch_split_convert(op, s);
+    case OMNI_OP_MLP_FUSED: return omni_launch_mlp_fused(op, s);
     case OMNI_OP_GLUE: return omni_launch_glue(op, s);
     case OMNI_OP_OVERLAY: return omni_launch_overlay(op, s);
     case OMNI_OP_PNG_PACK: return omni_launch_png_pack(op, s);

@@ -336,6 +336,163 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
   *reinterpret_cast<u32x4*>(dst + 48) = u32x4{lo[2].x, lo[2].y, lo[3].x, lo[3].y};
 }
 
+// ---- OMNI_OP_MLP_FUSED: the FFN of a DaViT block, y = x1 + fc2(GELU(fc1(h))), as ONE kernel for the narrow stage (C = 128, hidden
+// 512: 4.7 M tokens per 128-crop micro-batch at 768x768).  As two GEMM launches its K = 128 / N = 128 layers are bound by everything
+// except the matrix pipe: fc1 writes 9.7 GB of hidden activations (4 K slices of MFMA work per 256 KB tile written, GELU for 64 K
+// elements with the pipe idle), fc2 reads them back — 154 and 231 TF/s where the K = 2048 layers reach 411
+// (profiles/r3_s9_caption_per_op.txt).  Here a wave keeps its 32 tokens' input fragments (K = 128: 64 registers) and its 32 x 128
+// output accumulators in registers and walks the hidden dimension in chunks of 32 channels:
+//   acc1[32 hidden x 32 tokens]  = W1[chunk] . h^T              24 MFMAs (8 K groups x hi.hi + lo.hi + hi.lo)
+//   g = GELU(acc1 * 2^-k1 + b1) -> (hi, lo) halves in registers
+//   acc2[128 out x 32 tokens]   += W2[:, chunk] . g^T           24 MFMAs
+// The D layout of the first product (lane = token, 4 consecutive hidden channels per accumulator quad) IS an MFMA column operand of
+// the second one up to the order of the K index inside a 16-group: lane half h holds channels {4h..4h+3, 8+4h..8+4h+3}, so W2 is
+// packed with its hidden axis permuted the same way inside every 16-group (planner.pack_weight_dma(kperm=True)) and the hidden
+// activations never leave the register file.  Weight chunks (16 KB of W1 rows + 16 KB of W2 columns) stream L2 -> LDS by LDS-DMA
+// into a two-stage ring shared by the block's four waves (same 128-byte rows, same XOR swizzle as gemm_dma_kernel); two blocks per
+// CU, so one block's GELU / barrier overlaps the other's MFMAs.  HBM traffic: h in, residual in, y out — 12 bytes per element of
+// the token matrix instead of 44.
+struct MlpArgs {
+  const unsigned char* x; const unsigned char* w1; const unsigned char* w2; const float* b1;
+  GemmArgs ep;                        // epilogue view: bias = b2, res, y, M, ldo, out_coff, ldr, res_coff, oscale = 2^-k2
+  int ldi, in_coff;
+  float osc1;                         // 2^-k1
+};
+
+template <int C, int HID>
+__global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs a) {
+#if defined(__HIP_DEVICE_COMPILE__)
+  static_assert(C == 128 && HID % 32 == 0, "written for the C = 128 stage: 8 K groups in registers, 4 output tiles");
+  constexpr int NW = 4, KG = C / 16, OB = C / 32, NCH = HID / 32;
+  constexpr int W1B = 32 * C * 4, W2B = C * 128, STAGE = W1B + W2B;      // bytes of one chunk's W1 rows / W2 columns
+  constexpr int P1 = W1B / 1024 / NW, P2 = W2B / 1024 / NW;              // 1 KiB DMA pieces per wave and chunk
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE + HID * 4];
+  float* lb1 = reinterpret_cast<float*>(lds + 2 * STAGE);
+
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int m0 = blockIdx.x * (NW * 32);
+  const int hsel = lane >> 5, swz = (lane >> 1) & 7;
+
+  // ---- fc1 bias -> LDS (2 KB, read per chunk)
+  for (int e = tid * 4; e < HID; e += 256 * 4) *reinterpret_cast<f32x4*>(lb1 + e) = *reinterpret_cast<const f32x4*>(a.b1 + e);
+
+  // ---- LDS-DMA descriptors (piece = 8 rows x 128 B; lane l supplies row 8p + l/8, 16-byte slot l%8 from SOURCE chunk slot ^ swizzle)
+  const int rsub = lane >> 3, slot = lane & 7;
+  unsigned voff1[P1], voff2[P2];
+#pragma unroll
+  for (int i = 0; i < P1; ++i) {            // W1 chunk in LDS: [K slice s][32 hidden rows][128 B]; this wave: piece index wave * P1 + i
+    const int pc = wave * P1 + i, rl = (pc & 3) * 8 + rsub, sl = pc >> 2;
+    voff1[i] = (unsigned)rl * (unsigned)(C * 4) + (unsigned)(sl * 128) + (unsigned)((slot ^ ((rl >> 1) & 7)) * 16);
+  }
+#pragma unroll
+  for (int i = 0; i < P2; ++i) {            // W2 chunk in LDS: [C output rows][128 B = this chunk's 32 hidden channels]
+    const int rl = (wave * P2 + i) * 8 + rsub;
+    voff2[i] = (unsigned)rl * (unsigned)(HID * 4) + (unsigned)((slot ^ ((rl >> 1) & 7)) * 16);
+  }
+  const __amdgpu_buffer_rsrc_t rsrc1 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w1, 0, 0x7fffffff, 0x00020000);
+  const __amdgpu_buffer_rsrc_t rsrc2 = __builtin_amdgcn_make_buffer_rsrc((void*)a.w2, 0, 0x7fffffff, 0x00020000);
+  auto issue = [&](int c, int stage) {
+#pragma unroll
+    for (int i = 0; i < P1; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc1, (lds_void*)(lds + stage * STAGE + (wave * P1 + i) * 1024), 16, voff1[i], c * (32 * C * 4), 0, 0);
+#pragma unroll
+    for (int i = 0; i < P2; ++i)
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrc2, (lds_void*)(lds + stage * STAGE + W1B + (wave * P2 + i) * 1024), 16, voff2[i], c * 128, 0, 0);
+  };
+  issue(0, 0);
+
+  // ---- this wave's 32 tokens: all K = C input fragments stay in registers (lane -> token lane & 31, 8 halves 8 * (lane >> 5) .. of a group)
+  f16x8 xh[KG], xl[KG];
+  {
+    const int m = min(m0 + wave * 32 + (lane & 31), a.ep.M - 1);             // M tail: re-read the last row (never stored)
+    const unsigned char* xrow = a.x + ((long long)m * a.ldi + a.in_coff) * 4 + hsel * 16;
+#pragma unroll
+    for (int g = 0; g < KG; ++g) {
+      xh[g] = *reinterpret_cast<const f16x8*>(xrow + g * 64);
+      xl[g] = *reinterpret_cast<const f16x8*>(xrow + g * 64 + 32);
+    }
+  }
+  // fragment read offsets inside a stage: row lane & 31, 16-byte chunk (group gg of the 32-wide slice, part hi / lo) = 4 gg + 2 part +
+  // half, swizzled — four values; K slice (W1) and output tile (W2) are immediate offsets on top
+  int fo[2][2];
+#pragma unroll
+  for (int gg = 0; gg < 2; ++gg)
+#pragma unroll
+    for (int pt = 0; pt < 2; ++pt) fo[gg][pt] = (lane & 31) * 128 + (((gg * 4 + pt * 2 + hsel) ^ swz) * 16);
+
+  f32x16 acc2[1][OB];
+#pragma unroll
+  for (int j = 0; j < OB; ++j)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc2[0][j][e] = 0.0f;
+  const float osc1 = a.osc1;
+  __syncthreads();                                       // fc1 bias visible
+
+  for (int c = 0; c < NCH; ++c) {
+    const int stage = c & 1;
+    OMNI_WAIT_VMCNT(0);                                  // this wave's pieces of chunk c (and, the first time, its input fragments)
+    __builtin_amdgcn_s_barrier();                        // everybody's pieces landed; everybody is done reading the other stage
+    if (c + 1 < NCH) issue(c + 1, stage ^ 1);
+    const unsigned char* st = lds + stage * STAGE;
+    // ---- fc1 chunk: two accumulators (even / odd K groups) so that consecutive MFMAs do not wait for each other
+    f32x16 a1[2];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { a1[0][e] = 0.0f; a1[1][e] = 0.0f; }
+#pragma unroll
+    for (int g = 0; g < KG; g += 2) {
+      const unsigned char* sl = st + (g >> 1) * 4096;       // K slice g / 2 of the W1 rows; g even -> group 0, g + 1 -> group 1
+      const f16x8 wh0 = *reinterpret_cast<const f16x8*>(sl + fo[0][0]), wl0 = *reinterpret_cast<const f16x8*>(sl + fo[0][1]);
+      const f16x8 wh1 = *reinterpret_cast<const f16x8*>(sl + fo[1][0]), wl1 = *reinterpret_cast<const f16x8*>(sl + fo[1][1]);
+      a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xh[g], a1[0], 0, 0, 0);
+      a1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xh[g + 1], a1[1], 0, 0, 0);
+      a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, xh[g], a1[0], 0, 0, 0);
+      a1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, xh[g + 1], a1[1], 0, 0, 0);
+      a1[0] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, xl[g], a1[0], 0, 0, 0);
+      a1[1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, xl[g + 1], a1[1], 0, 0, 0);
+    }
+    // ---- bias + GELU + split: accumulator e = 4q + r is hidden channel 32c + 8q + 4 * (lane >> 5) + r of token lane & 31
+    f16x8 gh[2], gl[2];
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg) {
+      uint2 hq[2], lq[2];
+#pragma unroll
+      for (int qq = 0; qq < 2; ++qq) {
+        const int q = kg * 2 + qq;
+        const f32x4 bq = *reinterpret_cast<const f32x4*>(lb1 + c * 32 + 8 * q + 4 * hsel);
+        float v[4];
+#pragma unroll
+        for (int r = 0; r < 4; r += 2) {
+          const f32x2 t = omni_gelu2((f32x2{a1[0][q * 4 + r], a1[0][q * 4 + r + 1]} + f32x2{a1[1][q * 4 + r], a1[1][q * 4 + r + 1]}) * osc1 +
+                                     f32x2{bq[r], bq[r + 1]});
+          v[r] = t[0]; v[r + 1] = t[1];
+        }
+        omni_split4(v, hq[qq], lq[qq]);
+      }
+      gh[kg] = __builtin_bit_cast(f16x8, u32x4{hq[0].x, hq[0].y, hq[1].x, hq[1].y});
+      gl[kg] = __builtin_bit_cast(f16x8, u32x4{lq[0].x, lq[0].y, lq[1].x, lq[1].y});
+    }
+    // ---- fc2 chunk: output tiles two at a time (their weight fragments are the live registers that decide the occupancy)
+#pragma unroll
+    for (int kg = 0; kg < 2; ++kg)
+#pragma unroll
+      for (int j = 0; j < OB; j += 2) {
+        const unsigned char* sw = st + W1B + j * 4096;
+        const f16x8 wh0 = *reinterpret_cast<const f16x8*>(sw + fo[kg][0]), wl0 = *reinterpret_cast<const f16x8*>(sw + fo[kg][1]);
+        const f16x8 wh1 = *reinterpret_cast<const f16x8*>(sw + 4096 + fo[kg][0]), wl1 = *reinterpret_cast<const f16x8*>(sw + 4096 + fo[kg][1]);
+        acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, gh[kg], acc2[0][j], 0, 0, 0);
+        acc2[0][j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, gh[kg], acc2[0][j + 1], 0, 0, 0);
+        acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl0, gh[kg], acc2[0][j], 0, 0, 0);
+        acc2[0][j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wl1, gh[kg], acc2[0][j + 1], 0, 0, 0);
+        acc2[0][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh0, gl[kg], acc2[0][j], 0, 0, 0);
+        acc2[0][j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, gl[kg], acc2[0][j + 1], 0, 0, 0);
+      }
+  }
+  // ---- epilogue: 2^-k2, fc2 bias, residual, coalesced f32 rows (gemm_epilogue: four waves x 32 tokens x 128 channels)
+  gemm_epilogue<NW * 32, C, NW, 1, 1, OB, 2 * STAGE, OMNI_ACT_NONE, false, true>(acc2, a.ep, lds, m0, 0, wave, lane);
+#endif
+}
+
 template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
@@ -423,3 +580,29 @@ int omni_launch_split_convert(const omni_op_t* op, hipStream_t s) {
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
 }
+
+// OMNI_OP_MLP_FUSED (see include/omni_amd.h): y = res + fc2(GELU(fc1(x))) on format-B operands, C = 128.
+int omni_launch_mlp_fused(const omni_op_t* op, hipStream_t s) {
+  MlpArgs a;
+  a.x = (const unsigned char*)op->p[0]; a.w1 = (const unsigned char*)op->p[1]; a.b1 = (const float*)op->p[2];
+  a.w2 = (const unsigned char*)op->p[5];
+  a.ep.x = nullptr; a.ep.w = nullptr; a.ep.bias = (const float*)op->p[6]; a.ep.res = (const float*)op->p[3]; a.ep.y = (unsigned char*)op->p[4];
+  const long long M = (long long)op->i[0] * (op->i[1] > 0 ? op->i[1] : 1);
+  const int C = op->i[3], HID = op->i[12];
+  a.ldi = op->i[4]; a.in_coff = op->i[5];
+  a.ep.ldo = op->i[13]; a.ep.out_coff = op->i[14]; a.ep.ldr = op->i[16]; a.ep.res_coff = op->i[17];
+  a.osc1 = op->f[1] != 0.0f ? op->f[1] : 1.0f;
+  a.ep.oscale = op->f[2] != 0.0f ? op->f[2] : 1.0f;
+  OMNI_REQUIRE(op->dtype == OMNI_F32, "mlp_fused: f32 plans only");
+  OMNI_REQUIRE(a.x && a.w1 && a.w2 && a.b1 && a.ep.bias && a.ep.res && a.ep.y, "mlp_fused: null pointer (both biases and the residual are required)");
+  OMNI_REQUIRE(C == 128 && HID == 512, "mlp_fused: built for C = 128, hidden = 512 (got %d, %d)", C, HID);
+  OMNI_REQUIRE(M > 0 && M < (1ll << 31), "mlp_fused: bad row count");
+  OMNI_REQUIRE(a.ldi % 16 == 0 && a.in_coff % 16 == 0, "mlp_fused: split input needs 16-channel aligned ld / offset");
+  OMNI_REQUIRE(a.ep.ldo % 4 == 0 && a.ep.out_coff % 4 == 0 && a.ep.ldr % 4 == 0 && a.ep.res_coff % 4 == 0, "mlp_fused: output / residual alignment");
+  a.ep.M = (int)M; a.ep.N = C; a.ep.K = HID; a.ep.nk = 0; a.ep.ldi = 0; a.ep.in_coff = 0;
+  a.ep.mtiles = a.ep.ntiles = a.ep.xcd_order = a.ep.xcd_n = 0;
+  hipLaunchKernelGGL((mlp_fused_kernel<128, 512>), dim3((unsigned)((M + 127) / 128)), dim3(256), 0, s, a);
+  OMNI_HIP_CHECK(hipGetLastError());
+  return OMNI_OK;
+}
+

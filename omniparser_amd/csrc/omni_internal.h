@@ -152,6 +152,7 @@ __device__ __forceinline__ f32x2 omni_gelu2(f32x2 v) {
 int omni_launch_conv(const omni_op_t* op, hipStream_t s);
 int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s);
 int omni_launch_split_convert(const omni_op_t* op, hipStream_t s);
+int omni_launch_mlp_fused(const omni_op_t* op, hipStream_t s);
 int omni_launch_avgpool2(const omni_op_t* op, hipStream_t s);
 int omni_launch_maxpool(const omni_op_t* op, hipStream_t s);
 int omni_launch_resize_nearest(const omni_op_t* op, hipStream_t s);

@@ -378,7 +378,10 @@ class _CaptionPlans(_StepPlans):
             hbuf = pb.alloc(B, H, H, C)
             qkv = pb.alloc(B, H, H, 3 * C)
             att = pb.alloc(B, H, H, C)
-            ffn = pb.alloc(B, H, H, 4 * C)
+            # the FFN of the C = 128 stage is one kernel whose hidden activations stay in registers (csrc/gemm_dma.hip::mlp_fused_kernel):
+            # no [B, H, H, 4C] tensor (9.7 GB of a 128-crop plan at 768x768), 12 instead of 44 bytes of HBM traffic per token-channel
+            mlp_one = grp["dma"] and cap.fuse_mlp and C == 128 and sd[f"{vt}blocks.{s}.0.spatial_block.ffn.fc1.weight"].shape[0] == 512
+            ffn = None if mlp_one else pb.alloc(B, H, H, 4 * C)
             chunk_tokens = 1024
             chunks = (N + chunk_tokens - 1) // chunk_tokens
             cws = pb.raw((B * w.groups[s] * chunks * 1024,), torch.float32, zero=False)
@@ -405,6 +408,15 @@ class _CaptionPlans(_StepPlans):
                         att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
+                    if mlp_one:
+                        k1, k2 = pre + "ffn.fc1", pre + "ffn.fc2"
+                        w1p, b1p = packed(k1, lambda k=k1: (sd[k + ".weight"], sd[k + ".bias"]), dma=True)
+                        ck = (k2, dt, "dma-kperm")
+                        if ck not in wc:
+                            wc[ck] = (pb.pack_weight_dma(sd[k2 + ".weight"], kperm=True), pb.upload(sd[k2 + ".bias"].float()))
+                        w2p, b2p = wc[ck]
+                        pb.mlp_fused(tokens(hbuf), w1p, b1p, w2p, b2p, tokens(A_), tokens(A_))
+                        continue
                     linear(pre + "ffn.fc1", hbuf, ffn, act=L.ACT_GELU, out_split=True)
                     linear(pre + "ffn.fc2", ffn, A_, res=A_)
             x = A_
@@ -510,6 +522,7 @@ class Florence2Captioner:
     # plan composition switches (class attributes: the tests build the round-2 composition by overriding them)
     fuse_dwln = True          # x + dwconv(x) -> LayerNorm as one strip kernel (DaViT stages 0-2)
     attn_split_out = True     # attention kernels write format B for the projection GEMM themselves
+    fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
         device = L.require_device(device, "Florence2Captioner")

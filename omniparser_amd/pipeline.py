@@ -85,6 +85,7 @@ class ScreenParser:
         self.max_det, self.imgsz, self.batch_size = max_det, imgsz, max(1, min(int(batch_size), 128))   # caption plan capacity
         self.max_new_tokens = 20          # ref:util/utils.py:125 generate(max_new_tokens=20)
         self.encode_lanes = 2             # parse_stream: caption micro-batches in flight at once (HIP streams; 1 = one after the other)
+        self._ev = {}                     # HIP events of the last parse_batch (stage boundaries on the streams the stages run on)
         self.stats = {}
 
     # ---- stage 1: detector over the whole batch (one graph launch)
@@ -223,11 +224,13 @@ class ScreenParser:
                     seen[cls] = seen.get(cls, 0) + 1
             gs.h_meta[fi, 0] = m
         with torch.cuda.stream(det.stream):
+            self._ev["det0"] = det.stream.record_event(torch.cuda.Event(enable_timing=True))
             for bi, f in enumerate(frames):
                 dp.img[bi].copy_(f, non_blocking=True)
             gs.ocr.copy_(gs.h_ocr)
             gs.meta.copy_(gs.h_meta)
             gs.launch(det)                                        # detector + hand-off: one graph
+            self._ev["det1"] = det.stream.record_event(torch.cuda.Event(enable_timing=True))
             tables = (dp, gs)
             if snapshot:
                 snap = SimpleNamespace(out_boxes=dp.out_boxes.clone(), out_count=dp.out_count.clone(), elems=gs.elems.clone(),
@@ -304,6 +307,8 @@ class ScreenParser:
         if merged and not overlap:
             with torch.cuda.stream(cap.stream):
                 dec.reset()
+        if not overlap:
+            self._ev["cap0"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
         used = []
         for mbi, s in enumerate(range(0, len(flat), self.batch_size)):
             chunk = flat[s:s + self.batch_size]
@@ -354,7 +359,9 @@ class ScreenParser:
         ids_stream = cap.stream
         if merged and not overlap:
             with torch.cuda.stream(cap.stream):
+                self._ev["cap1"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
                 ids_all.append(cap._decode_merged(dec, len(flat), max_new_tokens))
+                self._ev["cap2"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
         elif merged:
             ids_stream = cap.dec_stream
             encoded = [st.record_event() for st in used]
@@ -364,6 +371,8 @@ class ScreenParser:
                 dec.reset()
                 ids_all.append(cap._decode_merged(dec, len(flat), max_new_tokens, ids_stream))
                 dec.free_evt = ids_stream.record_event()
+        if not overlap:
+            self._ev["capE"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
         return (list(frames), flat, ids_all, ids_stream)
 
     @torch.inference_mode()
@@ -486,6 +495,22 @@ class ScreenParser:
         if pending is not None:
             yield finish(pending)
 
+    def stage_ms(self):
+        """device time of the stages of the last `parse_batch` (HIP events recorded on the stream each stage runs on; everything has
+        been read back by now, so the events have completed): detector + hand-off graph, caption encode (crop -> DaViT -> BART encoder
+        -> cross K/V of every micro-batch), the 20 decode steps.  The reference returns one wall-clock `latency` per request
+        (ref:omnitool/omniparserserver/omniparserserver.py:42-44); the batch route adds this split."""
+        ev, out = self._ev, {}
+        for name, a, b in (("detect+handoff", "det0", "det1"), ("caption", "cap0", "capE"), ("caption_encode", "cap0", "cap1"),
+                           ("caption_decode", "cap1", "cap2")):
+            if a in ev and b in ev:
+                try:
+                    out[name] = round(float(ev[a].elapsed_time(ev[b])), 3)
+                except RuntimeError:       # an event of an earlier batch that never completed on this path
+                    pass
+        self._ev = {}
+        return out
+
     @staticmethod
     def _fill_captions(elems_all, caps):
         ids_out = []
@@ -507,7 +532,7 @@ class ScreenParser:
             caps = self.caption(frames, n_crops, crops_dev=gs.crops)
             elems_all = self.assemble(dp, gs, ocr_els, counts, iw, ih, len(frames))
             ids_out = self._fill_captions(elems_all, caps)
-            self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()]}
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()], "stage_ms": self.stage_ms()}
             self.last_crops = [gs.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
         if tiled:

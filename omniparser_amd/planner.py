@@ -135,9 +135,17 @@ class PlanBuilder:
         lo = (ws - hi.float()).to(torch.float16)
         return torch.cat([hi.view(cout, K // 16, 16), lo.view(cout, K // 16, 16)], -1).contiguous(), 2.0 ** -k
 
-    def pack_weight_dma(self, w: torch.Tensor) -> torch.Tensor:
-        """[Cout, Cin] or [Cout, Cin, 1, 1] f32 -> device format-B weight for the pre-split LDS-DMA GEMM (f32 plans)."""
+    KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)
+
+    def pack_weight_dma(self, w: torch.Tensor, kperm: bool = False) -> torch.Tensor:
+        """[Cout, Cin] or [Cout, Cin, 1, 1] f32 -> device format-B weight for the pre-split LDS-DMA GEMM (f32 plans).
+        kperm: the K axis is permuted inside every 16-group to the order in which a 32x32 MFMA accumulator tile holds it as the
+        column operand of the next product (fc2 of OMNI_OP_MLP_FUSED: position 8h + j holds channel 8 (j // 4) + 4h + j % 4)."""
         w2d = w.detach().float().reshape(w.shape[0], -1)
+        if kperm:
+            cout, K = w2d.shape
+            assert K % 16 == 0
+            w2d = w2d.view(cout, K // 16, 16)[:, :, list(self.KPERM16)].reshape(cout, K).contiguous()
         t, oscale = self.split_f16_b(w2d)
         t = self.upload(t)
         t.omni_fmt, t.omni_oscale = 2, oscale
@@ -205,6 +213,24 @@ class PlanBuilder:
         esz = 4 if self.dtype == L.F32 else 2
         self.flops += 2 * M * cout * k * k * x.C
         self.bytes += esz * (x.B * x.H * x.W * x.C + w_packed.numel() // (2 if wfmt else 1) + M * cout * (2 if res is not None else 1))
+        return out
+
+    def mlp_fused(self, x: View, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, res: View, out: View):
+        """out = res + fc2(GELU(fc1(x))) as ONE op (csrc/gemm_dma.hip::mlp_fused_kernel): x in format B, w1 / w2 from
+        pack_weight_dma (w2 with kperm=True), biases f32 on the device; hidden activations never reach HBM."""
+        C, hid = x.C, b1.numel()
+        assert self.dtype == L.F32 and x.fmt == "split" and res.fmt == "f32" and (C, hid) == (128, 512), (x.fmt, res.fmt, C, hid)
+        assert getattr(w1, "omni_fmt", 0) == 2 and getattr(w2, "omni_fmt", 0) == 2 and w1.numel() == 2 * hid * C == w2.numel()
+        assert (out.B, out.H, out.W, out.C) == (x.B, x.H, x.W, C) == (res.B, res.H, res.W, res.C) and b2.numel() == C
+        rows = x.B * x.H * x.W
+        self.ops.append(L.make_op(L.OP_MLP_FUSED, self.dtype,
+                                  p=[x.ptr, w1.data_ptr(), b1.data_ptr(), res.ptr, out.ptr, w2.data_ptr(), b2.data_ptr()],
+                                  i={0: rows, 1: 1, 3: C, 4: x.ld, 5: x.coff, 12: hid, 13: out.ld, 14: out.coff, 16: res.ld, 17: res.coff},
+                                  f={1: w1.omni_oscale, 2: w2.omni_oscale}))
+        self.keep += [w1, w2, b1, b2]
+        out.fmt = "f32"
+        self.flops += 2 * rows * C * hid * 2
+        self.bytes += 4 * (rows * C * 3 + 2 * C * hid)          # h in, residual in, y out, both weight matrices
         return out
 
     def split_convert(self, x: View, out: Optional[View] = None) -> View:

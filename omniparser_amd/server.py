@@ -107,8 +107,9 @@ class ParseService:
             else:
                 pngs = list(self.pool.map(lambda a: self._render(*a), [(images[i], el) for i, el in zip(group, elems)]))
             dt = time.time() - t0
+            stage_ms = dict(getattr(sp, "stats", {}).get("stage_ms", {}))      # HIP-event device time per stage of this group's batch
             for i, el, png in zip(group, elems, pngs):
-                results[i] = {"som_image_base64": png, "parsed_content_list": el, "latency": dt}
+                results[i] = {"som_image_base64": png, "parsed_content_list": el, "latency": dt, "stage_ms": stage_ms}
         return {"results": results, "latency": time.time() - start}
 
 

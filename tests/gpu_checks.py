@@ -187,6 +187,57 @@ def check_gemm_dma(seed=0, cases=None, tiles=(None, "256x128", "128x128")):
     return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), t, e) for c, t, e in details]}
 
 
+def check_mlp_fused(seed=0, cases=((300, 128, 0, 128, 0), (128, 128, 0, 128, 0), (517, 192, 48, 160, 16), (33, 128, 0, 128, 0)), inplace=True):
+    """OMNI_OP_MLP_FUSED (csrc/gemm_dma.hip::mlp_fused_kernel, C = 128, hidden = 512): y = res + fc2(GELU(fc1(x))) vs an f64
+    evaluation of the SAME (decoded) operands, and vs the two-launch composition it replaces (fc1 with GELU + format-B output, fc2
+    with the residual) on the same device — ragged row counts, channel slices of wider buffers, output aliasing the residual."""
+    from plan_interp import split_decode
+    g = torch.Generator().manual_seed(seed)
+    C, HID = 128, 512
+    worst, worst_vs_pair = 0.0, 0.0
+    for (M, ild, ioff, old, ooff) in cases:
+        x = torch.randn(M, C, generator=g) * (1.0 if M % 2 else 2.5)
+        w1 = torch.randn(HID, C, generator=g) / math.sqrt(C)
+        b1 = torch.randn(HID, generator=g) * 0.5
+        w2 = torch.randn(C, HID, generator=g) / math.sqrt(HID)
+        b2 = torch.randn(C, generator=g)
+        res = torch.randn(M, C, generator=g)
+        pb = PlanBuilder(DEV, L.F32)
+        xbuf = torch.randn(M, ild); xbuf[:, ioff:ioff + C] = x
+        xv = View(xbuf.clone().view(1, M, 1, ild).to(DEV), ioff, C)
+        pb.split_convert(xv)
+        obuf = torch.full((M, old), 7.0); obuf[:, ooff:ooff + C] = res
+        ov = View(obuf.view(1, M, 1, old).to(DEV), ooff, C)            # output slice initially holds the residual (in-place FFN)
+        rv = ov if inplace else View(res.clone().view(1, M, 1, C).to(DEV), 0, C)
+        w1p, w2p = pb.pack_weight_dma(w1), pb.pack_weight_dma(w2, kperm=True)
+        b1d, b2d = pb.upload(b1), pb.upload(b2)
+        pb.mlp_fused(xv, w1p, b1d, w2p, b2d, rv, ov)
+        # the composition it replaces, on a second output buffer
+        ffn = pb.alloc(1, M, 1, HID)
+        o2 = View(res.clone().view(1, M, 1, C).to(DEV), 0, C)
+        pb.conv(xv, w1p, b1d, ffn, 1, act=L.ACT_GELU, out_split=True)
+        pb.conv(ffn, pb.pack_weight_dma(w2), b2d, o2, 1, res=o2)
+        for op in pb.ops:
+            L.launch(op)
+        _sync()
+        xd = split_decode(xv.t.view(M, ild).cpu()[:, ioff:ioff + C].contiguous()).double()
+        w1d = split_decode(w1p.cpu().view(torch.float32).view(HID, C)).double() * w1p.omni_oscale
+        inv = [PlanBuilder.KPERM16.index(j) for j in range(16)]
+        w2d = split_decode(w2p.cpu().view(torch.float32).view(C, HID)).double().view(C, HID // 16, 16)[:, :, inv].reshape(C, HID) * w2p.omni_oscale
+        assert (w2d - w2.double()).abs().max() <= 2.0 ** -21 * w2.abs().max(), "kperm packing does not decode to the weights"
+        ref = F.gelu(xd @ w1d.t() + b1.double()) @ w2d.t() + b2.double() + res.double()
+        full = ov.t.view(M, old).cpu()
+        got = full[:, ooff:ooff + C].double()
+        mask = torch.ones(old, dtype=torch.bool); mask[ooff:ooff + C] = False
+        assert (full[:, mask] == 7.0).all(), f"mlp_fused wrote outside its channel slice: M={M}"
+        e = rel_err(got, ref)
+        assert e < 3e-6, f"mlp_fused M={M}: rel err {e:.3e} vs f64"
+        e2 = rel_err(got, o2.t.view(M, C).cpu().double())
+        assert e2 < 3e-6, f"mlp_fused M={M}: {e2:.3e} away from the two-launch composition"
+        worst, worst_vs_pair = max(worst, e), max(worst_vs_pair, e2)
+    return {"worst_rel_err": worst, "worst_vs_two_launches": worst_vs_pair, "cases": len(cases)}
+
+
 def check_mfma_layout():
     """A = I-like probe with asymmetric W: catches transposed / permuted MFMA fragment maps."""
     out = {}
@@ -1377,6 +1428,24 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
         if (got - pv).abs().max().item() > 1e-6:        # one u8 step of the resampled pixel is 1.4e-2 .. 1.8e-2 in these units
             problems.append(f"crop tensor differs for frame {f} crop {k} ({crops_g[f][k]}): max abs {(got - pv).abs().max().item():.3e}, "
                             f"{int((got != pv).sum())} of {pv.numel()} values")
+    # ---- the composition bench.py times by default is the PIPELINED one (ScreenParser.parse_stream: detector of batch i+1, two encode
+    #      lanes, decode of batch i on its own stream and decode plan): three batches of the same frames through it must reproduce
+    #      parse_batch's elements, crop rectangles and caption ids — of every crop, not a sample
+    want_ids = [[r.tolist() for r in f] for f in ids]
+    n_stream = 0
+    for el_s, ids_s in sp.parse_stream(iter([(frames, ocr)] * 3), return_ids=True):
+        if sp.last_crops != crops_g:
+            problems.append(f"parse_stream batch {n_stream}: crop rectangles differ from parse_batch")
+        if el_s != elems:
+            problems.append(f"parse_stream batch {n_stream}: elements differ from parse_batch")
+        got_ids = [[r.tolist() for r in f] for f in ids_s]
+        if got_ids != want_ids:
+            nbad = sum(a != b for fa, fb in zip(got_ids, want_ids) for a, b in zip(fa, fb))
+            problems.append(f"parse_stream batch {n_stream}: caption ids differ from parse_batch on {nbad} crops")
+        n_stream += 1
+    out["stream_batches_equal_parse_batch"] = n_stream
+    if n_stream != 3:
+        problems.append(f"parse_stream yielded {n_stream} of 3 batches")
     assert not problems, (problems, out)
     return out
 

@@ -67,6 +67,9 @@ def split_decode(buf: torch.Tensor) -> torch.Tensor:
     return (hl[:, :, 0] + hl[:, :, 1]).reshape(rows, C)
 
 
+KPERM16 = (0, 1, 2, 3, 8, 9, 10, 11, 4, 5, 6, 7, 12, 13, 14, 15)     # OMNI_OP_MLP_FUSED: K order of w2 inside a 16-group (include/omni_amd.h)
+
+
 def _tdt(op):
     return torch.float32 if op.dtype == L.F32 else torch.float16
 
@@ -99,6 +102,17 @@ def run_op(op, m):
             y = y + m.at(p[3], torch.float32)[: M * ldr].view(M, ldr)[:, rcoff:rcoff + Cout]
         out = m.at(p[4], torch.float32)[: M * ldo].view(M, ldo)
         out[:, ocoff:ocoff + Cout] = split_encode(y) if i[21] else y
+    elif k == L.OP_MLP_FUSED:
+        rows, C, ldi, icoff, hid, ldo, ocoff, ldr, rcoff = i[0] * max(i[1], 1), i[3], i[4], i[5], i[12], i[13], i[14], i[16], i[17]
+        x = split_decode(m.at(p[0], torch.float32)[: rows * ldi].view(rows, ldi)[:, icoff:icoff + C])
+        w1 = split_decode(m.at(p[1], torch.float16)[: 2 * hid * C].view(torch.float32).view(hid, C)) * f[1]
+        w2p = split_decode(m.at(p[5], torch.float16)[: 2 * hid * C].view(torch.float32).view(C, hid)) * f[2]
+        inv = [KPERM16.index(j) for j in range(16)]                     # stored position of original channel j inside its 16-group
+        w2 = w2p.view(C, hid // 16, 16)[:, :, inv].reshape(C, hid)
+        h = F.gelu(x @ w1.t() + m.at(p[2], torch.float32)[:hid])
+        h = split_decode(split_encode(h))                               # the kernel hands fc2 the (hi, lo) halves of the activations
+        y = h @ w2.t() + m.at(p[6], torch.float32)[:C] + m.at(p[3], torch.float32)[: rows * ldr].view(rows, ldr)[:, rcoff:rcoff + C]
+        m.at(p[4], torch.float32)[: rows * ldo].view(rows, ldo)[:, ocoff:ocoff + C] = y
     elif k == L.OP_SPLIT_CONVERT:
         rows, C, ldi, icoff, ldo, ocoff = i[0] * max(i[1], 1), i[3], i[4], i[5], i[13], i[14]
         x = m.at(p[0], torch.float32)[: rows * ldi].view(rows, ldi)[:, icoff:icoff + C].clone()

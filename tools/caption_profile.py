@@ -41,6 +41,9 @@ def main():
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 768
     rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
+    flags = sys.argv[4].split(",") if len(sys.argv) > 4 else []     # "nomlp": fc1 / fc2 of the C = 128 stage as two launches
+    if "nomlp" in flags:
+        Florence2Captioner.fuse_mlp = False
     ensure_via_subprocess("caption", seed=0)
     cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
     cap.use_graph = False           # eager plans: every op is timed on its own
