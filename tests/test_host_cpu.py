@@ -27,7 +27,7 @@ def test_library_exports_every_declared_symbol():
 def test_python_enums_mirror_the_header():
     hdr = (ROOT / "include" / "omni_amd.h").read_text()
     ops = dict(re.findall(r"\b(OMNI_OP_[A-Z0-9_]+) = (\d+),", hdr))
-    assert len(ops) == 23 and sorted(map(int, ops.values())) == list(range(1, 24))
+    assert len(ops) == 24 and sorted(map(int, ops.values())) == list(range(1, 25))
     for name, val in ops.items():
         assert getattr(L, name[len("OMNI_"):]) == int(val), name
     assert (L.F32, L.F16, L.ACT_NONE, L.ACT_SILU, L.ACT_GELU) == (0, 1, 0, 1, 2)
