@@ -84,7 +84,7 @@ def main():
     import torch.distributed as dist
     from omniparser_amd import _lib as L
     from omniparser_amd import dist as OD
-    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.synth import BENCH_SEEDS, synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
     from tools.make_weights import caption_dir, default_path, ensure_via_subprocess   # imports nothing from oracle/
 
@@ -107,8 +107,8 @@ def main():
     det = YOLOv9Detector(model_path=blob, device=dev, precision=args.precision)
     note("detector loaded (blob imported and verified against itself)")
     B = args.batch
-    frames = [torch.from_numpy(synthetic_screenshot(s, IW, IH)).to(dev) for s in range(8)]
-    ocr = [synthetic_ocr(s, IW, IH, 40) for s in range(8)]
+    frames = [torch.from_numpy(synthetic_screenshot(s, IW, IH)).to(dev) for s in BENCH_SEEDS]
+    ocr = [synthetic_ocr(s, IW, IH, 40) for s in BENCH_SEEDS]
     n_items = args.steps * B * world
     my_items = OD.shard_indices(args.steps * world, rank, world)      # step-granular round robin
     assert len(my_items) == args.steps
@@ -214,7 +214,7 @@ def main():
         "value": round(value, 4), "unit": "screenshots/s", "n_gpus": world, "steps": args.steps, "warmup": args.warmup,
         "ms_per_step": round(1000.0 * elapsed / args.steps, 3), "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
         "dtype": args.precision,   # activation / accumulate type (f32 = parity mode; its long-K GEMMs use split-f16 MFMA)
-        "data": "synthetic 1920x1080 GUI-like screenshots (8 seeds) + synthetic OCR boxes; seeded random-weight YOLOv9-E blob "
+        "data": "synthetic 1920x1080 GUI-like screenshots (seeds %s) + synthetic OCR boxes; seeded random-weight YOLOv9-E blob " % (list(BENCH_SEEDS),) +
                 "and Florence-2-base-shaped checkpoint",
         "config": {
             "workload": workload, "screenshots_per_step": B,

@@ -18,7 +18,6 @@
 // All softmax / LayerNorm statistics are f32; f16 tensors are converted on load.
 #include "omni_internal.h"
 #include <stdlib.h>
-#include <string.h>
 
 #pragma clang fp contract(off)
 
@@ -828,204 +827,10 @@ __device__ __forceinline__ void split4v(const f32x4& v, uint2& h, uint2& l) {
   split2(v[2], v[3], h.y, l.y);
 }
 
-// PAD = false: H and W are multiples of 12 (every DaViT stage at 768x768 crops) — no window token lies outside the image, so the
-// loads are unconditional and token addresses are 32-bit offsets from one per-window base pointer.  The output tile of a wave goes
-// through a 2.3 KB LDS slice so that a lane stores 8 consecutive channels of one query (two 16-byte stores, or the two 16-byte
-// halves of a format-B group) instead of eight scattered 4-byte (2-byte) stores.
-template <bool PAD>
+// Measured and not kept (profiles/r3_s10_caption_per_op_{default,ab}.txt: 13 % slower on every stage): a variant without padding
+// branches, with 32-bit token offsets and the output tile transposed through LDS for 16-byte stores — the extra LDS round trip and
+// wave synchronisation cost more than the scattered 4-byte stores of this kernel.
 __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
-  constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336, OP = 36;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW + 3 * 16 * OP * 4];
-  unsigned char* Kh = lds;
-  unsigned char* Kl = lds + NKP * KROW;
-  unsigned char* Vh = lds + 2 * NKP * KROW;
-  unsigned char* Vl = Vh + D * VROW;
-  const int g = blockIdx.z, h = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* Qp = (const float*)a.q; const float* Kp = (const float*)a.k; const float* Vp = (const float*)a.v;
-  // window origin (uniform): token row of window-local index i = base + (i / 12) * W + i % 12 unless it falls outside the image
-  const int wpi = a.wy * a.wx;
-  const int b = g / wpi, wrem = g - b * wpi;
-  const int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
-  const int r0 = wyi * 12, c0 = wxi * 12;
-  const long long base_row = ((long long)b * a.H + r0) * a.W + c0;          // token row of the window's first token
-  // token row of window-local index i RELATIVE to base_row (32-bit), or -1 outside the image (PAD only)
-  auto rel_of = [&](int i) -> int {
-    const int dr = i / 12, dc = i - dr * 12;
-    if (PAD && (r0 + dr >= a.H || c0 + dc >= a.W)) return -1;
-    return dr * a.W + dc;
-  };
-  const int qc = lane & 15, grp = lane >> 4;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  Qp += base_row * a.ldq + a.qoff + h * D;
-  Kp += base_row * a.ldk + a.koff + h * D;
-  Vp += base_row * a.ldv + a.voff + h * D;
-  // ---- 1. all global loads of the block
-  f32x4 qraw[3][2];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int rel = rel_of((wave + 3 * t) * 16 + qc);
-    const float* qp = Qp + (rel >= 0 ? rel : 0) * a.ldq + grp * 8;
-    qraw[t][0] = rel >= 0 ? *reinterpret_cast<const f32x4*>(qp) : z4;
-    qraw[t][1] = rel >= 0 ? *reinterpret_cast<const f32x4*>(qp + 4) : z4;
-  }
-  f32x4 kraw[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {                       // item e = (key, 4-channel group): 144 * 8 = 6 * 192
-    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
-    const int rel = rel_of(key);
-    if (rel >= 0) kraw[j] = *reinterpret_cast<const f32x4*>(Kp + rel * a.ldk + d0);
-    else kraw[j] = a.kbias ? f32x4{a.kbias[h * D + d0], a.kbias[h * D + d0 + 1], a.kbias[h * D + d0 + 2], a.kbias[h * D + d0 + 3]} : z4;
-  }
-  f32x4 vraw[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {                       // item e = (key quad, 4-channel group): 36 * 8 = 288 = 192 + 96
-    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
-    if (e < 288) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const int rel = rel_of(kq * 4 + u);
-        if (rel >= 0) vraw[j][u] = *reinterpret_cast<const f32x4*>(Vp + rel * a.ldv + d0);
-        else vraw[j][u] = a.vbias ? f32x4{a.vbias[h * D + d0], a.vbias[h * D + d0 + 1], a.vbias[h * D + d0 + 2], a.vbias[h * D + d0 + 3]} : z4;
-      }
-    }
-  }
-  // ---- 2. LDS image: K rows (hi | lo), V^T rows (hi | lo), keys 144..159 zero
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
-    uint2 kh, kl;
-    split4v(kraw[j], kh, kl);
-    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = kh;
-    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = kl;
-  }
-  if (tid < 128) {                                    // padding keys 144..159: 16 keys x 8 channel groups
-    const int key = 144 + (tid >> 3), d0 = (tid & 7) * 4;
-    const uint2 zh = {0u, 0u};
-    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = zh;
-    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = zh;
-  } else {                                            // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
-    const int r = tid - 128;                          // 0..63: (hi | lo, d)
-    unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(p) = z;
-    *reinterpret_cast<u32x4*>(p + 16) = z;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
-    if (e < 288) {
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
-        uint2 vh, vl;
-        split4v(f32x4{vraw[j][0][dd], vraw[j][1][dd], vraw[j][2][dd], vraw[j][3][dd]}, vh, vl);
-        *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + kq * 8) = vh;
-        *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + kq * 8) = vl;
-      }
-    }
-  }
-  __syncthreads();
-
-  const float inv2048 = 1.0f / 2048.0f;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int qt = wave + 3 * t;
-    u32x4 qhu, qlu;                                   // Q fragment (8 halves each), pre-multiplied by the softmax scale
-    {
-      const f32x4 q0 = qraw[t][0] * a.scale, q1 = qraw[t][1] * a.scale;
-      uint2 h0, l0, h1, l1;
-      split4v(q0, h0, l0);
-      split4v(q1, h1, l1);
-      qhu = u32x4{h0.x, h0.y, h1.x, h1.y};
-      qlu = u32x4{l0.x, l0.y, l1.x, l1.y};
-    }
-    const h16x8 qh = __builtin_bit_cast(h16x8, qhu), ql = __builtin_bit_cast(h16x8, qlu);
-    float sc[40];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 10; ++kt) {
-      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
-      h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
-      h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
-      f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
-      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
-      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
-      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + grp * 4 + r;
-        float sv = __builtin_fmaf(accC[r], inv2048, accM[r]);
-        sv = key < 144 ? sv : -INFINITY;
-        sc[kt * 4 + r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 40; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    f32x4 oM[2], oC[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      uint2 h0, l0, h1, l1;
-      split4v(f32x4{sc[8 * j + 0], sc[8 * j + 1], sc[8 * j + 2], sc[8 * j + 3]}, h0, l0);
-      split4v(f32x4{sc[8 * j + 4], sc[8 * j + 5], sc[8 * j + 6], sc[8 * j + 7]}, h1, l1);
-      const h16x8 ph = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
-      const h16x8 pl = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 32);
-        const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 32);
-        const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
-        const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
-        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
-        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
-        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
-      }
-    }
-    // ---- output: this lane holds O[query 4*grp + r][d = dt*16 + qc]; through the wave's LDS slice a lane gets 8 consecutive
-    //      channels (lane & 3) of query lane >> 2, normalises them and stores 2 x 16 bytes
-    float* ot = reinterpret_cast<float*>(lds + 2 * NKP * KROW + 2 * D * VROW) + wave * 16 * OP;
-#pragma unroll
-    for (int r = 0; r < 4; ++r)
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) ot[(grp * 4 + r) * OP + dt * 16 + qc] = __builtin_fmaf(oC[dt][r], inv2048, oM[dt][r]);
-    OMNI_WAVE_SYNC();
-    const int oq = lane >> 2, c8 = (lane & 3) * 8;
-    const f32x4 o0 = *reinterpret_cast<const f32x4*>(ot + oq * OP + c8), o1 = *reinterpret_cast<const f32x4*>(ot + oq * OP + c8 + 4);
-    const float inv = 1.0f / __shfl(sum, oq);
-    const int orel = rel_of(qt * 16 + oq);
-    if (orel >= 0) {
-      float v0[4] = {o0[0] * inv, o0[1] * inv, o0[2] * inv, o0[3] * inv}, v1[4] = {o1[0] * inv, o1[1] * inv, o1[2] * inv, o1[3] * inv};
-      const long long orow = base_row + orel;
-      const int c = a.ooff + h * D + c8;
-      if (a.osplit) {
-        uint2 h0, l0, h1, l1;
-        omni_split4(v0, h0, l0);
-        omni_split4(v1, h1, l1);
-        unsigned char* p = (unsigned char*)a.o + orow * a.ldo * 4 + omni_split_off(c);
-        *reinterpret_cast<u32x4*>(p) = u32x4{h0.x, h0.y, h1.x, h1.y};
-        *reinterpret_cast<u32x4*>(p + 32) = u32x4{l0.x, l0.y, l1.x, l1.y};
-      } else {
-        float* p = (float*)a.o + orow * a.ldo + c;
-        *reinterpret_cast<f32x4*>(p) = f32x4{v0[0], v0[1], v0[2], v0[3]};
-        *reinterpret_cast<f32x4*>(p + 4) = f32x4{v1[0], v1[1], v1[2], v1[3]};
-      }
-    }
-    OMNI_WAVE_SYNC();                                  // the next query tile overwrites the slice
-  }
-}
-
-
-// [A/B, temporary] the window-attention kernel as of profiles/r3_s3_caption_per_op.txt (scattered 4-byte output stores, 64-bit row
-// addressing): OMNI_AB=win_s3 selects it.
-__global__ __launch_bounds__(192) void window_attn_mfma_f32_s3_kernel(AttnArgs a) {
   constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
   unsigned char* Kh = lds;
@@ -1523,7 +1328,9 @@ __global__ __launch_bounds__(256) void chan_softmax_kernel(ChanArgs a) {
   for (int e = 0; e < 4; ++e) p0[i * 32 + j0 + e] = sa[i][j0 + e];     // A over the chunk-0 partial of this (image, group)
 }
 
-// [A/B, temporary] VALU apply, one token per lane (OMNI_AB=chan_valu)
+// apply: one token per lane, the 32x32 attention matrix of the (image, group) in LDS (broadcast 16-byte reads), 4 output channels per
+// store.  Measured and not kept (profiles/r3_s10_caption_per_op_{default,ab}.txt: 15 % slower): the same product on
+// v_mfma_f32_32x32x2_f32 with v loaded straight into the column operand (16 strided dword loads per 32-token tile).
 __global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
   __shared__ __attribute__((aligned(16))) float sa[32][36];
   const int g = blockIdx.y, b = blockIdx.z;
@@ -1566,54 +1373,6 @@ __global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
   }
 }
 
-// apply on the matrix cores (f32 plans).  A VALU apply kernel (one token per lane) reads the 32x32 attention matrix from LDS as
-// broadcast 16-byte reads — 256 KB of LDS traffic per 64 tokens, which bounds it at ~3 TB/s (measured 2.0: 3.3 % of the step).  Here out^T[i][n] = sum_j A[i][j] v[n][j] is v_mfma_f32_32x32x2_f32 (exact f32
-// products): A is the row operand, held in 16 registers per lane for the whole block; v goes from global memory straight into the
-// column operand (lane = (token lane & 31, j parity lane >> 5), one dword per lane per step: the 16 loads of a 32-token tile walk the
-// same 32 cache lines); a lane ends up with 4 x 4 consecutive output channels of ONE token -> 16-byte stores / format-B halves.
-__global__ __launch_bounds__(256) void chan_apply_mfma_kernel(ChanArgs a) {
-  const int g = blockIdx.y, b = blockIdx.z;
-  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
-  const int col = lane & 31, hsel = lane >> 5;
-  const float* __restrict__ A = a.ws + ((long long)b * a.G + g) * a.chunks * 1024;
-  float ar[16];
-#pragma unroll
-  for (int s = 0; s < 16; ++s) ar[s] = A[col * 32 + 2 * s + hsel];           // row operand: A[i = lane & 31][j = 2s + (lane >> 5)]
-#pragma unroll
-  for (int t = 0; t < 2; ++t) {                                            // a wave serves 64 of the block's 256 tokens
-    const int n0 = blockIdx.x * 256 + wave * 64 + t * 32;
-    if (n0 >= a.N) break;
-    const int n = n0 + col;
-    const bool ok = n < a.N;
-    const float* __restrict__ vrow = (const float*)a.qkv + ((long long)b * a.N + (ok ? n : n0)) * 3 * a.C + 2 * a.C + g * 32 + hsel;
-    float vr[16];
-#pragma unroll
-    for (int s = 0; s < 16; ++s) vr[s] = vrow[2 * s];
-    f32x16 acc;
-#pragma unroll
-    for (int e = 0; e < 16; ++e) acc[e] = 0.0f;
-#pragma unroll
-    for (int s = 0; s < 16; ++s) acc = __builtin_amdgcn_mfma_f32_32x32x2f32(ar[s], vr[s], acc, 0, 0, 0);
-    if (!ok) continue;
-    // D layout: col = token lane & 31, rows i = 8q + 4 * (lane >> 5) + 0..3 for q = 0..3
-    float* orow = (float*)a.o + ((long long)b * a.N + n) * a.C + g * 32;
-    unsigned char* srow = (unsigned char*)a.o + (((long long)b * a.N + n) * a.C) * 4;
-#pragma unroll
-    for (int q = 0; q < 4; ++q) {
-      float s4[4] = {acc[q * 4 + 0], acc[q * 4 + 1], acc[q * 4 + 2], acc[q * 4 + 3]};
-      const int i0 = 8 * q + 4 * hsel;
-      if (a.osplit) {
-        uint2 hi, lo;
-        omni_split4(s4, hi, lo);
-        unsigned char* p = srow + omni_split_off(g * 32 + i0);
-        *reinterpret_cast<uint2*>(p) = hi;
-        *reinterpret_cast<uint2*>(p + 32) = lo;
-      } else {
-        *reinterpret_cast<f32x4*>(orow + i0) = f32x4{s4[0], s4[1], s4[2], s4[3]};
-      }
-    }
-  }
-}
 
 // ------------------------------------------------------------------------------------ small glue kernels
 struct PrepArgs { const void* x; const float* pos; const float* temporal; void* y; int B, N, C; };
@@ -2062,10 +1821,7 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
   if (a.mode == 1 && D == 32) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { const char* ab = getenv("OMNI_AB");     // [A/B, temporary]
-            if (ab && strstr(ab, "win_s3")) hipLaunchKernelGGL(window_attn_mfma_f32_s3_kernel, grid, dim3(192), 0, s, a);
-            else if (a.H % 12 == 0 && a.W % 12 == 0) hipLaunchKernelGGL(window_attn_mfma_f32_kernel<false>, grid, dim3(192), 0, s, a);
-            else hipLaunchKernelGGL(window_attn_mfma_f32_kernel<true>, grid, dim3(192), 0, s, a); },
+      [&] { hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
   } else if (a.mode == 0 && D == 64) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
@@ -2099,9 +1855,7 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   if (op->dtype == OMNI_F32 && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
     hipLaunchKernelGGL(chan_scores_mfma_kernel, g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(chan_softmax_kernel, dim3(a.G, a.B), dim3(256), 0, s, a);
-    { const char* ab = getenv("OMNI_AB");            // [A/B, temporary]
-      if (ab && strstr(ab, "chan_valu")) hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
-      else hipLaunchKernelGGL(chan_apply_mfma_kernel, g2, dim3(256), 0, s, a); }
+    hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
     OMNI_HIP_CHECK(hipGetLastError());
     return OMNI_OK;
   }
