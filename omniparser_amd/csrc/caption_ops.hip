@@ -1608,6 +1608,9 @@ __global__ __launch_bounds__(256) void greedy_step_kernel(GreedyArgs a) {
       __syncthreads();
     }
     tok = sidx[0];
+    // no logit compared greater than -inf: every entry is NaN or -inf (a row nobody asked for, computed from padding, or a diverged
+    // input).  torch.argmax returns position 0 then; never hand an out-of-range id to the next step's embedding gather
+    if (tok < 0 || tok >= a.V) tok = 0;
   }
   if (threadIdx.x == 0) {
     int fin = a.finished[b];

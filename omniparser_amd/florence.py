@@ -222,7 +222,9 @@ class _DecodePlans(_StepPlans):
         S = (R // 32) ** 2 + 1 + len(PROMPT_IDS)
         self.S = S
         pk = PlanBuilder(dev, dt)
-        self.cross_kv = [pk.alloc(B, S, 1, 2 * w.d_model) for _ in range(w.dec_layers)]
+        # zero-initialised: the rows behind the last crop are never written (the micro-batches copy their own rows only) but ARE decoded;
+        # recycled allocator memory there can hold NaN bit patterns, whose logits are all-NaN rows (found by the one-process GPU suite)
+        self.cross_kv = [pk.alloc(B, S, 1, 2 * w.d_model, zero=True) for _ in range(w.dec_layers)]
         self._keep = pk.keep
         self._build_step(cap, B, max_new, S, self.cross_kv)
         self.free_evt = None       # recorded behind the decode that last used this plan on another stream (pipelined batches)

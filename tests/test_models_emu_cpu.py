@@ -211,6 +211,17 @@ def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
     frame = torch.from_numpy(synthetic_screenshot(3, 640, 480))
     rects = [[[10, 20, 60, 70], [300, 200, 340, 260], [500, 100, 620, 140]], [[40, 40, 90, 80], [200, 300, 280, 360]]]
     got = {}
+    # the decode plan has 8 rows for 5 crops: its rows 5..7 are decoded although nobody reads them.  Poison them (and nothing else) with
+    # NaN, as recycled allocator memory can: all-NaN logits must not turn into an out-of-range token id for the next embedding gather
+    # (the one-process GPU suite of round 3 died on exactly that), and rows 0..4 must not notice
+    real_plans = cap.decode_plans
+
+    def poisoned(*a, **k):
+        dec = real_plans(*a, **k)
+        for kv in dec.cross_kv:
+            kv.t[5:] = float("nan")
+        return dec
+    monkeypatch.setattr(cap, "decode_plans", poisoned)
     for mode in ("1", "0"):
         monkeypatch.setenv("OMNI_MERGED_DECODE", mode)
         sp = ScreenParser(None, cap, batch_size=2)
@@ -218,6 +229,8 @@ def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
         out = sp.caption([frame, frame], rects)
         got[mode] = [[row.tolist() for _, row in f] for f in out]
     assert any(k[0] == "dec" for k in cap._plans)                                          # the merged path ran
+    dec = next(v for k, v in cap._plans.items() if k[0] == "dec")
+    assert int(dec.ids.min()) >= 0 and int(dec.ids.max()) < cap.w.vocab, "a padding row produced an out-of-range token id"
     assert [len(f) for f in got["1"]] == [3, 2]
     strip = lambda rows: [[t for t in r if t != cap.w.pad] for r in rows]
     assert [strip(f) for f in got["1"]] == [strip(f) for f in got["0"]]
