@@ -1,4 +1,4 @@
-"""Time the window-attention op at the DaViT stage shapes (HIP events).  OMNI_ATTN_MFMA=0/1 selects the kernel."""
+"""Time the window-attention op at the DaViT stage shapes (HIP events)."""
 import os
 import sys
 from pathlib import Path
