@@ -208,6 +208,8 @@ def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
     from tools.make_weights import ensure_caption_checkpoint
     cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     monkeypatch.setattr(Florence2Captioner, "decode_bucket", staticmethod(lambda n: 8))       # a 128-row lm_head step costs the emulation minutes
+    import omniparser_amd.florence as FL
+    monkeypatch.setattr(FL, "_BUCKETS", (2, 128))                                            # 2-row encode plans for the 2-crop micro-batches
     frame = torch.from_numpy(synthetic_screenshot(3, 640, 480))
     rects = [[[10, 20, 60, 70], [300, 200, 340, 260], [500, 100, 620, 140]], [[40, 40, 90, 80], [200, 300, 280, 360]]]
     got = {}
