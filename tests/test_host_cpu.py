@@ -286,3 +286,35 @@ def test_erf_polynomial():
     err = np.abs(got - ref)
     assert err.max() < 6.5e-8
     assert (err / np.spacing(np.abs(ref).astype(np.float32)).astype(np.float64)).max() < 1.0
+
+
+def test_pmc_tools_on_a_synthetic_trace(tmp_path):
+    """tools/pmc_summary.py + tools/pmc_traffic.py (how profiles/r3_pmc_traffic.json is made): FETCH_SIZE doubled and KiB -> bytes,
+    kernels reduced to families, GEMM-family bytes per crop and per launch, fetch / write ratio of a streaming kernel."""
+    import csv
+    import json
+    import subprocess
+    import sys
+    from pathlib import Path
+    root = Path(__file__).resolve().parents[1]
+    rows = [("void (anonymous namespace)::gemm_dma_kernel<256, 256, 2, 4, 2, 0, false, true, 1>((anonymous namespace)::GemmArgs)", 1000.0, 500.0),
+            ("void (anonymous namespace)::dwln_strip_kernel<2, 64, true>((anonymous namespace)::DwLnArgs, int, int, int, unsigned int)", 250.0, 1000.0)]
+    for ctr, col in (("FETCH_SIZE", 1), ("WRITE_SIZE", 2)):
+        d = tmp_path / ctr / "run"
+        d.mkdir(parents=True)
+        with open(d / "1_counter_collection.csv", "w", newline="") as fh:
+            w = csv.writer(fh)
+            w.writerow(["Kernel_Name", "Counter_Name", "Counter_Value", "Start_Timestamp", "End_Timestamp"])
+            for r in rows:
+                for launch in range(4):
+                    w.writerow([r[0], ctr, r[col], 1000 * launch, 1000 * launch + 500])
+        out = subprocess.run([sys.executable, str(root / "tools" / "pmc_summary.py"), str(tmp_path / ctr)], capture_output=True, text=True, check=True)
+        (tmp_path / f"{ctr}.json").write_text(out.stdout)
+    out = subprocess.run([sys.executable, str(root / "tools" / "pmc_traffic.py"), str(tmp_path / "FETCH_SIZE.json"), str(tmp_path / "WRITE_SIZE.json"),
+                          "8", "1000000"], capture_output=True, text=True, check=True)
+    t = json.loads(out.stdout)
+    assert t["gemm_launches"] == 4
+    assert t["gemm_fetch_bytes"] == 4 * 1000.0 * 2 * 1024 and t["gemm_write_bytes"] == 4 * 500.0 * 1024
+    assert t["gemm_fetch_bytes_per_crop"] == round(4 * 1000.0 * 2048 / 8) and t["gemm_bytes_per_launch"] == round((1000.0 * 2048 + 500.0 * 1024))
+    strip = next(v for k, v in t["families"].items() if k.startswith("dwln_strip_kernel"))
+    assert strip["fetch_over_write"] == 0.5 and strip["launches"] == 4
