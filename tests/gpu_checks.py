@@ -912,6 +912,28 @@ def check_caption_ops(dtype=L.F32, seed=0):
     return res
 
 
+def check_greedy_degenerate_rows():
+    """OMNI_OP_GREEDY_STEP on rows whose logits are all NaN or all -inf (padding rows of a decode plan fed recycled memory, a diverged
+    input): the emitted id must be a valid vocabulary index — 0, what torch.argmax returns for such a row — never the arg-max search's
+    initial value, which the next step's embedding gather would read out of range (the crash of the first closing GPU suite of round 3)."""
+    Bq, Vv, T = 4, 1000, 21
+    logits = torch.randn(Bq, Vv)
+    logits[1] = float("nan")
+    logits[2] = float("-inf")
+    ids = torch.zeros(Bq, T, dtype=torch.int32); ids[:, 0] = 2
+    ids[:, 1:6] = torch.tensor([[0, 7, 8, 7, 9]] * Bq, dtype=torch.int32)
+    d = {"logits": logits.to(DEV), "ids": ids.to(DEV), "fin": torch.zeros(Bq, dtype=torch.int32, device=DEV),
+         "step": torch.tensor([5], dtype=torch.int32, device=DEV)}
+    L.launch(L.make_op(L.OP_GREEDY_STEP, L.F32, p=[d["logits"].data_ptr(), None, d["ids"].data_ptr(), d["fin"].data_ptr(), None, None,
+                                                 d["step"].data_ptr()],
+                       i={0: Bq, 1: Vv, 2: Vv, 3: T, 4: 20, 5: 0, 6: 0, 7: 2, 8: 1, 9: -1, 10: -1, 11: 1}))
+    _sync()
+    got = d["ids"].cpu()[:, 6].tolist()
+    want = [int(torch.argmax(logits[0])), 0, 0, int(torch.argmax(logits[3]))]
+    assert got == want, (got, want)
+    return {"ids": got}
+
+
 def logit_margins(model, cap, cp, pix, ids_ref, max_new):
     """How close is the HIP path to flipping an arg-max?  Per decoding step: the CPU model's top-1/top-2 margin of the raw
     logits (free steps only: not the forced BOS / EOS steps, not finished rows) and the GPU-vs-CPU logit difference."""

@@ -54,6 +54,11 @@ def test_gemm_dma_presplit_every_tile(emu):
     assert r["cases"] == 3 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
 
 
+def test_greedy_step_never_emits_an_out_of_range_id(emu):
+    import gpu_checks as G
+    G.check_greedy_degenerate_rows()
+
+
 def test_mlp_fused_vs_f64_and_vs_two_launches(emu):
     import gpu_checks as G
     r = G.check_mlp_fused(cases=((140, 128, 0, 128, 0), (65, 192, 48, 160, 16)))
