@@ -44,6 +44,12 @@ def test_mlp_fused():
     assert r["worst_vs_two_launches"] < 3e-6
 
 
+def test_greedy_step_degenerate_rows():
+    """all-NaN / all -inf logit rows (padding rows fed recycled memory, a diverged input) yield token 0, never an out-of-range id."""
+    import gpu_checks as G
+    G.check_greedy_degenerate_rows()
+
+
 @pytest.mark.parametrize("dtype", [L.F32, L.F16])
 def test_pool_and_resize(dtype):
     import gpu_checks as G
