@@ -235,6 +235,7 @@ def main():
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
+        out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
         if args.pipeline:
             out["config"]["pipeline"] = ("parse_stream: detector + hand-off graph of step i+1 on the detector's stream, caption micro-batches alternating "
                                          "over %d encode stream(s), the 20 decode steps of step i on their own stream (two decode plans)" % args.lanes)

@@ -4,16 +4,14 @@ There is NO CPU fallback: if the shared object is missing, cannot be built, or d
 symbol the header declares, importing the product path fails loudly.
 """
 import ctypes
-import os
 from ctypes import c_char_p, c_float, c_int, c_int32, c_void_p, POINTER, Structure
 
 from . import build as _build
 
-# The pipelined stream (pipeline.py::parse_stream) keeps five HIP streams busy (detector, two encode lanes, decode, torch's own); the
-# runtime maps streams onto 4 hardware queues by default, and two streams that share a queue serialise.  Read by the HIP runtime when
-# it initialises, i.e. effective when this module is imported before the first CUDA call (bench.py, the server and the tests do);
-# an explicit setting of the user wins.  Measured: 694 vs 701 ms per bench step (profiles/r3_s10_bench_pipelined_*.json).
-os.environ.setdefault("GPU_MAX_HW_QUEUES", "8")
+# GPU_MAX_HW_QUEUES is deliberately left at the HIP runtime's default (4 hardware queues).  With 8, the two-lane pipelined stream
+# (pipeline.py::parse_stream) measured +1 % (694 vs 701 ms per bench step), but one encode lane next to the decode stream measured 1034
+# instead of 709 ms — which streams end up sharing a hardware pipe depends on the order in which every stream of the process was created
+# (RCCL's included), so the faster setting has a cliff next to it that a multi-GPU run could land on (profiles/r3_probe_*.json, DESIGN §5).
 
 # op kinds / enums (mirror include/omni_amd.h)
 F32, F16 = 0, 1
