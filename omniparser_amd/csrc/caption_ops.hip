@@ -995,6 +995,220 @@ __global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
   }
 }
 
+// split2 with the remainder as one mixed-precision fma per value (v_fma_mix_f32 reads the f16 hi half directly: no v_cvt_f32_f16, no
+// subtraction): 2048 (x - hi) = fma(hi, -2048, 2048 x), exact like the form above (2048 x is exact, x - hi has <= 13 significant bits)
+__device__ __forceinline__ void split2m(float a, float b, unsigned& h, unsigned& l) {
+  typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
+  const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
+  const f32x2 s = f32x2{a, b} * 2048.0f;
+  const hv2 ll = __builtin_amdgcn_cvt_pkrtz(__builtin_fmaf((float)hh[0], -2048.0f, s[0]), __builtin_fmaf((float)hh[1], -2048.0f, s[1]));
+  h = __builtin_bit_cast(unsigned, hh);
+  l = __builtin_bit_cast(unsigned, ll);
+}
+__device__ __forceinline__ void split4m(const f32x4& v, uint2& h, uint2& l) {
+  split2m(v[0], v[1], h.x, l.x);
+  split2m(v[2], v[3], h.y, l.y);
+}
+
+// Candidate successor of window_attn_mfma_f32_kernel (op->i[17] = 1; written after the last GPU session of round 3: verified on the
+// host emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above issues 2 319 VALU instructions
+// per wave for 171 MFMAs (profiles/r3_static_isa_report.txt): it is bound by its vector ALU, not by HBM (2.1-2.3 TB/s) or the matrix
+// pipe.  Same LDS image, same split-f16 x3 arithmetic, same blocks; what changes is where the VALU instructions went:
+//   * token addressing: ~30 calls of row_of() per thread (two divisions by 12, a 64-bit row index, a 64-bit multiply by the row
+//     pitch each).  Here the window origin is ONE uniform 64-bit pointer per tensor and every token of the window is a 32-bit element
+//     offset from it; the divisions by 12 are done once per thread (a thread's K items are 24 keys = 2 window rows apart, its V
+//     items 8 rows, its Q tiles 4 rows);
+//   * P V: the MFMA takes V^T as the ROW operand and P as the column operand (the per-lane register contents are the same, only the
+//     roles swap), so the accumulator holds O^T — each lane owns ONE query and 4 consecutive channels: no __shfl of the row sum, one
+//     output row address per tile, 16-byte f32 stores / 8-byte hi and lo stores instead of sixteen 2- or 4-byte stores per tile;
+//   * scores: the 10th key tile (keys 144..159) is padding for every window — not computed; log2(e) is folded into the Q scale so an
+//     exponential is v_sub + v_exp; merges, maxima and sums are written on pairs (packed f32 instructions).
+// Results agree with the kernel above to f32 rounding (the exponentials see scores scaled before the split instead of after).
+__global__ __launch_bounds__(192, 2) void window_attn_mfma_f32_v2_kernel(AttnArgs a) {
+  constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
+  unsigned char* Kh = lds;
+  unsigned char* Kl = lds + NKP * KROW;
+  unsigned char* Vh = lds + 2 * NKP * KROW;
+  unsigned char* Vl = Vh + D * VROW;
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  // window origin (uniform).  Token (wr, wc) of the window, 0 <= wr, wc < 12, lies wr * W + wc rows behind it and exists iff
+  // wr < rows_left and wc < cols_left (windows of the last row / column of a padded image are cut)
+  const int wpi = a.wy * a.wx;
+  const int b = g / wpi, wrem = g - b * wpi;
+  const int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
+  const int r0 = wyi * 12, c0 = wxi * 12;
+  const int rows_left = a.H - r0, cols_left = a.W - c0;
+  const long long row00 = ((long long)b * a.H + r0) * a.W + c0;
+  const float* Qb = (const float*)a.q + row00 * a.ldq + a.qoff + h * D;
+  const float* Kb = (const float*)a.k + row00 * a.ldk + a.koff + h * D;
+  const float* Vb = (const float*)a.v + row00 * a.ldv + a.voff + h * D;
+  const int qc = lane & 15, grp = lane >> 4;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  // ---- 1. all global loads of the block
+  // Q: tile t of this wave holds window tokens 16 * (wave + 3 t) + qc = iq0 + 48 t: 4 t window rows below token iq0
+  const int iq0 = 16 * wave + qc;
+  const int qwr = iq0 / 12, qwc = iq0 - 12 * qwr;
+  const int qtok = qwr * a.W + qwc;
+  f32x4 qraw[3][2];
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    const bool ok = qwr + 4 * t < rows_left && qwc < cols_left;
+    const float* qp = Qb + (ok ? (qtok + 4 * t * a.W) * a.ldq : 0) + grp * 8;
+    qraw[t][0] = ok ? *reinterpret_cast<const f32x4*>(qp) : z4;
+    qraw[t][1] = ok ? *reinterpret_cast<const f32x4*>(qp + 4) : z4;
+  }
+  // K: item e = tid + 192 j = (key, 4-channel group) with key = t8 + 24 j: 2 j window rows below key t8
+  const int t8 = tid >> 3, d0 = (tid & 7) * 4;
+  const int kwr = t8 >= 12 ? 1 : 0, kwc = t8 - 12 * kwr;
+  const int ktok = kwr * a.W + kwc;
+  f32x4 kpad = z4, vpad = z4;
+  if (a.kbias) kpad = *reinterpret_cast<const f32x4*>(a.kbias + h * D + d0);
+  if (a.vbias) vpad = *reinterpret_cast<const f32x4*>(a.vbias + h * D + d0);
+  f32x4 kraw[6];
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const bool ok = kwr + 2 * j < rows_left && kwc < cols_left;
+    kraw[j] = ok ? *reinterpret_cast<const f32x4*>(Kb + (ktok + 2 * j * a.W) * a.ldk + d0) : kpad;
+  }
+  // V: item e = tid + 192 j = (key quad kq = t8 + 24 j, 4-channel group): keys 4 kq + u = window row t8 / 3 + 8 j, columns 4 (t8 % 3) + u
+  const int vwr = t8 / 3, vwc = 4 * (t8 - 3 * vwr);
+  const int vtok = vwr * a.W + vwc;
+  f32x4 vraw[2][4];
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    if (j == 0 || tid < 96) {
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        const bool ok = vwr + 8 * j < rows_left && vwc + u < cols_left;
+        vraw[j][u] = ok ? *reinterpret_cast<const f32x4*>(Vb + (vtok + 8 * j * a.W + u) * a.ldv + d0) : vpad;
+      }
+    }
+  }
+  // ---- 2. LDS image: K rows (hi | lo), V^T rows (hi | lo), keys 144..159 zero (identical to the kernel above)
+#pragma unroll
+  for (int j = 0; j < 6; ++j) {
+    const int key = t8 + 24 * j;
+    uint2 kh, kl;
+    split4m(kraw[j], kh, kl);
+    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = kh;
+    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = kl;
+  }
+  if (tid >= 128) {                                   // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
+    const int r = tid - 128;                          // (the K rows 144..159 are never read: the 10th score tile is not computed)
+    unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
+    const u32x4 z = {0u, 0u, 0u, 0u};
+    *reinterpret_cast<u32x4*>(p) = z;
+    *reinterpret_cast<u32x4*>(p + 16) = z;
+  }
+#pragma unroll
+  for (int j = 0; j < 2; ++j) {
+    const int kq = t8 + 24 * j;
+    if (j == 0 || tid < 96) {
+#pragma unroll
+      for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
+        uint2 vh, vl;
+        split4m(f32x4{vraw[j][0][dd], vraw[j][1][dd], vraw[j][2][dd], vraw[j][3][dd]}, vh, vl);
+        *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + kq * 8) = vh;
+        *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + kq * 8) = vl;
+      }
+    }
+  }
+  __syncthreads();
+
+  const float inv2048 = 1.0f / 2048.0f;
+  const float qscale = a.scale * 1.4426950408889634f;  // scores in units of log2: exp(s - m) = exp2(s' - m')
+  unsigned char* const Ob = (unsigned char*)a.o + (row00 * a.ldo + a.ooff + h * D) * 4;   // a split row has the f32 row's pitch
+#pragma unroll
+  for (int t = 0; t < 3; ++t) {
+    u32x4 qhu, qlu;                                   // Q fragment (8 halves each), pre-multiplied by the softmax scale
+    {
+      const f32x4 q0 = qraw[t][0] * qscale, q1 = qraw[t][1] * qscale;
+      uint2 h0, l0, h1, l1;
+      split4m(q0, h0, l0);
+      split4m(q1, h1, l1);
+      qhu = u32x4{h0.x, h0.y, h1.x, h1.y};
+      qlu = u32x4{l0.x, l0.y, l1.x, l1.y};
+    }
+    const h16x8 qh = __builtin_bit_cast(h16x8, qhu), ql = __builtin_bit_cast(h16x8, qlu);
+    f32x2 sc[18];                                     // scores of query qc against keys 16 kt + 4 grp + {0..3}, kt = 0..8
+    float mx = -INFINITY;
+#pragma unroll
+    for (int kt = 0; kt < 9; ++kt) {
+      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
+      const h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+      const h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
+      f32x4 accM = z4, accC = z4;
+      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
+      sc[2 * kt] = f32x2{accC[0], accC[1]} * inv2048 + f32x2{accM[0], accM[1]};
+      sc[2 * kt + 1] = f32x2{accC[2], accC[3]} * inv2048 + f32x2{accM[2], accM[3]};
+      mx = fmaxf(fmaxf(mx, sc[2 * kt][0]), sc[2 * kt][1]);           // v_max3_f32
+      mx = fmaxf(fmaxf(mx, sc[2 * kt + 1][0]), sc[2 * kt + 1][1]);
+    }
+    mx = fmaxf(mx, __shfl_xor(mx, 16));
+    mx = fmaxf(mx, __shfl_xor(mx, 32));
+    f32x2 sum2 = {0.f, 0.f};
+#pragma unroll
+    for (int e = 0; e < 18; ++e) {
+      const f32x2 d = sc[e] - mx;
+      sc[e] = f32x2{__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+      sum2 += sc[e];
+    }
+    float sum = sum2[0] + sum2[1];
+    sum += __shfl_xor(sum, 16);
+    sum += __shfl_xor(sum, 32);                       // row sum of query qc, in every lane that holds a part of it
+    f32x4 oM[2], oC[2];
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
+#pragma unroll
+    for (int j = 0; j < 5; ++j) {
+      unsigned h0, l0, h1, l1, h2 = 0u, l2 = 0u, h3 = 0u, l3 = 0u;
+      split2m(sc[4 * j][0], sc[4 * j][1], h0, l0);
+      split2m(sc[4 * j + 1][0], sc[4 * j + 1][1], h1, l1);
+      if (j < 4) {                                    // j = 4: slots 4..7 are keys 144..159 (padding): P = 0
+        split2m(sc[4 * j + 2][0], sc[4 * j + 2][1], h2, l2);
+        split2m(sc[4 * j + 3][0], sc[4 * j + 3][1], h3, l3);
+      }
+      const h16x8 ph = __builtin_bit_cast(h16x8, u32x4{h0, h1, h2, h3});
+      const h16x8 pl = __builtin_bit_cast(h16x8, u32x4{l0, l1, l2, l3});
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
+        const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 32);
+        const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 32);
+        const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+        const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
+        // O^T[channel dt * 16 + 4 grp + r][query qc]: V^T is the row operand
+        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, ph, oM[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vl, ph, oC[dt], 0, 0, 0);
+        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(vh, pl, oC[dt], 0, 0, 0);
+      }
+    }
+    // ---- normalise and store: this lane holds channels dt * 16 + 4 grp + 0..3 of query qc
+    if (qwr + 4 * t < rows_left && qwc < cols_left) {
+      const float inv = 1.0f / sum;
+      unsigned char* orow = Ob + (long long)(qtok + 4 * t * a.W) * a.ldo * 4;
+#pragma unroll
+      for (int dt = 0; dt < 2; ++dt) {
+        const f32x4 o = (oC[dt] * inv2048 + oM[dt]) * inv;
+        const int c = dt * 16 + 4 * grp;
+        if (a.osplit) {
+          const float v[4] = {o[0], o[1], o[2], o[3]};
+          uint2 hi, lo;
+          omni_split4(v, hi, lo);
+          *reinterpret_cast<uint2*>(orow + omni_split_off(c)) = hi;
+          *reinterpret_cast<uint2*>(orow + omni_split_off(c) + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(orow + c * 4) = o;
+        }
+      }
+    }
+  }
+}
+
 // ------------------------------------------------------------------------------------ plain MHA on MFMA (BART encoder)
 // softmax(q k^T * scale) v for head_dim 64 and any key count (hf:models/bart/modeling_bart.py:143-257), flash-style:
 // keys are walked in blocks of 32 with an online softmax; both contractions use split-f16 MFMA exactly as in
@@ -1823,8 +2037,12 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(!a.osplit || (a.mode == 1 && D == 32) || (a.mode == 0 && D == 64), "attn_rows: split output exists on the MFMA kernels only");
   if (a.mode == 1 && D == 32) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
+    // op->i[17] = 1: the candidate kernel (vectorised rows: needs 4-element aligned row pitches and channel offsets)
+    const bool v2 = op->i[17] == 1 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 &&
+                    a.qoff % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0 && a.ooff % 4 == 0;
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a); },
+      [&] { if (v2) hipLaunchKernelGGL(window_attn_mfma_f32_v2_kernel, grid, dim3(192), 0, s, a);
+            else hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
   } else if (a.mode == 0 && D == 64) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);

@@ -399,7 +399,8 @@ class _CaptionPlans(_StepPlans):
                             L.OP_ATTN_ROWS, dt,
                             p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr, qb.data_ptr() + 4 * C, qb.data_ptr() + 8 * C],
                             i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
-                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if (attn_split and grp["dma"]) else 0},
+                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if (attn_split and grp["dma"]) else 0,
+                               17: 1 if (cap.window_attn_v2 and dt == L.F32) else 0},
                             f={0: (C // w.heads[s]) ** -0.5}))
                         att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "window_attn.proj", att, B_, res=B_)
@@ -524,6 +525,10 @@ class Florence2Captioner:
     # plan composition switches (class attributes: the tests build the round-2 composition by overriding them)
     fuse_dwln = True          # x + dwconv(x) -> LayerNorm as one strip kernel (DaViT stages 0-2)
     attn_split_out = True     # attention kernels write format B for the projection GEMM themselves
+    window_attn_v2 = False    # CANDIDATE, not timed on the MI355X yet (written after round 3's last GPU minute): the f32 window-attention
+                              # kernel with 32-bit window-relative addressing, O^T accumulators (vector stores, no shuffles) and mixed-precision
+                              # fma splits — 1 490 instead of 2 841 VALU instructions per wave (csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel);
+                              # emulated checks green incl. cut windows; A/B: tools/r4_open.sh
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):

@@ -289,6 +289,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 template <class A, class B> inline auto min(A a, B b) { using T = std::common_type_t<A, B>; return (T)a < (T)b ? (T)a : (T)b; }
 template <class A, class B> inline auto max(A a, B b) { using T = std::common_type_t<A, B>; return (T)a > (T)b ? (T)a : (T)b; }
 inline float __expf(float x) { return expf(x); }
+#define __builtin_amdgcn_exp2f(x) exp2f(x)
 inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }

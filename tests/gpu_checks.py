@@ -741,7 +741,7 @@ def _cmp(a, b, tol, what):
     return e
 
 
-def check_caption_ops(dtype=L.F32, seed=0):
+def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,)):
     g = torch.Generator().manual_seed(seed)
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     tol = 2e-5 if dtype == L.F32 else 5e-3
@@ -794,26 +794,29 @@ def check_caption_ops(dtype=L.F32, seed=0):
                                             i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
                                                11: Bq, 12: 0, 15: D}, f={0: D ** -0.5}))
     res["attn_plain"] = _cmp(gq["o"], c["o"], tol * 5, "attn_rows plain")
-    for (Hh, heads, D) in ((16, 4, 32), (24, 4, 32), (2, 8, 32)):
-        Cm = heads * D
-        Bq = 2
-        nw = ((Hh + 11) // 12) ** 2
-        t = {"qkv": R(Bq * Hh * Hh, 3 * Cm).to(tdt), "bias": R(3 * Cm), "o": torch.zeros(Bq * Hh * Hh, Cm, dtype=tdt)}
-        c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_ROWS, dtype,
-                                                p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
-                                                i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
-                                                   11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D}, f={0: D ** -0.5}))
-        res[f"attn_window_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh}")
-        if dtype == L.F32:
-            # the f32 window-attention kernel's format-B output
+    # window_variants: 0 = the shipped f32 window kernel, 1 = its candidate successor (op i[17]; f32 plans only).  12 = no padding
+    # (every real stage at 768x768), 16 / 24 / 2 = cut windows, 13 = one row / column of a second window
+    for variant in (window_variants if dtype == L.F32 else (0,)):
+        tag = "" if variant == 0 else f"_v{variant + 1}"
+        for (Hh, heads, D) in ((16, 4, 32), (24, 4, 32), (2, 8, 32)) + (((12, 2, 32), (13, 1, 32)) if variant else ()):
+            Cm = heads * D
+            Bq = 2
+            nw = ((Hh + 11) // 12) ** 2
+            t = {"qkv": R(Bq * Hh * Hh, 3 * Cm).to(tdt), "bias": R(3 * Cm), "o": torch.zeros(Bq * Hh * Hh, Cm, dtype=tdt)}
             mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype,
                                              p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
                                              i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
-                                                11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D, 16: osplit}, f={0: D ** -0.5})
-            if Cm % 16 == 0:
+                                                11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D, 16: osplit, 17: variant}, f={0: D ** -0.5})
+            c, gq = _op_pair(t, lambda P: mk(P, 0))
+            res[f"attn_window{tag}_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh} variant {variant}")
+            if dtype == L.F32 and Cm % 16 == 0:
+                # the f32 window-attention kernel's format-B output
                 cs, gs = _op_pair(t, lambda P: mk(P, 1))
                 assert torch.equal(gs["o"].view(torch.uint8), cs["o"].view(torch.uint8)) or \
-                    _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"window attention split out H={Hh}") is not None
+                    _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"window attention split out H={Hh} variant {variant}") is not None
+                if variant:
+                    # the candidate's two output formats hold the same numbers: format B is the split of the f32 rows, bit for bit
+                    assert torch.equal(split_decode(gs["o"]), gq["o"]) or (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
     # channel attention
     Bq, N, G = 2, 2500, 4
     Cm = G * 32
