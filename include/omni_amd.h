@@ -121,7 +121,8 @@ enum {
    *  i17 = 1 (f32 plans, mode 1, head_dim 32): the candidate window kernel (window-relative 32-bit addressing, O^T accumulators) */
   OMNI_OP_ATTN_ROWS = 10,
   /* DaViT grouped channel attention (florence2 :223-259): p0 qkv [B*N,3C] p4 o [B*N,C] p5 ws f32[B*G*chunks*1024]
-   *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5) */
+   *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5)
+   *  i7 = 1 (f32 plans): the candidate apply kernel (split-f16 MFMA instead of f32 VALU) */
   OMNI_OP_CHAN_ATTN = 11,
   /* projector input (florence2 :568-590): y[b] = [mean_n(x+pos+t) ; x+pos+t]; p0 x [B,N,C] p1 pos2d f32[N,C] p2 temporal f32[C] p4 y [B,N+1,C]
    *  i0 B i1 N i3 C */

@@ -1588,6 +1588,89 @@ __global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
 }
 
 
+// Candidate successor of chan_apply_v4_kernel (op->i[7] = 1; written after the last GPU session of round 3: verified on the host
+// emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above spends 1 024 v_fma_f32 and 256
+// broadcast ds_read_b128 per wave for 64 tokens: ~4 100 VALU cycles and as many LDS cycles per 16 KB of HBM traffic — it is bound by
+// its vector ALU and the LDS pipe (2.0-2.5 TB/s measured), not by HBM.  The f32 MFMA variant measured in round 3 (32x32x2: 16 x 64
+// cycles per 32-token tile, dword column loads) was slower still.  Here the product runs on the f16 matrix pipe with the split-f16 x3
+// arithmetic of the attention kernels (hi * hi into one accumulator, hi * lo' + lo' * hi into a second, lo' = 2048 lo):
+//   out^T[i][n] = sum_j A[i][j] v[n][j]:  the (image, group)'s 32x32 matrix is the ROW operand — split ONCE per wave into four
+//   fragment registers sets; the token tile is the column operand — lane (n, kg) loads 2 x 32 contiguous bytes of token n's row
+//   (16-byte loads, every byte used once) and splits its 16 values in registers; 6 MFMAs (32x32x16) per 32 tokens; the accumulator
+//   quad q of a lane is 4 consecutive channels 8 q + 4 kg of ONE token: 16-byte f32 stores / 8-byte hi and lo stores.
+// ~130 VALU instructions and 192 MFMA cycles per 32 tokens instead of 2 048 + 2 048 cycles: the kernel becomes a streaming one.
+__global__ __launch_bounds__(256, 2) void chan_apply_mfma_split_kernel(ChanArgs a) {
+  const int g = blockIdx.y, b = blockIdx.z;
+  const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  const float inv2048 = 1.0f / 2048.0f;
+  // ---- all loads first: the wave's two 32-token tiles (rows clamped to the last token: tail tiles), then the matrix
+  const int n00 = blockIdx.x * 256 + wave * 64;
+  if (n00 >= a.N) return;                                    // wave-uniform
+  const float* V = (const float*)a.qkv + (long long)b * a.N * 3 * a.C + 2 * a.C + g * 32 + kg * 8;
+  f32x4 vraw[2][4];
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int nl = min(n00 + t * 32 + col, a.N - 1);
+    const float* vp = V + (long long)nl * 3 * a.C;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      vraw[t][2 * ks] = *reinterpret_cast<const f32x4*>(vp + 16 * ks);
+      vraw[t][2 * ks + 1] = *reinterpret_cast<const f32x4*>(vp + 16 * ks + 4);
+    }
+  }
+  // row operand: lane (i = col, kg) holds A[i][16 ks + 8 kg + 0..7]
+  const float* A = a.ws + ((long long)b * a.G + g) * a.chunks * 1024 + col * 32 + kg * 8;
+  h16x8 Ah[2], Al[2];
+#pragma unroll
+  for (int ks = 0; ks < 2; ++ks) {
+    uint2 h0, l0, h1, l1;
+    split4m(*reinterpret_cast<const f32x4*>(A + 16 * ks), h0, l0);
+    split4m(*reinterpret_cast<const f32x4*>(A + 16 * ks + 4), h1, l1);
+    Ah[ks] = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+    Al[ks] = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+  }
+  float* const O = (float*)a.o + (long long)b * a.N * a.C + g * 32 + 4 * kg;
+  unsigned char* const S = (unsigned char*)a.o + (long long)b * a.N * a.C * 4;
+#pragma unroll
+  for (int t = 0; t < 2; ++t) {
+    const int n = n00 + t * 32 + col;
+    if (n00 + t * 32 >= a.N) break;                          // wave-uniform
+    f32x16 accM, accC;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { accM[e] = 0.f; accC[e] = 0.f; }
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      uint2 h0, l0, h1, l1;
+      split4m(vraw[t][2 * ks], h0, l0);
+      split4m(vraw[t][2 * ks + 1], h1, l1);
+      const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+      const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+      accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], vh, accM, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Ah[ks], vl, accC, 0, 0, 0);
+      accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(Al[ks], vh, accC, 0, 0, 0);
+    }
+    if (n < a.N) {
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {                          // channels 8 q + 4 kg + 0..3 of token n
+        const f32x4 o = f32x4{accC[4 * q], accC[4 * q + 1], accC[4 * q + 2], accC[4 * q + 3]} * inv2048 +
+                        f32x4{accM[4 * q], accM[4 * q + 1], accM[4 * q + 2], accM[4 * q + 3]};
+        if (a.osplit) {
+          const float v[4] = {o[0], o[1], o[2], o[3]};
+          uint2 hi, lo;
+          omni_split4(v, hi, lo);
+          unsigned char* p = S + (long long)n * a.C * 4 + omni_split_off(g * 32 + 8 * q + 4 * kg);
+          *reinterpret_cast<uint2*>(p) = hi;
+          *reinterpret_cast<uint2*>(p + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>(O + (long long)n * a.C + 8 * q) = o;
+        }
+      }
+    }
+  }
+}
+
+
 // ------------------------------------------------------------------------------------ small glue kernels
 struct PrepArgs { const void* x; const float* pos; const float* temporal; void* y; int B, N, C; };
 
@@ -2076,7 +2159,8 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   if (op->dtype == OMNI_F32 && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
     hipLaunchKernelGGL(chan_scores_mfma_kernel, g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(chan_softmax_kernel, dim3(a.G, a.B), dim3(256), 0, s, a);
-    hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
+    if (op->i[7] == 1) hipLaunchKernelGGL(chan_apply_mfma_split_kernel, g2, dim3(256), 0, s, a);   // candidate (see the kernel)
+    else hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
     OMNI_HIP_CHECK(hipGetLastError());
     return OMNI_OK;
   }

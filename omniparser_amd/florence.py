@@ -407,7 +407,8 @@ class _CaptionPlans(_StepPlans):
                     else:
                         linear(pre + "channel_attn.qkv", hbuf, qkv)
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
-                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if (attn_split and grp["dma"]) else 0}))
+                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if (attn_split and grp["dma"]) else 0,
+                                               7: 1 if (cap.chan_apply_mfma and dt == L.F32) else 0}))
                         att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
@@ -529,6 +530,9 @@ class Florence2Captioner:
                               # kernel with 32-bit window-relative addressing, O^T accumulators (vector stores, no shuffles) and mixed-precision
                               # fma splits — 1 490 instead of 2 841 VALU instructions per wave (csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel);
                               # emulated checks green incl. cut windows; A/B: tools/r4_open.sh
+    chan_apply_mfma = False   # CANDIDATE, not timed on the MI355X yet: the channel-attention apply on the f16 matrix pipe (split-f16 x3, the
+                              # 32x32 matrix as the MFMA row operand, 16-byte token loads / stores, no LDS) — ~330 instead of ~1 700 VALU
+                              # instructions per 64 tokens (csrc/caption_ops.hip::chan_apply_mfma_split_kernel); A/B: tools/r4_open.sh
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):

@@ -741,7 +741,7 @@ def _cmp(a, b, tol, what):
     return e
 
 
-def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,)):
+def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(0,)):
     g = torch.Generator().manual_seed(seed)
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     tol = 2e-5 if dtype == L.F32 else 5e-3
@@ -828,15 +828,21 @@ def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,)):
     if dtype == L.F32:
         # f32 plans: MFMA scores + one softmax per (image, group) + MFMA apply, and the format-B output; a token count that is a
         # multiple of the 32-token MFMA trip (the real shapes) and a tiny one (R = 64)
-        for (Bq2, N2) in ((2, 2500), (1, 4096), (3, 16)):
-            ch2 = (N2 + 1023) // 1024
-            t2 = {"qkv": R(Bq2 * N2, 3 * Cm).to(tdt), "o": torch.zeros(Bq2 * N2, Cm, dtype=tdt), "ws": torch.zeros(Bq2 * G * ch2 * 1024)}
-            mk = lambda P, osplit: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
-                                             i={0: Bq2, 1: N2, 3: Cm, 4: G, 5: 1024, 6: osplit})
-            c2, g_new = _op_pair(t2, lambda P: mk(P, 0))
-            res[f"chan_attn_{N2}"] = _cmp(g_new["o"], c2["o"], tol * 10, f"channel attention N={N2}")
-            cs, gs = _op_pair(t2, lambda P: mk(P, 1))
-            _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 10, f"channel attention split out N={N2}")
+        # chan_variants: 0 = the shipped VALU apply kernel, 1 = the candidate split-f16 MFMA apply (op i[7]); N = 2500 / 300 / 16 end in
+        # partial 32-token tiles, partial waves and partial blocks
+        for variant in chan_variants:
+            tag = "" if variant == 0 else f"_v{variant + 1}"
+            for (Bq2, N2) in ((2, 2500), (1, 4096), (3, 16)) + (((2, 300),) if variant else ()):
+                ch2 = (N2 + 1023) // 1024
+                t2 = {"qkv": R(Bq2 * N2, 3 * Cm).to(tdt), "o": torch.zeros(Bq2 * N2, Cm, dtype=tdt), "ws": torch.zeros(Bq2 * G * ch2 * 1024)}
+                mk = lambda P, osplit: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
+                                                 i={0: Bq2, 1: N2, 3: Cm, 4: G, 5: 1024, 6: osplit, 7: variant})
+                c2, g_new = _op_pair(t2, lambda P: mk(P, 0))
+                res[f"chan_attn{tag}_{N2}"] = _cmp(g_new["o"], c2["o"], tol * 10, f"channel attention N={N2} variant {variant}")
+                cs, gs = _op_pair(t2, lambda P: mk(P, 1))
+                _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 10, f"channel attention split out N={N2} variant {variant}")
+                if variant:
+                    assert (split_decode(gs["o"]) - g_new["o"]).abs().max() <= 1e-6 * g_new["o"].abs().max()    # both formats: the same numbers
     # proj_prep / assemble
     Bq, N, Cm = 2, 36, 256
     t = {"x": R(Bq, N, Cm).to(tdt), "pos": R(N, Cm), "tmp": R(Cm), "y": torch.zeros(Bq, N + 1, Cm, dtype=tdt)}
