@@ -53,6 +53,8 @@ def parse_args():
     ap.set_defaults(pipeline=True)
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
+    ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
+                    "(window_attn_v2, chan_apply_mfma: kernels not adopted yet); recorded in config.candidates")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -117,6 +119,9 @@ def main():
     if args.mode == "e2e":
         from omniparser_amd.florence import Florence2Captioner
         from omniparser_amd.pipeline import ScreenParser
+        for name in filter(None, args.candidates.split(",")):
+            assert isinstance(getattr(Florence2Captioner, name, None), bool), f"--candidates: unknown composition switch {name}"
+            setattr(Florence2Captioner, name, True)
         cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
         parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
         parser.encode_lanes = args.lanes
@@ -235,6 +240,8 @@ def main():
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
+        if args.candidates:
+            out["config"]["candidates"] = args.candidates.split(",")
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
         if args.pipeline:
             out["config"]["pipeline"] = ("parse_stream: detector + hand-off graph of step i+1 on the detector's stream, caption micro-batches alternating "

@@ -318,3 +318,25 @@ def test_pmc_tools_on_a_synthetic_trace(tmp_path):
     assert t["gemm_fetch_bytes_per_crop"] == round(4 * 1000.0 * 2048 / 8) and t["gemm_bytes_per_launch"] == round((1000.0 * 2048 + 500.0 * 1024))
     strip = next(v for k, v in t["families"].items() if k.startswith("dwln_strip_kernel"))
     assert strip["fetch_over_write"] == 0.5 and strip["launches"] == 4
+
+
+def test_hwq_gap_summary_on_a_synthetic_trace():
+    """tools/hwq_gaps.py (the round-4 diagnosis of the hardware-queue cliff): busy union, idle time, per-queue gaps, idle attribution."""
+    from tools.hwq_gaps import summarise
+    G = "void (anonymous namespace)::gemm_dma_kernel<256, 256, 2, 4, 2, 0, false, true, 1>((anonymous namespace)::GemmArgs)"
+    S = "(anonymous namespace)::attn_decode_cross_kernel((anonymous namespace)::DecArgs)"
+    rows = [  # queue 1: two long kernels back to back, then a 200 us hole; queue 2: a short kernel inside the first, one inside the hole
+        {"Kernel_Name": G, "Start_Timestamp": 0, "End_Timestamp": 1_000_000, "Queue_Id": 1, "Stream_Id": 3},
+        {"Kernel_Name": G, "Start_Timestamp": 1_000_000, "End_Timestamp": 2_000_000, "Queue_Id": 1, "Stream_Id": 3},
+        {"Kernel_Name": S, "Start_Timestamp": 100_000, "End_Timestamp": 150_000, "Queue_Id": 2, "Stream_Id": 5},
+        {"Kernel_Name": S, "Start_Timestamp": 2_100_000, "End_Timestamp": 2_150_000, "Queue_Id": 2, "Stream_Id": 5},
+        {"Kernel_Name": G, "Start_Timestamp": 2_200_000, "End_Timestamp": 3_200_000, "Queue_Id": 1, "Stream_Id": 3},
+    ]
+    r = summarise(rows)
+    assert r["launches"] == 5 and abs(r["span_ms"] - 3.2) < 1e-9
+    assert abs(r["gpu_busy_ms"] - 3.05) < 1e-9 and abs(r["gpu_idle_ms"] - 0.15) < 1e-9          # holes: 2.0-2.1 and 2.15-2.2
+    assert abs(r["concurrent_kernel_ms"] - 0.05) < 1e-9
+    assert r["idle_over_50us"] == 1 and r["idle_intervals"] == 2
+    assert r["per_queue"]["1"]["gaps_over_50us"] == 1 and abs(r["per_queue"]["1"]["gap_ms"] - 0.2) < 1e-9
+    assert r["per_queue"]["2"]["streams"] == ["5"] and r["per_queue"]["2"]["launches"] == 2
+    assert list(r["idle_before_kernel_family_ms"]) == ["attn_decode_cross_kernel", "gemm_dma_kernel"]

@@ -1,6 +1,8 @@
 """Per-op device time of the caption plans (HIP events around every op of an eager replay: omni_plan_profile), with the
 algorithmic bytes / FLOPs of each op -> GB/s and TF/s per op, aggregated by (kernel family, tensor shape).
-usage: python tools/caption_profile.py [capacity=128] [R=768] [repeat=2]   -> JSON on stdout, table on stderr"""
+usage: python tools/caption_profile.py [capacity=128] [R=768] [repeat=2] [flags]   -> JSON on stdout, table on stderr
+flags (comma separated): nomlp = stage-0 FFN as two launches; any boolean composition switch of Florence2Captioner to turn ON
+(window_attn_v2, chan_apply_mfma: the candidate kernels)"""
 import json
 import os
 import sys
@@ -44,6 +46,10 @@ def main():
     flags = sys.argv[4].split(",") if len(sys.argv) > 4 else []     # "nomlp": fc1 / fc2 of the C = 128 stage as two launches
     if "nomlp" in flags:
         Florence2Captioner.fuse_mlp = False
+    for f in flags:                                                  # candidate kernels: "window_attn_v2", "chan_apply_mfma", ...
+        if f != "nomlp":
+            assert isinstance(getattr(Florence2Captioner, f, None), bool), f"unknown composition switch {f}"
+            setattr(Florence2Captioner, f, True)
     ensure_via_subprocess("caption", seed=0)
     cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
     cap.use_graph = False           # eager plans: every op is timed on its own

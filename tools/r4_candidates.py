@@ -1,0 +1,43 @@
+"""Hardware check of the candidate kernels written after round 3's last GPU minute (Florence2Captioner.window_attn_v2 /
+chan_apply_mfma: csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel, chan_apply_mfma_split_kernel) — they have only run on the host
+emulation.  (1) the kernel-level checks of tests/gpu_checks.py with both variants of each op, (2) per candidate and for both together:
+real 768x768 crops through a caption plan against transformers on the CPU (features, encoder output, step-1 logits, token-exact ids).
+usage (GPU box): python tools/r4_candidates.py > gpurun_out/r4/candidates.json      exit code 0 = every check passed"""
+import json
+import sys
+from pathlib import Path
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+
+
+def main():
+    import gpu_checks as G
+    from omniparser_amd import _lib as L
+    from omniparser_amd.florence import Florence2Captioner
+    out, ok = {}, True
+    try:
+        r = G.check_caption_ops(L.F32, window_variants=(0, 1), chan_variants=(0, 1))
+        out["kernel_checks"] = {k: v for k, v in r.items() if "attn_window" in k or "chan_attn" in k}
+    except AssertionError as e:
+        out["kernel_checks"] = {"failed": str(e)[:500]}
+        ok = False
+    for names in (("window_attn_v2",), ("chan_apply_mfma",), ("window_attn_v2", "chan_apply_mfma")):
+        for n in ("window_attn_v2", "chan_apply_mfma"):
+            setattr(Florence2Captioner, n, n in names)
+        try:
+            rec, cap = G.check_captioner_real_crops(R=768, n=4, seed=0)
+            rec["passed"] = bool(rec["x_in_bitwise"] and rec["ids_equal"] and rec["enc_rel_err"] < 1e-4 and rec["feat_rel_err"] < 1e-4)
+            del cap
+        except Exception as e:                                     # noqa: BLE001 — report, keep going
+            rec = {"passed": False, "error": repr(e)[:500]}
+        ok = ok and rec["passed"]
+        out["+".join(names)] = rec
+    out["all_passed"] = ok
+    print(json.dumps(out, indent=1))
+    return 0 if ok else 1
+
+
+if __name__ == "__main__":
+    sys.exit(main())

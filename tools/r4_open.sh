@@ -1,0 +1,64 @@
+#!/usr/bin/env bash
+# Round-4 opening GPU session (one gpurun call, ~25 GPU-minutes).  Round 3 ended with three things unmeasured:
+#   A. two candidate kernels that have only run on the host emulation (window attention v2, channel-attention apply on the matrix
+#      pipe: Florence2Captioner.window_attn_v2 / chan_apply_mfma) -> hardware parity, per-op A/B, bench A/B
+#   B. the hardware-queue cliff (one encode lane + the decode stream at GPU_MAX_HW_QUEUES=8: 1034 instead of 709 ms per step)
+#      -> kernel trace of the slow and the fast case, per-queue gap summary (tools/hwq_gaps.py)
+#   C. the suite and the default bench line at the round-3 final commit on a fresh box (what the driver recorded at round end)
+# usage: gpurun --timeout 1700 -- 'bash tools/r4_open.sh'
+set -u
+cd "${GRAFT_REPO_ROOT:-/root/repo}"
+export TMPDIR=/tmp
+OUT=gpurun_out/r4open
+mkdir -p "$OUT"
+python tools/make_weights.py --ensure detector > /dev/null 2>&1
+python tools/make_weights.py --ensure caption > /dev/null 2>&1
+echo "=== A1. candidate kernels on hardware: kernel checks + real 768x768 crops against transformers"
+( timeout 420 python tools/r4_candidates.py > "$OUT/candidates.json" 2> "$OUT/candidates.err"; echo "exit $?" )
+python - "$OUT/candidates.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    print("all_passed", d.get("all_passed"))
+    for k, v in d.items():
+        if isinstance(v, dict):
+            print("  ", k, {a: (round(b, 8) if isinstance(b, float) else b) for a, b in v.items()})
+except Exception as e:
+    print("no report:", e)
+PY
+echo "=== A2. per-op profile of one 128-crop plan: default, each candidate, both"
+for f in "" "window_attn_v2" "chan_apply_mfma" "window_attn_v2,chan_apply_mfma"; do
+  tag=${f:-default}; tag=${tag//,/+}
+  ( timeout 200 python tools/caption_profile.py 128 768 2 $f > "$OUT/per_op_$tag.json" 2> "$OUT/per_op_$tag.txt"; echo "$tag exit $?" )
+  grep -E "^--- encode|attn_rows|chan_attn" "$OUT/per_op_$tag.txt" | head -12
+done
+echo "=== A3. bench A/B (K = 6): default, both candidates"
+for f in "" "window_attn_v2,chan_apply_mfma"; do
+  tag=${f:-default}; tag=${tag//,/+}
+  ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra ${f:+--candidates $f} > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
+  python - "$OUT/bench_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    r = d["roofline"]
+    print("   ", d["value"], "screenshots/s", d["ms_per_step"], "ms/step; gemm", r.get("gemm_ms_per_step"), "non-gemm share", r.get("non_gemm_share"))
+    print("   ", r.get("kernel_family_ms_per_step"))
+except Exception as e:
+    print("    no line:", e)
+PY
+done
+echo "=== B. hardware-queue cliff: kernel traces of --lanes 1 at 4 and 8 hardware queues (K = 3), gap summary per queue"
+for q in 4 8; do
+  ( GPU_MAX_HW_QUEUES=$q OMNI_BENCH_WATCHDOG=120 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_hwq$q" -- \
+      python bench.py --steps 3 --warmup 2 --lanes 1 --no-cpu-baseline --no-extra > "$OUT/bench_lanes1_hwq$q.json" 2> "$OUT/bench_lanes1_hwq$q.err"; echo "hwq$q exit $?" )
+  f=$(find "$OUT/trace_hwq$q" -name "*kernel_trace.csv" | head -1)
+  python tools/hwq_gaps.py "$f" > "$OUT/hwq_gaps_$q.json" 2> "$OUT/hwq_gaps_$q.err"; head -c 1500 "$OUT/hwq_gaps_$q.json"; echo
+  find "$OUT/trace_hwq$q" -name "*.csv" -size +4M -delete; find "$OUT/trace_hwq$q" -name "*.db" -delete
+done
+echo "=== C. pytest tests/ -x -q -m gpu (one process, as the driver runs it) and the default bench line"
+t0=$(date +%s)
+( timeout 1200 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=10 > "$OUT/pytest.log" 2>&1; echo "exit $?" >> "$OUT/pytest.log" )
+echo "($(( $(date +%s) - t0 )) s)"; grep -v "Warning\|warnings.warn\|^$\|_create_method\|amdgpu.ids" "$OUT/pytest.log" | tail -16 | cut -c1-300
+( OMNI_BENCH_WATCHDOG=200 timeout 900 python bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"; echo "bench exit $?" )
+tail -c 1200 "$OUT/bench_full.json"; echo
+ls -la "$OUT" | head -40
