@@ -118,7 +118,8 @@ enum {
    *  i0 ldq i1 ldk i2 ldv i3 ldo i4 qoff i5 koff i6 voff i7 ooff i8 heads i9 nq i10 nk i11 groups
    *  i12 mode i13 H i14 W i15 head_dim (32|64); f0 scale
    *  i16 = 1 (f32 plans, MFMA kernels): write o in format B (see OMNI_OP_CONV i20 = 2) for the LDS-DMA GEMM that follows
-   *  i17 = 1 (f32 plans, mode 1, head_dim 32): the candidate window kernel (window-relative 32-bit addressing, O^T accumulators) */
+   *  i17 = 1 (f32 plans): the candidate kernels — mode 1, head_dim 32: window kernel with window-relative 32-bit addressing and O^T
+   *  accumulators; mode 0, head_dim 64: double-buffered 64-key stages, 32x32x16 MFMAs, lazily moved softmax reference */
   OMNI_OP_ATTN_ROWS = 10,
   /* DaViT grouped channel attention (florence2 :223-259): p0 qkv [B*N,3C] p4 o [B*N,C] p5 ws f32[B*G*chunks*1024]
    *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5)

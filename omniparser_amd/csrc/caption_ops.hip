@@ -1364,6 +1364,202 @@ __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
   }
 }
 
+
+// Candidate successor of mha_mfma_kernel<float> (op->i[17] = 1 in mode 0; written after the last GPU session of round 3: verified on
+// the host emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above stages 32 keys at a time
+// with 4-byte loads, converts one value per instruction, writes V^T to LDS two bytes at a time and brackets every 32 keys with two
+// block barriers and no load in flight across them: at 585 keys a block spends its 19 iterations mostly waiting (1.0 ms per launch
+// at 134.6 GFLOP = 132 TF/s of useful work; the MFMA work alone is ~0.25 ms).  Here:
+//   * 64 keys per iteration, TWO LDS stages: the global loads of iteration i + 1 (eight 16-byte loads per thread) are issued before
+//     the arithmetic of iteration i, converted and written to the other stage after it — ONE barrier per 64 keys;
+//   * 16-byte loads, pair-wise splits (split4m), V transposed in registers per (4 keys x 4 channels) item -> 8-byte LDS writes;
+//   * 32x32x16 MFMAs: the wave's 32 queries are ONE tile (half the K / V^T fragment reads per MAC of the 16x16 form); S^T = K Q^T
+//     leaves query (lane & 31) in the lane, and O^T = V^T P^T takes the lane's own exponentials as the column operand with the key
+//     order of the accumulator layout (the V^T fragment is read in that order): no cross-lane traffic between the two products;
+//   * online softmax with a LAZY reference maximum: the row's reference only moves when a block maximum exceeds it by more than 2^8
+//     (scores are kept in log2 units: log2(e) folded into the Q scale), so the 64 accumulator multiplications of a rescale happen a
+//     few times per row instead of once per block; p = exp2(s - ref) <= 256 stays well inside f16 / f32 range and the final
+//     division by the row sum makes the result independent of the reference;
+//   * each lane owns ONE query and 4 consecutive channels per accumulator quad: 16-byte f32 / 8-byte hi and lo stores.
+__global__ __launch_bounds__(256, 2) void mha_mfma_f32_v2_kernel(AttnArgs a) {
+  constexpr int D = 64, KB = 64;
+  constexpr int KROW = 144;                     // bytes per staged K row: 64 halves + 16 pad (16-byte fragment reads, conflict-free)
+  constexpr int VROW = 136;                     // bytes per staged V^T row: 64 halves + 8 pad (8-byte fragment reads, conflict-free)
+  constexpr int STAGE = 2 * KB * KROW + 2 * D * VROW;
+  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * STAGE];
+  const int g = blockIdx.z, h = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  const int col = lane & 31, kg = lane >> 5;
+  const float inv2048 = 1.0f / 2048.0f;
+  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
+  const float* Kb = (const float*)a.k + (long long)g * a.nk * a.ldk + a.koff + h * D;
+  const float* Vb = (const float*)a.v + (long long)g * a.nk * a.ldv + a.voff + h * D;
+
+  // ---- staging roles: K items (key = t16 + 16 j, channels d0..d0+3), j = 0..3; one V item (keys 4 t16 .. 4 t16 + 3, channels d0..d0+3)
+  const int t16 = tid >> 4, d0 = (tid & 15) * 4;
+  f32x4 kraw[4], vraw[4];
+  auto load_block = [&](int k0) {
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int key = k0 + t16 + 16 * j;
+      kraw[j] = key < a.nk ? *reinterpret_cast<const f32x4*>(Kb + key * a.ldk + d0) : z4;
+    }
+#pragma unroll
+    for (int u = 0; u < 4; ++u) {
+      const int key = k0 + 4 * t16 + u;
+      vraw[u] = key < a.nk ? *reinterpret_cast<const f32x4*>(Vb + key * a.ldv + d0) : z4;
+    }
+  };
+  auto store_block = [&](unsigned char* st) {
+    unsigned char* Kh = st;
+    unsigned char* Kl = st + KB * KROW;
+    unsigned char* Vh = st + 2 * KB * KROW;
+    unsigned char* Vl = Vh + D * VROW;
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      uint2 kh, kl;
+      split4m(kraw[j], kh, kl);
+      *reinterpret_cast<uint2*>(Kh + (t16 + 16 * j) * KROW + d0 * 2) = kh;
+      *reinterpret_cast<uint2*>(Kl + (t16 + 16 * j) * KROW + d0 * 2) = kl;
+    }
+#pragma unroll
+    for (int dd = 0; dd < 4; ++dd) {                  // channel d0 + dd: its four keys 4 t16 .. 4 t16 + 3
+      uint2 vh, vl;
+      split4m(f32x4{vraw[0][dd], vraw[1][dd], vraw[2][dd], vraw[3][dd]}, vh, vl);
+      *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + t16 * 8) = vh;
+      *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + t16 * 8) = vl;
+    }
+  };
+  load_block(0);
+
+  // ---- Q fragments: query qi = q0 + col, channels 16 ks + 8 kg + 0..7, pre-multiplied by scale * log2(e)
+  const int qi = blockIdx.x * 128 + wave * 32 + col;
+  const float qscale = a.scale * 1.4426950408889634f;
+  h16x8 qh[4], ql[4];
+  {
+    const float* qp = (const float*)a.q + ((long long)g * a.nq + min(qi, a.nq - 1)) * a.ldq + a.qoff + h * D + kg * 8;
+#pragma unroll
+    for (int ks = 0; ks < 4; ++ks) {
+      uint2 h0, l0, h1, l1;
+      split4m(*reinterpret_cast<const f32x4*>(qp + 16 * ks) * qscale, h0, l0);
+      split4m(*reinterpret_cast<const f32x4*>(qp + 16 * ks + 4) * qscale, h1, l1);
+      qh[ks] = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
+      ql[ks] = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
+    }
+  }
+  f32x16 oM[2], oC[2];                                // O^T: channels dt * 32 + 8 (r >> 2) + 4 kg + (r & 3) of query col
+#pragma unroll
+  for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) { oM[dt][e] = 0.f; oC[dt][e] = 0.f; }
+  float mref = -INFINITY, lsum = 0.0f;                // reference maximum of the row (log2 units); this lane's part of the row sum
+
+  store_block(lds);
+  __syncthreads();
+  const int nblk = (a.nk + KB - 1) / KB;
+  for (int ib = 0; ib < nblk; ++ib) {
+    const int k0 = ib * KB;
+    unsigned char* st = lds + (ib & 1) * STAGE;
+    if (ib + 1 < nblk) load_block(k0 + KB);           // in flight under this block's arithmetic
+    const unsigned char* Kh = st;
+    const unsigned char* Vh = st + 2 * KB * KROW;
+    const bool tail = k0 + KB > a.nk;                 // uniform: only the last block can hold keys >= nk
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      // ---- S^T[key][query] for 32 keys: lane holds keys kt * 32 + (r & 3) + 8 (r >> 2) + 4 kg of query col
+      f32x16 accM, accC;
+#pragma unroll
+      for (int e = 0; e < 16; ++e) { accM[e] = 0.f; accC[e] = 0.f; }
+#pragma unroll
+      for (int ks = 0; ks < 4; ++ks) {
+        const unsigned char* kr = Kh + (kt * 32 + col) * KROW + (16 * ks + 8 * kg) * 2;
+        const h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
+        const h16x8 kl = *reinterpret_cast<const h16x8*>(kr + KB * KROW);
+        accM = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, qh[ks], accM, 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(kh, ql[ks], accC, 0, 0, 0);
+        accC = __builtin_amdgcn_mfma_f32_32x32x16_f16(kl, qh[ks], accC, 0, 0, 0);
+      }
+      f32x2 sc[8];
+#pragma unroll
+      for (int e = 0; e < 8; ++e) sc[e] = f32x2{accC[2 * e], accC[2 * e + 1]} * inv2048 + f32x2{accM[2 * e], accM[2 * e + 1]};
+      if (tail) {                                     // keys >= nk: -inf added (an addition, not a select: the result stays a canonical number
+#pragma unroll                                        // for the maxima below)
+        for (int e = 0; e < 8; ++e) {
+          const int key = k0 + kt * 32 + ((2 * e) & 3) + 8 * (e >> 1) + 4 * kg;
+          sc[e] += f32x2{key >= a.nk ? -INFINITY : 0.f, key + 1 >= a.nk ? -INFINITY : 0.f};
+        }
+      }
+      float bm = fmaxf(sc[0][0], sc[0][1]);
+#pragma unroll
+      for (int e = 1; e < 8; ++e) bm = fmaxf(fmaxf(bm, sc[e][0]), sc[e][1]);     // v_max3_f32
+      bm = fmaxf(bm, __shfl_xor(bm, 32));             // both halves of the wave hold the same queries
+      const bool need = bm > mref + 8.0f;             // first block: mref = -inf; a fully masked sub-block (bm = -inf) never moves it
+      if (__any(need)) {                              // wave-uniform branch, per-lane arithmetic
+        const float mn = need ? bm : mref;
+        const float corr = __builtin_amdgcn_exp2f(mref - mn);      // 1 where the reference stays; 0 on the first block
+        mref = mn;
+        lsum *= corr;
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) { oM[dt] *= corr; oC[dt] *= corr; }
+      }
+      f32x2 ps = {0.f, 0.f};
+#pragma unroll
+      for (int e = 0; e < 8; ++e) {
+        const f32x2 d = sc[e] - mref;
+        sc[e] = f32x2{__builtin_amdgcn_exp2f(d[0]), __builtin_amdgcn_exp2f(d[1])};
+        ps += sc[e];
+      }
+      lsum += ps[0] + ps[1];
+      // ---- O^T += V^T P^T: k-step s covers the lane's values r = 8 s .. 8 s + 7 = keys 16 s + 4 kg + {0..3} and 16 s + 8 + 4 kg + {0..3}
+#pragma unroll
+      for (int s = 0; s < 2; ++s) {
+        unsigned ph[4], pl[4];
+#pragma unroll
+        for (int e = 0; e < 4; ++e) split2m(sc[4 * s + e][0], sc[4 * s + e][1], ph[e], pl[e]);
+        const h16x8 phv = __builtin_bit_cast(h16x8, u32x4{ph[0], ph[1], ph[2], ph[3]});
+        const h16x8 plv = __builtin_bit_cast(h16x8, u32x4{pl[0], pl[1], pl[2], pl[3]});
+#pragma unroll
+        for (int dt = 0; dt < 2; ++dt) {
+          const unsigned char* vr = Vh + (dt * 32 + col) * VROW + (kt * 32 + 16 * s + 4 * kg) * 2;
+          const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 16);
+          const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 16);
+          const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
+          const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
+          oM[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, phv, oM[dt], 0, 0, 0);
+          oC[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vl, phv, oC[dt], 0, 0, 0);
+          oC[dt] = __builtin_amdgcn_mfma_f32_32x32x16_f16(vh, plv, oC[dt], 0, 0, 0);
+        }
+      }
+    }
+    if (ib + 1 < nblk) store_block(lds + ((ib + 1) & 1) * STAGE);   // the other stage: its last readers passed the barrier below one iteration ago
+    __syncthreads();
+  }
+  // ---- normalise and store
+  const float tot = lsum + __shfl_xor(lsum, 32);
+  if (qi < a.nq) {
+    const float inv = 1.0f / tot;
+    const long long orow = (long long)g * a.nq + qi;
+#pragma unroll
+    for (int dt = 0; dt < 2; ++dt)
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const f32x4 o = (f32x4{oC[dt][4 * q], oC[dt][4 * q + 1], oC[dt][4 * q + 2], oC[dt][4 * q + 3]} * inv2048 +
+                         f32x4{oM[dt][4 * q], oM[dt][4 * q + 1], oM[dt][4 * q + 2], oM[dt][4 * q + 3]}) * inv;
+        const int c = a.ooff + h * D + dt * 32 + 8 * q + 4 * kg;
+        if (a.osplit) {
+          const float v[4] = {o[0], o[1], o[2], o[3]};
+          uint2 hi, lo;
+          omni_split4(v, hi, lo);
+          unsigned char* p = (unsigned char*)a.o + orow * a.ldo * 4 + omni_split_off(c);
+          *reinterpret_cast<uint2*>(p) = hi;
+          *reinterpret_cast<uint2*>(p + 32) = lo;
+        } else {
+          *reinterpret_cast<f32x4*>((float*)a.o + orow * a.ldo + c) = o;
+        }
+      }
+  }
+}
+
 // ------------------------------------------------------------------------------------ channel attention
 struct ChanArgs {
   const void* qkv; void* o; float* ws;    // qkv [B*N, 3C]; ws [B][G][chunks][32][32]
@@ -2129,8 +2325,12 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
   } else if (a.mode == 0 && D == 64) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
+    // op->i[17] = 1: the candidate kernel (16-byte rows: 4-element aligned pitches and offsets)
+    const bool v2 = op->i[17] == 1 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 &&
+                    a.qoff % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0 && a.ooff % 4 == 0;
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { hipLaunchKernelGGL((mha_mfma_kernel<float>), grid, dim3(256), 0, s, a); },
+      [&] { if (v2) hipLaunchKernelGGL(mha_mfma_f32_v2_kernel, grid, dim3(256), 0, s, a);
+            else hipLaunchKernelGGL((mha_mfma_kernel<float>), grid, dim3(256), 0, s, a); },
       [&] { hipLaunchKernelGGL((mha_mfma_kernel<half_t>), grid, dim3(256), 0, s, a); });
   } else {
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);

@@ -483,7 +483,8 @@ class _CaptionPlans(_StepPlans):
             linear(None, xin, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
             pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
                                 i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
-                                   12: 0, 15: 64, 16: 1 if (attn_split and dma_enc) else 0}, f={0: 64 ** -0.5}))
+                                   12: 0, 15: 64, 16: 1 if (attn_split and dma_enc) else 0,
+                                   17: 1 if (cap.mha_v2 and dt == L.F32) else 0}, f={0: 64 ** -0.5}))
             att.fmt = "split" if (attn_split and dma_enc) else "f32"
             linear(pre + "self_attn.out_proj", att, tmp, res=xa)
             layernorm(pre + "self_attn_layer_norm", tmp, xa, split=xs)
@@ -533,6 +534,9 @@ class Florence2Captioner:
     chan_apply_mfma = False   # CANDIDATE, not timed on the MI355X yet: the channel-attention apply on the f16 matrix pipe (split-f16 x3, the
                               # 32x32 matrix as the MFMA row operand, 16-byte token loads / stores, no LDS) — ~330 instead of ~1 700 VALU
                               # instructions per 64 tokens (csrc/caption_ops.hip::chan_apply_mfma_split_kernel); A/B: tools/r4_open.sh
+    mha_v2 = False            # CANDIDATE, not timed on the MI355X yet: the encoder's attention with 64-key double-buffered LDS stages (loads
+                              # of the next keys in flight under the arithmetic, one barrier per 64 keys), 32x32x16 MFMAs, a lazily moved softmax
+                              # reference (csrc/caption_ops.hip::mha_mfma_f32_v2_kernel); A/B: tools/r4_open.sh
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):

@@ -314,6 +314,9 @@ template <class T> inline T __shfl_xor(T v, int mask, int width = 64) {
   const int l = emu::cur->lane, base = l & ~(width - 1);
   return emu::collective(v, [&](auto get) { return get(base + ((l ^ mask) & (width - 1))); });
 }
+inline int __any(int pred) {
+  return emu::collective(pred, [&](auto get) { int r = 0; for (int q = 0; q < 64; ++q) r |= get(q) != 0; return r; });
+}
 template <class T> inline T emu_readlane(T v, int lane) { return emu::collective(v, [&](auto get) { return get(lane); }); }
 #define __builtin_amdgcn_readlane(v, l) emu_readlane((v), (l))
 #define __builtin_amdgcn_readfirstlane(v) emu_readlane((v), 0)

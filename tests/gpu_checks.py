@@ -741,7 +741,7 @@ def _cmp(a, b, tol, what):
     return e
 
 
-def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(0,)):
+def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(0,), mha_variants=(0,)):
     g = torch.Generator().manual_seed(seed)
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     tol = 2e-5 if dtype == L.F32 else 5e-3
@@ -787,13 +787,28 @@ def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(
                                                 i={0: rows, 1: 1, 3: Cc, 5: period}, f={0: 1e-5}))
         res[f"layernorm{Cc}"] = _cmp(gq["y"], c["y"], tol * 5, f"layernorm C={Cc}")
     # plain attention (encoder shape, odd S) and window attention with padding (H=W=16 -> 2x2 windows)
-    Bq, S, heads, D = 2, 77, 12, 64
-    Cm = heads * D
-    t = {"qkv": R(Bq * S, 3 * Cm).to(tdt), "o": torch.zeros(Bq * S, Cm, dtype=tdt)}
-    c, gq = _op_pair(t, lambda P: L.make_op(L.OP_ATTN_ROWS, dtype, p=[P("qkv"), P("qkv"), P("qkv"), None, P("o")],
-                                            i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
-                                               11: Bq, 12: 0, 15: D}, f={0: D ** -0.5}))
-    res["attn_plain"] = _cmp(gq["o"], c["o"], tol * 5, "attn_rows plain")
+    # mha_variants: 0 = the shipped MFMA kernel, 1 = its candidate successor (op i[17], f32 plans).  S = 77: two key blocks of the
+    # candidate, the second one partial with a fully masked half; 5: one partial block; 200: partial query tile, four key blocks
+    for variant in (mha_variants if dtype == L.F32 else (0,)):
+        tag = "" if variant == 0 else f"_v{variant + 1}"
+        for (Bq, S, heads) in ((2, 77, 12),) + (((1, 5, 2), (1, 200, 3)) if variant else ()):
+            D = 64
+            Cm = heads * D
+            t = {"qkv": R(Bq * S, 3 * Cm).to(tdt), "o": torch.zeros(Bq * S, Cm, dtype=tdt)}
+            mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype, p=[P("qkv"), P("qkv"), P("qkv"), None, P("o")],
+                                             i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
+                                                11: Bq, 12: 0, 15: D, 16: osplit, 17: variant}, f={0: D ** -0.5})
+            c, gq = _op_pair(t, lambda P: mk(P, 0))
+            res[f"attn_plain{tag}" + ("" if S == 77 else f"_{S}")] = _cmp(gq["o"], c["o"], tol * 5, f"attn_rows plain S={S} variant {variant}")
+            if variant:
+                cs, gs = _op_pair(t, lambda P: mk(P, 1))
+                _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"attn_rows plain split out S={S} variant {variant}")
+                assert (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
+                # scores far apart (rows whose maximum moves by much more than the lazy-rescale threshold between key blocks)
+                t2 = {"qkv": t["qkv"].clone(), "o": torch.zeros_like(t["o"])}
+                t2["qkv"][:, :Cm] *= 6.0
+                c2, g2 = _op_pair(t2, lambda P: mk(P, 0))
+                res[f"attn_plain{tag}_{S}_sharp"] = _cmp(g2["o"], c2["o"], tol * 5, f"attn_rows plain sharp S={S} variant {variant}")
     # window_variants: 0 = the shipped f32 window kernel, 1 = its candidate successor (op i[17]; f32 plans only).  12 = no padding
     # (every real stage at 768x768), 16 / 24 / 2 = cut windows, 13 = one row / column of a second window
     for variant in (window_variants if dtype == L.F32 else (0,)):

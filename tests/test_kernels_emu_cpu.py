@@ -89,8 +89,9 @@ def test_caption_kernels_vs_interpreter(emu, dtype):
     import gpu_checks as G
     # window_variants (0, 1): the shipped f32 window-attention kernel and the candidate behind op i[17] (Florence2Captioner.window_attn_v2)
     # chan_variants (0, 1): the shipped channel-attention apply kernel and the candidate behind op i[7] (Florence2Captioner.chan_apply_mfma)
-    r = G.check_caption_ops(dtype, window_variants=(0, 1), chan_variants=(0, 1))
-    assert dtype != L.F32 or ("attn_window_v2_13" in r and "chan_attn_v2_300" in r)
+    # mha_variants (0, 1): the shipped encoder MHA kernel and the candidate behind op i[17] in mode 0 (Florence2Captioner.mha_v2)
+    r = G.check_caption_ops(dtype, window_variants=(0, 1), chan_variants=(0, 1), mha_variants=(0, 1))
+    assert dtype != L.F32 or ("attn_window_v2_13" in r and "chan_attn_v2_300" in r and "attn_plain_v2_200_sharp" in r)
 
 
 def test_presplit_gemm_accuracy_versus_activation_scale(emu):

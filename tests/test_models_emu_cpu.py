@@ -54,15 +54,17 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
         cp2.encode_plan.run(cap2.stream)
     assert G.rel_err(cp2.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
     assert G.rel_err(cp2.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
-    # the candidate kernels (Florence2Captioner.window_attn_v2 / chan_apply_mfma) inside the default composition: at 64x64 every stage
+    # the candidate kernels (Florence2Captioner.window_attn_v2 / chan_apply_mfma / mha_v2) inside the default composition: at 64x64 every stage
     # has cut windows (16, 8, 4, 2 tokens per side) and token counts 256, 64, 16, 4 per channel-attention group; same features, encode pass only
     monkeypatch.undo()
     monkeypatch.setattr(Florence2Captioner, "window_attn_v2", True)
     monkeypatch.setattr(Florence2Captioner, "chan_apply_mfma", True)        # and the candidate channel-attention apply kernel (op i[7])
+    monkeypatch.setattr(Florence2Captioner, "mha_v2", True)                 # and the candidate encoder attention (op i[17] in mode 0)
     cap3 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     cp3 = cap3.plans(1, 64, max_new)
-    assert sum(op.kind == L.OP_ATTN_ROWS and op.i[17] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
+    assert sum(op.kind == L.OP_ATTN_ROWS and op.i[12] == 1 and op.i[17] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
     assert sum(op.kind == L.OP_CHAN_ATTN and op.i[7] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
+    assert sum(op.kind == L.OP_ATTN_ROWS and op.i[12] == 0 and op.i[17] == 1 for op in cp3.encode_plan.ops) == cap3.w.enc_layers
     with torch.inference_mode():
         cp3.reset()
         cp3.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)

@@ -1,5 +1,5 @@
 """Hardware check of the candidate kernels written after round 3's last GPU minute (Florence2Captioner.window_attn_v2 /
-chan_apply_mfma: csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel, chan_apply_mfma_split_kernel) — they have only run on the host
+chan_apply_mfma / mha_v2: csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel, chan_apply_mfma_split_kernel, mha_mfma_f32_v2_kernel) — they have only run on the host
 emulation.  (1) the kernel-level checks of tests/gpu_checks.py with both variants of each op, (2) per candidate and for both together:
 real 768x768 crops through a caption plan against transformers on the CPU (features, encoder output, step-1 logits, token-exact ids).
 usage (GPU box): python tools/r4_candidates.py > gpurun_out/r4/candidates.json      exit code 0 = every check passed"""
@@ -18,13 +18,14 @@ def main():
     from omniparser_amd.florence import Florence2Captioner
     out, ok = {}, True
     try:
-        r = G.check_caption_ops(L.F32, window_variants=(0, 1), chan_variants=(0, 1))
-        out["kernel_checks"] = {k: v for k, v in r.items() if "attn_window" in k or "chan_attn" in k}
+        r = G.check_caption_ops(L.F32, window_variants=(0, 1), chan_variants=(0, 1), mha_variants=(0, 1))
+        out["kernel_checks"] = {k: v for k, v in r.items() if "attn_window" in k or "chan_attn" in k or "attn_plain" in k}
     except AssertionError as e:
         out["kernel_checks"] = {"failed": str(e)[:500]}
         ok = False
-    for names in (("window_attn_v2",), ("chan_apply_mfma",), ("window_attn_v2", "chan_apply_mfma")):
-        for n in ("window_attn_v2", "chan_apply_mfma"):
+    ALL = ("window_attn_v2", "chan_apply_mfma", "mha_v2")
+    for names in tuple((n,) for n in ALL) + (ALL,):
+        for n in ALL:
             setattr(Florence2Captioner, n, n in names)
         try:
             rec, cap = G.check_captioner_real_crops(R=768, n=4, seed=0)

@@ -1,7 +1,7 @@
 #!/usr/bin/env bash
 # Round-4 opening GPU session (one gpurun call, ~25 GPU-minutes).  Round 3 ended with three things unmeasured:
-#   A. two candidate kernels that have only run on the host emulation (window attention v2, channel-attention apply on the matrix
-#      pipe: Florence2Captioner.window_attn_v2 / chan_apply_mfma) -> hardware parity, per-op A/B, bench A/B
+#   A. three candidate kernels that have only run on the host emulation (window attention v2, channel-attention apply on the matrix
+#      pipe, encoder attention v2: Florence2Captioner.window_attn_v2 / chan_apply_mfma / mha_v2) -> hardware parity, per-op A/B, bench A/B
 #   B. the hardware-queue cliff (one encode lane + the decode stream at GPU_MAX_HW_QUEUES=8: 1034 instead of 709 ms per step)
 #      -> kernel trace of the slow and the fast case, per-queue gap summary (tools/hwq_gaps.py)
 #   C. the suite and the default bench line at the round-3 final commit on a fresh box (what the driver recorded at round end)
@@ -27,13 +27,13 @@ except Exception as e:
     print("no report:", e)
 PY
 echo "=== A2. per-op profile of one 128-crop plan: default, each candidate, both"
-for f in "" "window_attn_v2" "chan_apply_mfma" "window_attn_v2,chan_apply_mfma"; do
+for f in "" "window_attn_v2" "chan_apply_mfma" "mha_v2" "window_attn_v2,chan_apply_mfma,mha_v2"; do
   tag=${f:-default}; tag=${tag//,/+}
   ( timeout 200 python tools/caption_profile.py 128 768 2 $f > "$OUT/per_op_$tag.json" 2> "$OUT/per_op_$tag.txt"; echo "$tag exit $?" )
   grep -E "^--- encode|attn_rows|chan_attn" "$OUT/per_op_$tag.txt" | head -12
 done
-echo "=== A3. bench A/B (K = 6): default, both candidates"
-for f in "" "window_attn_v2,chan_apply_mfma"; do
+echo "=== A3. bench A/B (K = 6): default, all candidates"
+for f in "" "window_attn_v2,chan_apply_mfma,mha_v2"; do
   tag=${f:-default}; tag=${tag//,/+}
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra ${f:+--candidates $f} > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
