@@ -56,3 +56,32 @@ def emu():
     from emu_runtime import emulated_device
     with emulated_device() as L:
         yield L
+
+
+def small_vocab_caption_checkpoint(seed=0, vocab=8192):
+    """The stand-in caption checkpoint with its token table cut to the first `vocab` rows (every prompt id is < 6191): same DaViT / BART
+    weights, an lm_head of 8192 instead of 51290 rows.  For the EMULATED tests that compare the device path with itself (merged vs
+    per-micro-batch decode, C entry points vs Python objects, pipelined vs synchronous stream): a 128-row lm_head tile over the full table
+    costs the host emulation 15 G multiply-adds per decode step, 6x what those tests need.  Tests against transformers use the full one."""
+    import json
+    from safetensors.torch import load_file, save_file
+    from tools.make_weights import caption_dir, ensure_caption_checkpoint
+    src = ensure_caption_checkpoint(seed)
+    dst = src.with_name(src.name + f"_vocab{vocab}")
+    if not (dst / "model.safetensors").exists():
+        dst.mkdir(parents=True, exist_ok=True)
+        sd = load_file(str(src / "model.safetensors"))
+        full = sd["model.language_model.shared.weight"].shape[0]
+        out = {}
+        for k, v in sd.items():
+            if v.dim() == 2 and v.shape[0] == full:                      # the (tied) token table
+                v = v[:vocab].contiguous()
+            elif "final_logits_bias" in k and v.shape[-1] == full:
+                v = v[..., :vocab].contiguous()
+            out[k] = v
+        save_file(out, str(dst / "model.safetensors"))
+        cfg = json.loads((src / "config.json").read_text())
+        cfg.setdefault("text_config", {})["vocab_size"] = vocab
+        (dst / "config.json").write_text(json.dumps(cfg))
+        (dst / "generation_config.json").write_text((src / "generation_config.json").read_text())
+    return dst

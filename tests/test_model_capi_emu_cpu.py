@@ -53,7 +53,8 @@ def test_captioner_bundle_through_c_entry_points(emu, tmp_path):
     from omniparser_amd.florence import Florence2Captioner
     from omniparser_amd.synth import synthetic_screenshot
     from tools.make_weights import ensure_caption_checkpoint
-    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    from conftest import small_vocab_caption_checkpoint        # 8192-row token table: see its docstring
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     img = synthetic_screenshot(1, 640, 480)
     boxes = [[10, 20, 60, 70], [300, 200, 340, 260], [500, 100, 620, 140]]
     max_new = 2                                   # the emulation pays ~15 G multiply-adds per lm_head step

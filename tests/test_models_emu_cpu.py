@@ -85,7 +85,8 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
     from tools.make_weights import ensure_blob, ensure_caption_checkpoint
     monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")                 # proven in the detector test above
     det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
-    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    from conftest import small_vocab_caption_checkpoint        # 8192-row token table: see its docstring
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     frames = [torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in (0, 2)]
     ocr = [synthetic_ocr(0, 640, 480, 12), ([], [])]                                  # second frame without OCR
     kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)
@@ -130,7 +131,8 @@ def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):
     monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
     monkeypatch.setenv("OMNI_DEVICE_GLUE", "0")
     det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
-    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    from conftest import small_vocab_caption_checkpoint        # 8192-row token table: see its docstring
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
 
     def fingerprint(cp, n, max_new, defer=False):
         x = cp.x_in.t[:n, :, :, :3].double()
@@ -171,7 +173,8 @@ def test_parse_stream_device_handoff_equals_parse_batch(emu, monkeypatch):
     monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
     monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
     det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=0.25), device="cuda", precision="f32")
-    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    from conftest import small_vocab_caption_checkpoint        # 8192-row token table: see its docstring
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     slots_used = []
 
     def fake_plans(B, R, max_new, slot=0):
@@ -224,7 +227,8 @@ def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
     from omniparser_amd.pipeline import ScreenParser
     from omniparser_amd.synth import synthetic_screenshot
     from tools.make_weights import ensure_caption_checkpoint
-    cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    from conftest import small_vocab_caption_checkpoint        # 8192-row token table: see its docstring
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     monkeypatch.setattr(Florence2Captioner, "decode_bucket", staticmethod(lambda n: 8))       # a 128-row lm_head step costs the emulation minutes
     import omniparser_amd.florence as FL
     monkeypatch.setattr(FL, "_BUCKETS", (2, 128))                                            # 2-row encode plans for the 2-crop micro-batches
