@@ -26,9 +26,10 @@ def hf_reference(model, pixel_values, max_new_tokens=20):
 
 def build_cpu_plans(weights_dir, B, R, dtype=L.F32, max_new=20):
     """_CaptionPlans on CPU tensors (no kernels run) for the interpreter."""
+    # every plan-composition switch of the class (its bool class attributes), so a new switch cannot be forgotten here
+    switches = {k: v for k, v in vars(FL.Florence2Captioner).items() if isinstance(v, bool)}
     cap = SimpleNamespace(w=FL.FlorenceWeights(weights_dir), device=torch.device("cpu"), dtype=dtype, _wcache={},
-                          use_graph=False, stream=None, fuse_dwln=FL.Florence2Captioner.fuse_dwln,
-                          attn_split_out=FL.Florence2Captioner.attn_split_out, fuse_mlp=FL.Florence2Captioner.fuse_mlp)
+                          use_graph=False, stream=None, **switches)
     cp = FL._CaptionPlans(cap, B, R, max_new)
     return cap, cp
 
