@@ -43,7 +43,7 @@ def compile_dir(src_dir: Path, stem: str, work: Path):
 
 def demangle(names):
     r = subprocess.run(["c++filt"], input="\n".join(names), capture_output=True, text=True)
-    return [n.split("(")[0].replace("(anonymous namespace)::", "") for n in r.stdout.strip().split("\n")] if r.returncode == 0 else names
+    return [n.replace("(anonymous namespace)::", "").split("(")[0] for n in r.stdout.strip().split("\n")] if r.returncode == 0 else names
 
 
 def main():
