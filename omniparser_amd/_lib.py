@@ -131,6 +131,45 @@ def require_device(device, what):
     return device
 
 
+class DeviceLock:
+    """The launch lock of a model (its plans own their device buffers: one inference at a time per model).  Entering it also makes
+    the model's GPU the calling thread's current HIP device: the current device is per thread and every new thread starts on
+    device 0, so a web-server worker or a pipeline helper thread driving a model on cuda:k (one process per GPU under torchrun
+    addresses its GPU as cuda:LOCAL_RANK) would otherwise launch this library's kernels with the wrong device current.  torch's own
+    ops guard themselves from their tensors; the ctypes launches have nothing but this.  The previous device is restored on exit."""
+
+    def __init__(self, device, reentrant=False):
+        import threading
+        import torch
+        self._torch = torch
+        self._lock = threading.RLock() if reentrant else threading.Lock()
+        self._index = device.index if getattr(device, "type", None) == "cuda" else None
+        self._local = threading.local()          # per thread: stack of the devices to restore (the reentrant lock nests)
+
+    def __enter__(self):
+        self._lock.acquire()
+        prev = None
+        if self._index is not None:
+            cur = self._torch.cuda.current_device()
+            if cur != self._index:
+                self._torch.cuda.set_device(self._index)
+                prev = cur
+        stack = getattr(self._local, "stack", None)
+        if stack is None:
+            stack = self._local.stack = []
+        stack.append(prev)
+        return self
+
+    def __exit__(self, *exc):
+        prev = self._local.stack.pop()
+        try:
+            if prev is not None:
+                self._torch.cuda.set_device(prev)
+        finally:
+            self._lock.release()
+        return False
+
+
 def check(rc: int):
     if rc != 0:
         raise OmniError(f"libomni_amd error {rc}: {lib().omni_last_error().decode()}")

@@ -9,7 +9,6 @@ on the path and no CPU fallback.
 import json
 import math
 import os
-import threading
 from pathlib import Path
 from types import SimpleNamespace
 from typing import Dict, List, Optional
@@ -557,7 +556,7 @@ class Florence2Captioner:
         self.max_new_tokens = 20
         self.early_exit_every = 5        # poll the all-rows-finished flag every N decode steps (0 = always run max_new_tokens steps)
         self._lut = None
-        self._lock = threading.RLock()   # plans own their device buffers: one caption batch at a time per model
+        self._lock = L.DeviceLock(self.device, reentrant=True)   # one caption batch at a time per model; makes this GPU the thread's current device
 
     def to(self, *a, **k):
         return self

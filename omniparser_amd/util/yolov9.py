@@ -9,7 +9,6 @@ libomni_amd.so the constructor raises.
 """
 import math
 import os
-import threading
 from pathlib import Path
 from typing import Union
 
@@ -166,7 +165,7 @@ class YOLOv9Detector:
         self.stream = torch.cuda.Stream(device=self.device)
         self._wcache = {}
         self._plans = {}
-        self._lock = threading.Lock()   # plans own their device buffers: one inference at a time per detector
+        self._lock = L.DeviceLock(self.device)   # one inference at a time per detector; makes this GPU the thread's current device
         self.model = self   # callers touch `.model` only to move devices
         self.import_rel_err = None      # largest relative head difference blob vs lowered network on the probe (None = check skipped)
         if os.environ.get("OMNI_VERIFY_IMPORT", "1") != "0":

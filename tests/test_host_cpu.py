@@ -340,3 +340,42 @@ def test_hwq_gap_summary_on_a_synthetic_trace():
     assert r["per_queue"]["1"]["gaps_over_50us"] == 1 and abs(r["per_queue"]["1"]["gap_ms"] - 0.2) < 1e-9
     assert r["per_queue"]["2"]["streams"] == ["5"] and r["per_queue"]["2"]["launches"] == 2
     assert list(r["idle_before_kernel_family_ms"]) == ["attn_decode_cross_kernel", "gemm_dma_kernel"]
+
+
+def test_device_lock_makes_the_models_gpu_current_in_every_thread(monkeypatch):
+    """A model's launch lock (L.DeviceLock) sets the calling thread's current HIP device to the model's GPU and restores it: worker
+    threads start on device 0, one process per GPU addresses its GPU as cuda:LOCAL_RANK.  torch.cuda is replaced by a per-thread
+    stand-in (no GPU here)."""
+    import threading
+    import torch
+    from omniparser_amd import _lib as L
+    cur = threading.local()
+    calls = []
+    monkeypatch.setattr(torch.cuda, "current_device", lambda: getattr(cur, "d", 0))
+    monkeypatch.setattr(torch.cuda, "set_device", lambda d: (calls.append((threading.current_thread().name, d)), setattr(cur, "d", d)))
+    lock = L.DeviceLock(torch.device("cuda", 3), reentrant=True)
+    seen = {}
+
+    def worker():
+        with lock:
+            seen["inside"] = torch.cuda.current_device()
+            with lock:                                   # reentrant: the nested entry finds the device already current
+                seen["nested"] = torch.cuda.current_device()
+            seen["after_nested"] = torch.cuda.current_device()
+        seen["after"] = torch.cuda.current_device()
+
+    t = threading.Thread(target=worker, name="w")
+    t.start(); t.join()
+    assert seen == {"inside": 3, "nested": 3, "after_nested": 3, "after": 0}
+    assert calls == [("w", 3), ("w", 0)]
+    calls.clear()
+    cur.d = 3                                            # a thread already on the model's device: no device calls at all
+    with lock:
+        pass
+    assert calls == []
+    with L.DeviceLock(torch.device("cpu")):              # emulated / CPU stand-in models: a plain lock
+        pass
+    assert calls == []
+    plain = L.DeviceLock(torch.device("cuda", 1))
+    with plain:
+        assert not plain._lock.acquire(blocking=False)   # non-reentrant flavour really excludes
