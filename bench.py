@@ -249,6 +249,7 @@ def main():
         out["config"]["decode"] = ("one 20-step decode over all crops of the batch (cross-attention K/V of every micro-batch copied into one plan)"
                                    if os.environ.get("OMNI_MERGED_DECODE", "1") != "0" else "per micro-batch")
         out["config"]["hand_off"] = "device (detector + hand-off ops in one hipGraph)" if getattr(parser, "device_glue", False) else "host"
+    out["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # plans + weights of this process (torch allocator)
 
     if rank == 0:
         # the timed result above is final: nothing below may keep the JSON line from being printed

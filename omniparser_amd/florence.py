@@ -245,6 +245,7 @@ class _CaptionPlans(_StepPlans):
         sd = w.sd
         self.B, self.R, self.T = B, R, max_new + 1
         pb = PlanBuilder(dev, dt)
+        pb.reuse = bool(cap.reuse_activations)
         self.pb = pb
         V = pb.V
         wc = cap._wcache
@@ -351,7 +352,7 @@ class _CaptionPlans(_StepPlans):
         x = self.x_in
         vt = "model.vision_tower."
         self.chan_ws = None
-        self.stage_out = []          # output of every DaViT stage (stays valid after the encode plan: each stage owns its buffers)
+        self.stage_out = []          # output of every DaViT stage (valid after the encode plan unless cap.reuse_activations: each stage owns its buffers)
         for s in range(4):
             C = w.embed_dim[s]
             grp["dma"] = use_dma and C % 128 == 0
@@ -364,6 +365,7 @@ class _CaptionPlans(_StepPlans):
                 cur = pb.alloc(B, Ho, Ho, C)
                 wp, bp = packed(conv_key, lambda ck=conv_key: (sd[ck + ".weight"], sd[ck + ".bias"]))
                 pb.conv(xn, wp, bp, cur, k, st, pd)
+                pb.release(xn, *([] if x is self.x_in else [x]))   # reuse_activations: the previous stage's output has had its last reader
             else:
                 t0 = pb.alloc(B, Ho, Ho, C)
                 ck2 = (conv_key, dt, "pad")
@@ -373,6 +375,7 @@ class _CaptionPlans(_StepPlans):
                 pb.conv(x, wp, bp, t0, k, st, pd)
                 cur = pb.alloc(B, Ho, Ho, C)
                 layernorm(f"{vt}convs.{s}.norm", t0, cur)
+                pb.release(t0)               # (x is the plan's input here: the crop kernels write it, never released)
             H = Ho
             N = H * H
             A_, B_ = cur, pb.alloc(B, H, H, C)
@@ -424,6 +427,8 @@ class _CaptionPlans(_StepPlans):
                     linear(pre + "ffn.fc2", ffn, A_, res=A_)
             x = A_
             self.stage_out.append(A_)
+            # reuse_activations: the stage's scratch tensors back the (smaller) tensors of the next stages
+            pb.release(B_, hbuf, qkv, att, ffn, cws)
         self.vision_out = x
         grp["dma"] = use_dma
         # ---------------- projector
@@ -537,6 +542,10 @@ class Florence2Captioner:
                               # of the next keys in flight under the arithmetic, one barrier per 64 keys), 32x32x16 MFMAs, a lazily moved softmax
                               # reference (csrc/caption_ops.hip::mha_mfma_f32_v2_kernel); A/B: tools/r4_open.sh
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
+    reuse_activations = False  # CANDIDATE (same kernels, same order, different addresses; not run on the MI355X yet): scratch tensors of a
+                              # DaViT stage are released at its end and back the tensors of the later stages (PlanBuilder.release) —
+                              # a 128-crop plan at 768x768 holds ~0.2 GB per crop instead of ~0.4; with it `stage_out[:3]` are no
+                              # longer valid after the encode plan (the bisection taps of tools/r3_bisect.py need it off)
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
         device = L.require_device(device, "Florence2Captioner")

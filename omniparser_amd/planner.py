@@ -88,20 +88,65 @@ class PlanBuilder:
         self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
+        self.reuse = False       # lifetime reuse of released scratch tensors (see `release`)
+        self._free, self._released, self._pins = [], set(), []
+        self.reused_bytes = 0    # bytes handed out from released tensors instead of fresh allocations
         self.flops = 0           # 2*MAC of all conv ops (algorithmic work, for the roofline)
         self.bytes = 0           # algorithmic HBM bytes (each operand read once, output written once)
 
     # ---- memory
     def alloc(self, B, H, W, C, zero=False) -> View:
+        tdt = torch_dtype(self.dtype)
+        if not zero:
+            t = self._from_free((B, H, W, C), tdt)
+            if t is not None:
+                return View(t, 0, C)
         fn = torch.zeros if zero else torch.empty
-        t = fn((B, H, W, C), dtype=torch_dtype(self.dtype), device=self.device)
+        t = fn((B, H, W, C), dtype=tdt, device=self.device)
         self.keep.append(_register(t, "zero" if zero else "scratch"))
         return View(t, 0, C)
 
     def raw(self, shape, dtype, zero=True) -> torch.Tensor:
+        if not zero:
+            t = self._from_free(tuple(shape), dtype)
+            if t is not None:
+                return t
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
         self.keep.append(_register(t, "zero" if zero else "scratch"))
         return t
+
+    # Lifetime reuse of scratch tensors (`reuse = True`; off unless the plan's author turns it on).  Ops of a plan run in program
+    # order on ONE stream, so a scratch tensor whose last reader has been added to the plan may back any tensor allocated later:
+    # `release` returns its bytes to a free list, `alloc` / `raw` (zero=False) carve the best-fitting free block (256-byte granules,
+    # the rest of the block stays free).  Only whole registered tensors ever enter the list, so the registry above (plan export)
+    # keeps seeing each address range once; a carved tensor is a view of the block it came from.
+    def release(self, *tensors):
+        if not self.reuse:
+            return
+        for t in tensors:
+            t = t.t if isinstance(t, View) else t
+            if t is None or id(t) in self._released or t.numel() == 0:
+                continue
+            self._released.add(id(t))
+            self._pins.append(t)                       # keeps id(t) unique for the lifetime of the builder
+            nbytes = t.numel() * t.element_size() // 256 * 256
+            if nbytes:
+                self._free.append((t.view(-1).view(torch.uint8)[:nbytes], nbytes))
+
+    def _from_free(self, shape, dtype):
+        if not self.reuse or not self._free:
+            return None
+        need = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        cand = [(nb, k) for k, (_, nb) in enumerate(self._free) if nb >= need]
+        if not cand or need == 0:
+            return None
+        nb, k = min(cand)
+        block, _ = self._free.pop(k)
+        rest = (nb - need) // 256 * 256
+        if rest:
+            self._free.append((block[nb - rest:], rest))
+        self.reused_bytes += need
+        return block[:need].view(dtype).view(shape)
 
     def upload(self, host_tensor: torch.Tensor) -> torch.Tensor:
         t = host_tensor.contiguous().to(self.device)

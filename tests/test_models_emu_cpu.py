@@ -72,6 +72,21 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     assert G.rel_err(cp3.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
     assert G.rel_err(cp3.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
     assert G.rel_err(cp3.enc_out.t[:1, :, 0, :].float(), cp.enc_out.t[:1, :, 0, :].float()) < 2e-5
+    # Florence2Captioner.reuse_activations (candidate): the default kernels on aliased scratch buffers (a stage's tensors back the later
+    # stages') — the same ops in the same order on the same data: features and encoder output bit for bit those of the default plan
+    monkeypatch.undo()
+    cp1 = cap.plans(1, 64, max_new)              # the default composition at the same row count (tile choices follow the row count)
+    monkeypatch.setattr(Florence2Captioner, "reuse_activations", True)
+    cap4 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cp4 = cap4.plans(1, 64, max_new)
+    assert cp4.pb.reused_bytes > 0 and cp1.pb.reused_bytes == 0
+    with torch.inference_mode():
+        for c, p in ((cap, cp1), (cap4, cp4)):
+            p.reset()
+            p.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
+            p.encode_plan.run(c.stream)
+    assert torch.equal(cp4.img_feat.t, cp1.img_feat.t) and torch.equal(cp4.enc_out.t, cp1.enc_out.t)
+    assert all(torch.equal(a.t, b.t) for a, b in zip(cp4.cross_kv, cp1.cross_kv))
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):

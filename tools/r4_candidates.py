@@ -1,6 +1,6 @@
 """Hardware check of the candidate kernels written after round 3's last GPU minute (Florence2Captioner.window_attn_v2 /
-chan_apply_mfma / mha_v2: csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel, chan_apply_mfma_split_kernel, mha_mfma_f32_v2_kernel) — they have only run on the host
-emulation.  (1) the kernel-level checks of tests/gpu_checks.py with both variants of each op, (2) per candidate and for both together:
+chan_apply_mfma / mha_v2: csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel, chan_apply_mfma_split_kernel, mha_mfma_f32_v2_kernel) and of the
+scratch-tensor reuse (Florence2Captioner.reuse_activations) — they have only run on the host emulation.  (1) the kernel-level checks of tests/gpu_checks.py with both variants of each op, (2) per candidate and for both together:
 real 768x768 crops through a caption plan against transformers on the CPU (features, encoder output, step-1 logits, token-exact ids).
 usage (GPU box): python tools/r4_candidates.py > gpurun_out/r4/candidates.json      exit code 0 = every check passed"""
 import json
@@ -23,8 +23,9 @@ def main():
     except AssertionError as e:
         out["kernel_checks"] = {"failed": str(e)[:500]}
         ok = False
-    ALL = ("window_attn_v2", "chan_apply_mfma", "mha_v2")
-    for names in tuple((n,) for n in ALL) + (ALL,):
+    KERNELS = ("window_attn_v2", "chan_apply_mfma", "mha_v2")
+    ALL = KERNELS + ("reuse_activations",)        # reuse_activations: the shipped kernels on aliased scratch tensors (PlanBuilder.release)
+    for names in tuple((n,) for n in ALL) + (KERNELS, ALL):
         for n in ALL:
             setattr(Florence2Captioner, n, n in names)
         try:

@@ -33,7 +33,7 @@ for f in "" "window_attn_v2" "chan_apply_mfma" "mha_v2" "window_attn_v2,chan_app
   grep -E "^--- encode|attn_rows|chan_attn" "$OUT/per_op_$tag.txt" | head -12
 done
 echo "=== A3. bench A/B (K = 6): default, all candidates"
-for f in "" "window_attn_v2,chan_apply_mfma,mha_v2"; do
+for f in "" "window_attn_v2,chan_apply_mfma,mha_v2" "reuse_activations"; do   # reuse_activations: same kernels on aliased scratch (config.hbm_peak_allocated_gb)
   tag=${f:-default}; tag=${tag//,/+}
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra ${f:+--candidates $f} > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
@@ -41,7 +41,8 @@ import json, sys
 try:
     d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
     r = d["roofline"]
-    print("   ", d["value"], "screenshots/s", d["ms_per_step"], "ms/step; gemm", r.get("gemm_ms_per_step"), "non-gemm share", r.get("non_gemm_share"))
+    print("   ", d["value"], "screenshots/s", d["ms_per_step"], "ms/step; gemm", r.get("gemm_ms_per_step"), "non-gemm share", r.get("non_gemm_share"),
+          "HBM peak", d["config"].get("hbm_peak_allocated_gb"), "GB")
     print("   ", r.get("kernel_family_ms_per_step"))
 except Exception as e:
     print("    no line:", e)
