@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
-                    "(window_attn_v2, chan_apply_mfma: kernels not adopted yet); recorded in config.candidates")
+                    "or PlanBuilder (window_attn_v2, chan_apply_mfma, mha_v2, reuse_activations, fuse_splitk: not adopted yet); recorded in config.candidates")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
     a = ap.parse_args()
     if a.batch is None:
@@ -90,6 +90,9 @@ def main():
     from omniparser_amd.util.yolov9 import YOLOv9Detector
     from tools.make_weights import caption_dir, default_path, ensure_via_subprocess   # imports nothing from oracle/
 
+    if args.candidates:
+        from tools import switch_on
+        switch_on(args.candidates.split(","))          # A/B only: boolean switches of Florence2Captioner / PlanBuilder, off by default
     rank, world, local_rank = OD.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
     torch.cuda.set_device(local_rank)
@@ -119,9 +122,6 @@ def main():
     if args.mode == "e2e":
         from omniparser_amd.florence import Florence2Captioner
         from omniparser_amd.pipeline import ScreenParser
-        for name in filter(None, args.candidates.split(",")):
-            assert isinstance(getattr(Florence2Captioner, name, None), bool), f"--candidates: unknown composition switch {name}"
-            setattr(Florence2Captioner, name, True)
         cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
         parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
         parser.encode_lanes = args.lanes
@@ -240,8 +240,6 @@ def main():
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
-        if args.candidates:
-            out["config"]["candidates"] = args.candidates.split(",")
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
         if args.pipeline:
             out["config"]["pipeline"] = ("parse_stream: detector + hand-off graph of step i+1 on the detector's stream, caption micro-batches alternating "
@@ -249,6 +247,8 @@ def main():
         out["config"]["decode"] = ("one 20-step decode over all crops of the batch (cross-attention K/V of every micro-batch copied into one plan)"
                                    if os.environ.get("OMNI_MERGED_DECODE", "1") != "0" else "per micro-batch")
         out["config"]["hand_off"] = "device (detector + hand-off ops in one hipGraph)" if getattr(parser, "device_glue", False) else "host"
+    if args.candidates:
+        out["config"]["candidates"] = args.candidates.split(",")
     out["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # plans + weights of this process (torch allocator)
 
     if rank == 0:

@@ -38,7 +38,9 @@ struct ConvArgs {
   int Cout, ldo, out_coff, act, ldr, res_coff;
   int M, K, ktiles, cin_tiles;
   int splits, kt_per_split, mtiles, ntiles, xcd_order, xcd_n;
-  float* ws; long long ws_bytes;
+  float* ws;
+  unsigned* cnt;          // split-K tickets per output tile (zero between launches) — only read by the FR = true kernels below.  (This slot
+                          // held the host-only workspace size until the FR variant: the kernel arguments of every other kernel are unchanged.)
   float scale;
 };
 
@@ -351,7 +353,14 @@ __device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& 
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
-template <int BM, int BN, int NW, bool PW>
+// FR (candidate, off by default — op p[6] / PlanBuilder.fuse_splitk): split-K WITHOUT the second launch.  Every split writes its
+// partial tile to the workspace as before, then takes a ticket of its output tile (device-scope atomic behind a release fence); the
+// split that draws the last ticket adds up ALL partials of the tile from the workspace in the fixed order z = 0 .. splits - 1 and
+// applies bias / scale / activation / residual — instruction for instruction the arithmetic of splitk_reduce_kernel, so the result
+// is bit-identical to the two-launch path whichever split finishes last.  It also leaves the ticket counter at zero for the next
+// launch (hipGraph replays included).  What it saves is a launch per split-K conv: ~230 of the batch-1 detector's ~500 kernels
+// (4.5 ms for 189 GFLOP: launch-bound) and 36 of a decode step's ~110.
+template <int BM, int BN, int NW, bool PW, bool FR = false>
 __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
   // NW waves as 2 (M) x NW/2 (N)
   constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
@@ -514,6 +523,35 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
         }
       }
     }
+    if constexpr (FR) {
+      __shared__ int s_last;
+      __threadfence();                                   // release: this split's partials are visible device-wide before its ticket
+      __syncthreads();
+      if (tid == 0) {
+        unsigned* c = a.cnt + (mt * a.ntiles + nt);
+        const bool last = atomicAdd(c, 1u) + 1u == (unsigned)a.splits;
+        if (last) *c = 0u;                               // every split of the tile has drawn: zero again for the next launch
+        s_last = last ? 1 : 0;
+      }
+      __syncthreads();
+      if (!s_last) return;
+      __threadfence();                                   // acquire: the other splits' partials (written by other CUs, through L2)
+      const long long total = (long long)a.M * a.Cout;
+      const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
+      float* __restrict__ Y = reinterpret_cast<float*>(a.y);
+      for (int e = tid; e < BM * BN; e += NW * 64) {
+        const int m = m0 + e / BN, n = n0 + e % BN;
+        if (m >= a.M || n >= a.Cout) continue;
+        const long long idx = (long long)m * a.Cout + n;
+        float v = 0.0f;
+        for (int z = 0; z < a.splits; ++z) v += a.ws[(long long)z * total + idx];
+        v += a.bias ? a.bias[n] : 0.0f;
+        if (a.scale != 0.0f) v *= a.scale;
+        v = act_apply(v, a.act);
+        if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
+        Y[(long long)m * a.ldo + a.out_coff + n] = v;
+      }
+    }
     return;
   }
   auto run = [&](auto tag) {
@@ -545,6 +583,12 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   // 128x128: 8 waves (64x32 per wave, 4 waves/SIMD; measured 191-229 TF/s vs 172-209 for 4 waves of 64x64); smaller
   // tiles: 4 waves.  Round-1 variants that lost (two-slice register prefetch, weights straight to registers, 256x128,
   // 64-wide K slices, weight-only LDS-DMA) are recorded in DESIGN.md and profiles/r2_gemm_diag.md, not kept here.
+  constexpr int NWV = (BM == 128 && BN == 128) ? 8 : 4;
+  if (a.splits > 1 && a.cnt) {      // candidate: the split that finishes last reduces (see conv_split_kernel, FR)
+    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, NWV, true, true>), grid, dim3(NWV * 64), 0, s, a);
+    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, NWV, false, true>), grid, dim3(NWV * 64), 0, s, a);
+    return;
+  }
   if constexpr (BM == 128 && BN == 128) {
     if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false>), grid, dim3(512), 0, s, a);
@@ -558,7 +602,7 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   }
 }
 
-void launch_split(ConvArgs& a, hipStream_t s) {
+void launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s) {
   a.cin_tiles = a.Cin / 32;
   a.ktiles = a.K / 32;
   // 128x128 at 2 waves/SIMD is the fastest split tile (measured 171-207 TF/s vs 128-165 for 128x64); the
@@ -573,7 +617,7 @@ void launch_split(ConvArgs& a, hipStream_t s) {
     int want = (int)((768 + nb - 1) / nb);
     int maxs = a.ktiles / 4;
     if (maxs > 32) maxs = 32;
-    long long cap = a.ws_bytes / ((long long)a.M * a.Cout * 4);
+    long long cap = ws_bytes / ((long long)a.M * a.Cout * 4);
     if (maxs > cap) maxs = (int)cap;
     a.splits = want < maxs ? want : maxs;
     if (a.splits < 2) a.splits = 1;
@@ -611,7 +655,7 @@ struct ConvCfg { int bm, bn, rb, splits, kt_per_split, ktiles, cin_tiles; bool a
 // latency only with >= 3-4 waves per SIMD, i.e. >= ~1024 four-wave workgroups in flight, so small-M
 // layers (P4/P5 at batch 1: M = 1600 / 400) are split along K.
 template <typename T>
-ConvCfg choose_cfg(const ConvArgs& a) {
+ConvCfg choose_cfg(const ConvArgs& a, long long ws_bytes) {
   constexpr int V = ElemTraits<T>::kVec;
   ConvCfg c;
   c.rb = (a.Cin % (8 * V) == 0) ? 128 : 64;
@@ -641,7 +685,7 @@ ConvCfg choose_cfg(const ConvArgs& a) {
     int want = (int)((1024 + nb - 1) / nb);
     int maxs = c.ktiles / 4;                 // keep >= 4 K slices per split
     if (maxs > 32) maxs = 32;
-    long long cap = a.ws_bytes / ((long long)a.M * a.Cout * 4);
+    long long cap = ws_bytes / ((long long)a.M * a.Cout * 4);
     if (maxs > cap) maxs = (int)cap;
     c.splits = want < maxs ? want : maxs;
     if (c.splits < 2) c.splits = 1;
@@ -652,8 +696,8 @@ ConvCfg choose_cfg(const ConvArgs& a) {
 }
 
 template <typename T>
-void launch_typed(ConvArgs& a, hipStream_t s) {
-  ConvCfg c = choose_cfg<T>(a);
+void launch_typed(ConvArgs& a, long long ws_bytes, hipStream_t s) {
+  ConvCfg c = choose_cfg<T>(a, ws_bytes);
   a.cin_tiles = c.cin_tiles; a.ktiles = c.ktiles; a.splits = c.splits; a.kt_per_split = c.kt_per_split;
   if (c.rb == 128) {
     if (c.bm == 128 && c.bn == 128) launch_cfg<T, 128, 128, 128>(a, c.aligned, s);
@@ -677,7 +721,9 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   a.ldr = op->i[16]; a.res_coff = op->i[17];
   a.scale = op->f[0];
   a.ws = (float*)op->p[5];
-  a.ws_bytes = a.ws ? (long long)op->i[19] * 1024 : 0;   // i19 = workspace size in KiB
+  const long long ws_bytes = a.ws ? (long long)op->i[19] * 1024 : 0;   // i19 = workspace size in KiB
+  a.cnt = (unsigned*)op->p[6];                           // candidate: split-K tickets (i22 counters, zero) -> no reduce launch (split-f16 path)
+  OMNI_REQUIRE(!a.cnt || op->i[22] >= 512, "conv: the split-K ticket buffer holds %d counters, needs >= 512", op->i[22]);
   a.splits = 1; a.kt_per_split = 0;
   const int V = op->dtype == OMNI_F32 ? 4 : 8;
   OMNI_REQUIRE(op->dtype == OMNI_F32 || op->dtype == OMNI_F16, "conv: bad dtype %d", op->dtype);
@@ -693,9 +739,9 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   a.K = a.KH * a.KW * a.Cin;
   if (op->i[20]) {        // split-f16 weights ([Cout][K/16][16 hi | 16 lo]) + f32 activations
     OMNI_REQUIRE(op->dtype == OMNI_F32 && a.Cin % 32 == 0, "conv: split-f16 mode needs f32 activations and Cin %% 32 == 0");
-    launch_split(a, s);
-  } else if (op->dtype == OMNI_F32) launch_typed<float>(a, s);
-  else launch_typed<half_t>(a, s);
+    launch_split(a, ws_bytes, s);
+  } else if (op->dtype == OMNI_F32) launch_typed<float>(a, ws_bytes, s);
+  else launch_typed<half_t>(a, ws_bytes, s);
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
 }

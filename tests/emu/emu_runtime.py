@@ -62,7 +62,9 @@ def emulated_device(env=None):
     import build_emu
     from omniparser_amd import _lib as L
     # the product has no emulation switch: the test suite swaps the bound library and the device gate of omniparser_amd._lib
+    from omniparser_amd import planner
     prev = (L._lib, L.require_device)
+    prev_ws, planner.PlanBuilder.workspace_on_host = planner.PlanBuilder.workspace_on_host, True      # split-K launches as on the GPU
     L._lib = L.bind(build_emu.build())
     L.require_device = lambda device, what: torch.device("cpu")
     saved = {k: getattr(torch.cuda, k) for k in ("is_available", "current_device", "synchronize", "Stream", "Event", "stream", "device",
@@ -96,3 +98,4 @@ def emulated_device(env=None):
         for k, v in saved.items():
             setattr(torch.cuda, k, v)
         L._lib, L.require_device = prev
+        planner.PlanBuilder.workspace_on_host = prev_ws

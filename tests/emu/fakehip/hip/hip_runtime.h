@@ -294,6 +294,7 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 
+inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }       // blocks run on concurrent host threads: a real fence
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline float atomicAdd(float* p, float v) {

@@ -98,6 +98,64 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
 
 
 
+FUSED_SPLITK_CASES = [
+    # split-f16 path (Cin % 32 == 0, K >= 128) with few output tiles: the launcher splits along K
+    (1, 20, 20, 1024, 1024, 1, 1, 1024, 0, 1024, 0, False, L.ACT_GELU),   # 7 x 16 tiles of 64x64, 7 splits
+    (1, 20, 20, 512, 200, 3, 1, 512, 0, 256, 32, True, L.ACT_SILU),       # 3x3, ragged N tile, residual, channel-slice output
+    (2, 1, 1, 768, 768, 1, 1, 768, 0, 768, 0, True, L.ACT_NONE),          # a decode-step projection: M = 2
+    (3, 9, 9, 256, 96, 1, 1, 256, 0, 96, 0, False, L.ACT_NONE),
+]
+
+
+def check_conv_fused_splitk(seed=0, cases=None, replays=3):
+    """PlanBuilder.fuse_splitk (candidate): the split that finishes last for an output tile reduces the partials inside the conv
+    kernel.  Against the two-launch path (conv + splitk_reduce_kernel) on the same operands: outputs equal BIT FOR BIT (same
+    summation order whichever split is last), over several launches of the same op (the ticket counters return to zero), and the
+    fused kernel is really the one that ran (with poisoned tickets nobody reduces: the output keeps its fill value)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for case in (cases or FUSED_SPLITK_CASES):
+        B, H, W, Cin, Cout, k, s, ild, ioff, old, ooff, use_res, act = case
+        p = k // 2
+        x = torch.randn(B, Cin, H, W, generator=g)
+        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
+        b = torch.randn(Cout, generator=g)
+        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
+        res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
+        xv = _nhwc(x, torch.float32, ild, ioff)
+        rv = _nhwc(res, torch.float32, Cout + 4, 4) if use_res else None
+        outs = []
+        for fuse in (False, True):
+            pb = PlanBuilder(DEV, L.F32)
+            pb.fuse_splitk = fuse
+            assert pb.split, "the fused reduction lives on the split-f16 path (OMNI_CONV_SPLIT=1)"
+            ov = View(torch.full((B, Ho, Wo, old), 7.0, dtype=torch.float32, device=DEV), ooff, Cout)
+            wp = pb.pack_weight(w)
+            assert getattr(wp, "omni_fmt", 0) == 1, case
+            pb.conv(xv, wp, b, ov, k, s, act=act, res=rv)
+            op = pb.ops[0]
+            assert bool(op.p[6]) == fuse and (op.i[22] >= 512) == fuse
+            for _ in range(replays if fuse else 1):
+                ov.t.fill_(7.0)
+                L.launch(op)
+                _sync()
+                outs.append(ov.t.clone().cpu())
+            if fuse:
+                assert int(pb.cnt.abs().sum()) == 0, f"split-K tickets not back at zero: {case}"
+                pb.cnt.fill_(1 << 20)                    # poisoned tickets: no split ever draws the last one
+                ov.t.fill_(7.0)
+                L.launch(op)
+                _sync()
+                assert (ov.t == 7.0).all(), f"{case}: the output was written although no split could be last - the launcher did not split or did not take the fused kernel"
+                pb.cnt.zero_()
+        ref = outs[0]
+        assert (ref[..., ooff:ooff + Cout] != 7.0).any()
+        for o in outs[1:]:
+            assert torch.equal(o.view(torch.int32), ref.view(torch.int32)), f"fused split-K differs from the two-launch path: {case}"
+        out[str(case)] = "bit-identical x%d" % replays
+    return out
+
+
 # ------------------------------------------------------------------------------------------ pre-split LDS-DMA GEMM
 GEMM_DMA_CASES = [
     # M, K, N, in_ld, in_off, out_ld, out_off, res, act, out_split

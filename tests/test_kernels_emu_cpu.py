@@ -48,6 +48,18 @@ def test_conv_igemm_exact_f32_path(emu, monkeypatch):
     assert r["cases"] >= 6 and r["worst_rel_err"] < 2e-5
 
 
+def test_conv_fused_splitk_is_bit_identical_to_the_two_launch_path(emu):
+    """PlanBuilder.fuse_splitk (candidate, off by default): blocks of a launch run on concurrent host threads here, so the ticket /
+    fence protocol is exercised for real (on x86's memory model; the MI355X check is tools/r4_candidates.py)."""
+    import gpu_checks as G
+    r = G.check_conv_fused_splitk(cases=[
+        (1, 12, 12, 1024, 256, 1, 1, 1024, 0, 256, 0, False, L.ACT_GELU),
+        (1, 10, 10, 512, 200, 3, 1, 512, 0, 256, 32, True, L.ACT_SILU),
+        (2, 1, 1, 768, 768, 1, 1, 768, 0, 768, 0, True, L.ACT_NONE),
+    ], replays=3)
+    assert len(r) == 3
+
+
 def test_gemm_dma_presplit_every_tile(emu):
     import gpu_checks as G
     r = G.check_gemm_dma(cases=SMALL_GEMM_DMA)

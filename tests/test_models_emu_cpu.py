@@ -20,6 +20,31 @@ def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
     assert out["ops"] > 250
 
 
+def test_detector_with_fused_splitk_equals_the_default_plan_bit_for_bit(emu, monkeypatch):
+    """PlanBuilder.fuse_splitk (candidate): every split-K conv of the detector reduces inside the conv kernel (the split that finishes
+    last), no splitk_reduce launch — boxes and scores of a frame equal the default plan's bit for bit, and the plan really holds
+    split-K convs with ticket counters."""
+    from PIL import Image
+    from omniparser_amd.planner import PlanBuilder
+    from omniparser_amd.synth import synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import EXACT_FRAMES, ensure_blob
+    blob = ensure_blob(seed=0, nc=1, width=0.25)
+    pil = Image.fromarray(synthetic_screenshot(EXACT_FRAMES[(0.25, 320)][0], 640, 480))
+    res = []
+    for fuse in (False, True):
+        monkeypatch.setattr(PlanBuilder, "fuse_splitk", fuse)
+        monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
+        det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
+        r = [det.predict(pil, conf=0.05, imgsz=320, iou=0.1)[0] for _ in range(2)][-1]       # second pass: the counters were left at zero
+        dp = det.get_plan(640, 480, 320, 0.05, 0.1, 300)
+        convs = [op for op in dp.plan.ops if op.kind == L.OP_CONV]
+        assert all(bool(op.p[6]) == fuse for op in convs if op.p[5])
+        res.append((r.boxes.xyxy.clone(), r.boxes.conf.clone()))
+    assert res[0][0].shape[0] > 10
+    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
+
+
 def test_captioner_token_exact_r64(emu, monkeypatch):
     """Florence2Captioner.generate (DaViT tower, projector, BART encoder / decoder with KV cache, greedy loop: every captioner kernel)
     vs transformers on the CPU: image features, encoder output, greedy ids.  Three decode steps: a single-row lm_head (768 x 51289,

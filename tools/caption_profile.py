@@ -46,10 +46,8 @@ def main():
     flags = sys.argv[4].split(",") if len(sys.argv) > 4 else []     # "nomlp": fc1 / fc2 of the C = 128 stage as two launches
     if "nomlp" in flags:
         Florence2Captioner.fuse_mlp = False
-    for f in flags:                                                  # candidate kernels: "window_attn_v2", "chan_apply_mfma", ...
-        if f != "nomlp":
-            assert isinstance(getattr(Florence2Captioner, f, None), bool), f"unknown composition switch {f}"
-            setattr(Florence2Captioner, f, True)
+    from tools import switch_on                                      # candidates: "window_attn_v2", "chan_apply_mfma", "fuse_splitk", ...
+    switch_on([f for f in flags if f != "nomlp"])
     ensure_via_subprocess("caption", seed=0)
     cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
     cap.use_graph = False           # eager plans: every op is timed on its own

@@ -72,9 +72,18 @@ def main():
             diff = [k for k in old if k in new and old[k] != new[k]]
             gone = [k for k in old if k not in new]
             added = [k for k in new if k not in old]
+            # a kernel that only gained a (defaulted) template parameter has a new mangled name: identical if its instructions are
+            renamed = {}
+            for k in list(gone):
+                twin = next((n for n in added if new[n] == old[k]), None)
+                if twin is not None:
+                    renamed[k] = twin
+                    gone.remove(k); added.remove(twin); same.append(k)
             total_same += len(same)
             total_diff += len(diff) + len(gone)
             print(f"{stem}.hip: {len(same)} kernels identical, {len(diff)} changed, {len(gone)} removed, {len(added)} added")
+            for a_, b_ in zip(demangle(list(renamed)), demangle(list(renamed.values()))) if renamed else []:
+                print(f"    identical under a new name: {a_} -> {b_}")
             for tag, ks in (("changed", diff), ("removed", gone), ("added", added)):
                 for n in demangle(ks) if ks else []:
                     print(f"    {tag}: {n}")

@@ -23,6 +23,32 @@ def main():
     except AssertionError as e:
         out["kernel_checks"] = {"failed": str(e)[:500]}
         ok = False
+    # PlanBuilder.fuse_splitk: the split that finishes last reduces inside the conv kernel (no splitk_reduce launch) — kernel check
+    # (bit-identical to the two-launch path over repeated launches), then a detector pass (boxes bit-identical to the default plan's)
+    from omniparser_amd.planner import PlanBuilder
+    try:
+        out["fuse_splitk_kernel"] = G.check_conv_fused_splitk(replays=20)
+        from PIL import Image
+        from omniparser_amd.synth import synthetic_screenshot
+        from omniparser_amd.util.yolov9 import YOLOv9Detector
+        from tools.make_weights import ensure_blob
+        blob = ensure_blob(seed=0, nc=1, width=1.0)
+        pil = Image.fromarray(synthetic_screenshot(19, 1920, 1080))
+        res = []
+        for fuse in (False, True):
+            PlanBuilder.fuse_splitk = fuse
+            det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
+            r = [det.predict(pil, conf=0.05, imgsz=640, iou=0.1)[0] for _ in range(3)][-1]      # third pass: graph replays
+            res.append((r.boxes.xyxy.cpu(), r.boxes.conf.cpu()))
+            del det
+        import torch
+        same = bool(torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1]))
+        out["fuse_splitk_detector"] = {"boxes": int(res[0][0].shape[0]), "bit_identical_to_default": same, "passed": same}
+        ok = ok and same
+    except Exception as e:                                         # noqa: BLE001 — report, keep going
+        out["fuse_splitk"] = {"passed": False, "error": repr(e)[:500]}
+        ok = False
+    PlanBuilder.fuse_splitk = False
     KERNELS = ("window_attn_v2", "chan_apply_mfma", "mha_v2")
     ALL = KERNELS + ("reuse_activations",)        # reuse_activations: the shipped kernels on aliased scratch tensors (PlanBuilder.release)
     for names in tuple((n,) for n in ALL) + (KERNELS, ALL):

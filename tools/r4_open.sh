@@ -32,8 +32,21 @@ for f in "" "window_attn_v2" "chan_apply_mfma" "mha_v2" "window_attn_v2,chan_app
   ( timeout 200 python tools/caption_profile.py 128 768 2 $f > "$OUT/per_op_$tag.json" 2> "$OUT/per_op_$tag.txt"; echo "$tag exit $?" )
   grep -E "^--- encode|attn_rows|chan_attn" "$OUT/per_op_$tag.txt" | head -12
 done
+echo "=== A2b. batch-1 detector (configs[1], launch-bound): default vs fuse_splitk (no splitk_reduce launches)"
+for f in "" "fuse_splitk"; do
+  tag=det_${f:-default}
+  ( timeout 120 python bench.py --mode detect --steps 200 --warmup 20 --no-cpu-baseline --no-extra ${f:+--candidates $f} > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
+  python - "$OUT/bench_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", d["value"], d["unit"], d["ms_per_step"], "ms per screenshot")
+except Exception as e:
+    print("no result:", e)
+PY
+done
 echo "=== A3. bench A/B (K = 6): default, all candidates"
-for f in "" "window_attn_v2,chan_apply_mfma,mha_v2" "reuse_activations"; do   # reuse_activations: same kernels on aliased scratch (config.hbm_peak_allocated_gb)
+for f in "" "window_attn_v2,chan_apply_mfma,mha_v2" "reuse_activations" "fuse_splitk"; do   # reuse_activations: same kernels on aliased scratch (config.hbm_peak_allocated_gb)
   tag=${f:-default}; tag=${tag//,/+}
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra ${f:+--candidates $f} > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
