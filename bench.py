@@ -53,6 +53,8 @@ def parse_args():
     ap.set_defaults(pipeline=True)
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
+    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\", \"0-255:2;1-255:2\"; "
+                    "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
     ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
                     "or PlanBuilder (window_attn_v2, chan_apply_mfma, mha_v2, reuse_activations, fuse_splitk: not adopted yet); recorded in config.candidates")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
@@ -90,6 +92,10 @@ def main():
     from omniparser_amd.util.yolov9 import YOLOv9Detector
     from tools.make_weights import caption_dir, default_path, ensure_via_subprocess   # imports nothing from oracle/
 
+    if args.lane_masks:
+        from omniparser_amd.florence import Florence2Captioner as _F2C
+        _F2C.lane_cu_masks = tuple(args.lane_masks.split(";"))
+        os.environ["OMNI_HIPGRAPH"] = "0"       # graph launches may not honour a stream's CU mask (tools/cu_mask_probe.py measures it)
     if args.candidates:
         from tools import switch_on
         switch_on(args.candidates.split(","))          # A/B only: boolean switches of Florence2Captioner / PlanBuilder, off by default
@@ -249,6 +255,8 @@ def main():
         out["config"]["hand_off"] = "device (detector + hand-off ops in one hipGraph)" if getattr(parser, "device_glue", False) else "host"
     if args.candidates:
         out["config"]["candidates"] = args.candidates.split(",")
+    if args.lane_masks:
+        out["config"]["lane_cu_masks"] = args.lane_masks.split(";")
     out["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # plans + weights of this process (torch allocator)
 
     if rank == 0:

@@ -243,6 +243,14 @@ int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms);
  * directly comparable with `rocprofv3 --kernel-trace --stats` of the same replay.  h_ms holds omni_plan_num_ops floats. */
 int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms);
 
+/* A HIP stream for plans, optionally restricted to a set of compute units (hipExtStreamCreateWithCUMask; bit i of the
+ * mask = CU i in the HIP runtime's enumeration, n_words 32-bit words; n_words == 0: an ordinary non-blocking stream).
+ * For partitioning the chip between concurrently running plans — e.g. the MFMA-bound GEMMs of one caption micro-batch
+ * and the HBM-bound kernels of another (tools/cu_mask_probe.py measures whether that pays; nothing in the default
+ * path uses a masked stream).  The stream is created on the calling thread's current device. */
+int omni_stream_create(const uint32_t* cu_mask, int n_words, void** out_stream);
+int omni_stream_destroy(void* stream);
+
 /* Host mirror of the GEMM kernels' block -> output-tile permutation (XCD-aware order with an optional N partition
  * over XCD groups; csrc/conv_igemm.hip::tile_of_block).  Test/diagnostic entry point, no device work: for block
  * `bid` of a grid over mtiles x ntiles tiles writes the tile (or -1/-1 for a padding block), the grid size and the

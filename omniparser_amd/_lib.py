@@ -26,7 +26,7 @@ EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
-    "omni_debug_host_op", "omni_plan_profile",
+    "omni_debug_host_op", "omni_plan_profile", "omni_stream_create", "omni_stream_destroy",
     "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
     "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
 ]
@@ -87,6 +87,10 @@ def bind(path):
     L.omni_plan_destroy.restype = None
     L.omni_resample_coeffs.argtypes = [c_int, c_int, c_int, POINTER(c_int32), POINTER(c_int32)]
     L.omni_resample_coeffs.restype = c_int
+    L.omni_stream_create.argtypes = [POINTER(ctypes.c_uint32), c_int, POINTER(c_void_p)]
+    L.omni_stream_create.restype = c_int
+    L.omni_stream_destroy.argtypes = [c_void_p]
+    L.omni_stream_destroy.restype = c_int
     L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
     L.omni_plan_time.restype = c_int
     L.omni_plan_profile.argtypes = [c_void_p, c_void_p, POINTER(c_float)]
@@ -202,6 +206,43 @@ def _stream_ptr(stream):
     if isinstance(stream, int):
         return c_void_p(stream)
     return c_void_p(stream.cuda_stream)
+
+
+def parse_cu_spec(spec, total=256):
+    """"0-127" | "0-255:2" | "0-31,64-95" -> sorted CU indices (HIP runtime enumeration)."""
+    cus = set()
+    for item in filter(None, str(spec).split(",")):
+        rng, _, step = item.partition(":")
+        a, _, b = rng.partition("-")
+        cus.update(range(int(a), int(b or a) + 1, int(step or 1)))
+    if not cus or min(cus) < 0 or max(cus) >= total:
+        raise ValueError(f"bad CU set {spec!r} (indices 0..{total - 1})")
+    return sorted(cus)
+
+
+def cu_mask_words(cus, total=256):
+    """Set of CU indices (HIP runtime enumeration) -> the 32-bit words hipExtStreamCreateWithCUMask takes."""
+    words = [0] * ((total + 31) // 32)
+    for c in cus:
+        if not 0 <= c < total:
+            raise ValueError(f"CU index {c} outside 0..{total - 1}")
+        words[c // 32] |= 1 << (c % 32)
+    return words
+
+
+def masked_stream(device, words):
+    """A torch stream object over a HIP stream restricted to the CUs of `words` (cu_mask_words); the HIP stream lives as long as
+    the returned object.  Experimental plumbing for partitioning the chip between concurrent plans (tools/cu_mask_probe.py):
+    the default path never creates one."""
+    import torch
+    import weakref
+    arr = (ctypes.c_uint32 * len(words))(*words)
+    h = c_void_p()
+    with torch.cuda.device(device):
+        check(lib().omni_stream_create(arr, len(words), ctypes.byref(h)))
+    st = torch.cuda.ExternalStream(h.value, device=device)
+    weakref.finalize(st, lib().omni_stream_destroy, c_void_p(h.value))
+    return st
 
 
 class Plan:

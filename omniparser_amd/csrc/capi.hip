@@ -134,6 +134,21 @@ extern "C" void omni_plan_destroy(omni_plan_t* plan) {
   delete plan;
 }
 
+extern "C" int omni_stream_create(const uint32_t* cu_mask, int n_words, void** out_stream) {
+  if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) { omni_set_error("omni_stream_create: bad arguments"); return OMNI_E_ARG; }
+  hipStream_t s = nullptr;
+  if (n_words == 0) OMNI_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
+  else OMNI_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
+  *out_stream = (void*)s;
+  return OMNI_OK;
+}
+
+extern "C" int omni_stream_destroy(void* stream) {
+  if (!stream) { omni_set_error("omni_stream_destroy: null stream"); return OMNI_E_ARG; }
+  OMNI_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
+  return OMNI_OK;
+}
+
 extern "C" int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms) {
   if (!plan || iters <= 0 || !ms) { omni_set_error("omni_plan_time: bad arguments"); return OMNI_E_ARG; }
   hipStream_t s = (hipStream_t)stream;

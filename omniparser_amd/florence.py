@@ -541,6 +541,9 @@ class Florence2Captioner:
     mha_v2 = False            # CANDIDATE, not timed on the MI355X yet: the encoder's attention with 64-key double-buffered LDS stages (loads
                               # of the next keys in flight under the arithmetic, one barrier per 64 keys), 32x32x16 MFMAs, a lazily moved softmax
                               # reference (csrc/caption_ops.hip::mha_mfma_f32_v2_kernel); A/B: tools/r4_open.sh
+    lane_cu_masks = None      # EXPERIMENT (tools/cu_mask_probe.py, bench.py --lane-masks; never run on the MI355X): CU sets ("0-127", "128-255"
+                              # [, decode]) for the encode lanes' HIP streams (hipExtStreamCreateWithCUMask) — disjoint sets let the HBM-bound
+                              # kernels of one micro-batch really run beside the power-bound GEMMs of the other instead of queueing behind them
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
     reuse_activations = False  # CANDIDATE (same kernels, same order, different addresses; not run on the MI355X yet): scratch tensors of a
                               # DaViT stage are released at its end and back the tensors of the later stages (PlanBuilder.release) —
@@ -559,7 +562,7 @@ class Florence2Captioner:
         self.config = _Config(name_or_path=str(model_dir) if "florence" in str(model_dir).lower() else f"florence:{model_dir}",
                               model_type="florence2")
         self.use_graph = os.environ.get("OMNI_HIPGRAPH", "1") != "0"    # read when a plan is built: tools set the attribute to profile eagerly
-        self.stream = torch.cuda.Stream(device=device)
+        self.stream = self._lane_stream(0)
         self._wcache = {}
         self._plans = {}
         self.max_new_tokens = 20
@@ -631,12 +634,18 @@ class Florence2Captioner:
             run(stream)
         return dec.ids[:n].clone()                 # stream-ordered snapshot (read back by the caller)
 
+    def _lane_stream(self, k):
+        m = self.lane_cu_masks
+        if m and k < len(m) and m[k]:
+            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(m[k])))
+        return torch.cuda.Stream(device=self.device)
+
     @property
     def stream2(self):
         """second encode lane of the pipelined stream: while one 128-crop micro-batch is in its MFMA-bound GEMMs the other one's
         HBM-bound kernels (depthwise conv + LayerNorm, attention, short-K GEMMs) fill the wave slots the GEMM blocks leave free."""
         if getattr(self, "_stream2", None) is None:
-            self._stream2 = torch.cuda.Stream(device=self.device)
+            self._stream2 = self._lane_stream(1)
         return self._stream2
 
     @property
@@ -644,7 +653,7 @@ class Florence2Captioner:
         """second HIP stream of the captioner: decode steps of batch i (launch-bound GEMMs over a few hundred rows + the HBM-bound
         cross-attention) overlap the MFMA-bound encode of batch i+1 (pipeline.py::parse_stream)."""
         if getattr(self, "_dec_stream", None) is None:
-            self._dec_stream = torch.cuda.Stream(device=self.device)
+            self._dec_stream = self._lane_stream(2)
         return self._dec_stream
 
     # ---- decode loop shared by both entry points

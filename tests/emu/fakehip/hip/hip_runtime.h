@@ -443,6 +443,7 @@ inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); re
 inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) { std::memcpy(d, s_, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s_, n); return hipSuccess; }
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s_, unsigned) { *s_ = nullptr; return hipSuccess; }
+inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s_, uint32_t, const uint32_t*) { *s_ = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }
 inline hipError_t hipEventCreate(hipEvent_t* e) { *e = nullptr; return hipSuccess; }
 inline hipError_t hipEventRecord(hipEvent_t, hipStream_t) { return hipSuccess; }

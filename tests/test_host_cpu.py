@@ -379,3 +379,26 @@ def test_device_lock_makes_the_models_gpu_current_in_every_thread(monkeypatch):
     plain = L.DeviceLock(torch.device("cuda", 1))
     with plain:
         assert not plain._lock.acquire(blocking=False)   # non-reentrant flavour really excludes
+
+
+def test_encode_lanes_take_cu_masked_streams_when_asked(emu, monkeypatch):
+    """Florence2Captioner.lane_cu_masks (experiment, None by default): the encode lanes' streams come from L.masked_stream with the
+    CU sets given as "a-b[:step]" lists; a lane without a set (here the decode stream) keeps an ordinary stream.  The HIP call itself
+    (omni_stream_create -> hipExtStreamCreateWithCUMask) is exported and refuses bad arguments without a GPU."""
+    import ctypes
+    import torch
+    from conftest import small_vocab_caption_checkpoint
+    from omniparser_amd.florence import Florence2Captioner
+    assert L.parse_cu_spec("0-7:2,32-33") == [0, 2, 4, 6, 32, 33]
+    assert L.cu_mask_words([0, 31, 32, 255]) == [0x80000001, 1, 0, 0, 0, 0, 0, 0x80000000]
+    with pytest.raises(ValueError):
+        L.parse_cu_spec("0-256")
+    h = ctypes.c_void_p()
+    assert L.lib().omni_stream_create(None, 2, ctypes.byref(h)) != 0 and b"omni_stream_create" in L.lib().omni_last_error()
+    made = []
+    monkeypatch.setattr(L, "masked_stream", lambda device, words: (made.append(list(words)), torch.cuda.Stream())[1])
+    assert Florence2Captioner.lane_cu_masks is None
+    monkeypatch.setattr(Florence2Captioner, "lane_cu_masks", ("0-127", "0-255:2"))
+    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    _ = cap.stream2, cap.dec_stream
+    assert made == [[0xFFFFFFFF] * 4 + [0] * 4, [0x55555555] * 8]

@@ -1,7 +1,9 @@
 #!/usr/bin/env bash
-# Round-4 opening GPU session (one gpurun call, ~25 GPU-minutes).  Round 3 ended with three things unmeasured:
+# Round-4 opening GPU session (one gpurun call, ~30 GPU-minutes).  Round 3 ended with three things unmeasured:
 #   A. three candidate kernels that have only run on the host emulation (window attention v2, channel-attention apply on the matrix
 #      pipe, encoder attention v2: Florence2Captioner.window_attn_v2 / chan_apply_mfma / mha_v2) -> hardware parity, per-op A/B, bench A/B
+#      + written later, same status: PlanBuilder.fuse_splitk (split-K without the reduce launch), Florence2Captioner.reuse_activations
+#      (scratch-tensor reuse), CU-partitioned encode lanes (tools/cu_mask_probe.py, bench.py --lane-masks)
 #   B. the hardware-queue cliff (one encode lane + the decode stream at GPU_MAX_HW_QUEUES=8: 1034 instead of 709 ms per step)
 #      -> kernel trace of the slow and the fast case, per-queue gap summary (tools/hwq_gaps.py)
 #   C. the suite and the default bench line at the round-3 final commit on a fresh box (what the driver recorded at round end)
@@ -59,6 +61,31 @@ try:
     print("   ", r.get("kernel_family_ms_per_step"))
 except Exception as e:
     print("    no line:", e)
+PY
+done
+echo "=== A4. CU-partitioned lanes (experiment): probe (mask mapping, GEMM / LayerNorm scaling with the CU count, graph vs eager under a mask,"
+echo "        GEMM queue beside a LayerNorm queue on disjoint CU sets), then the bench with the two encode lanes on disjoint halves"
+( timeout 150 python tools/cu_mask_probe.py > "$OUT/cu_mask_probe.json" 2> "$OUT/cu_mask_probe.err"; echo "probe exit $?" )
+python - "$OUT/cu_mask_probe.json" <<'PY'
+import json, sys
+try:
+    d = json.load(open(sys.argv[1]))
+    for sec in ("single", "graph", "concurrent"):
+        for k, v in d[sec].items():
+            print("   ", sec, k, v)
+except Exception as e:
+    print("no report:", e)
+PY
+for m in "0-127;128-255" "0-255:2;1-255:2"; do
+  tag=lanes_$(echo "$m" | tr ';:-' '___')
+  ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --lane-masks "$m" > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
+  python - "$OUT/bench_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", d["config"].get("lane_cu_masks"), d["value"], "screenshots/s", d["ms_per_step"], "ms/step")
+except Exception as e:
+    print("no result:", e)
 PY
 done
 echo "=== B. hardware-queue cliff: kernel traces of --lanes 1 at 4 and 8 hardware queues (K = 3), gap summary per queue"
