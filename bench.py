@@ -53,7 +53,7 @@ def parse_args():
     ap.set_defaults(pipeline=True)
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
-    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\", \"0-255:2;1-255:2\"; "
+    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%8, every XCD needs a share - contiguous ranges; "
                     "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
     ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
                     "or PlanBuilder (window_attn_v2, chan_apply_mfma, mha_v2, reuse_activations, fuse_splitk: not adopted yet); recorded in config.candidates")

@@ -209,7 +209,9 @@ def _stream_ptr(stream):
 
 
 def parse_cu_spec(spec, total=256):
-    """"0-127" | "0-255:2" | "0-31,64-95" -> sorted CU indices (HIP runtime enumeration)."""
+    """"0-127" | "0-31,64-95" | "0-255:2" -> sorted mask-bit indices.  Measured on the MI355X (profiles/r3_cu_mask_probe.md): bit j is
+    CU j / 8 of XCD j % 8, and an XCD whose share of the mask is empty is not restricted at all — a partition of the chip is a
+    contiguous range in multiples of 8 bits ("0-127" = 16 CUs of every XCD); strided sets restrict nothing."""
     cus = set()
     for item in filter(None, str(spec).split(",")):
         rng, _, step = item.partition(":")

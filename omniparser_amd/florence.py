@@ -541,7 +541,7 @@ class Florence2Captioner:
     mha_v2 = False            # CANDIDATE, not timed on the MI355X yet: the encoder's attention with 64-key double-buffered LDS stages (loads
                               # of the next keys in flight under the arithmetic, one barrier per 64 keys), 32x32x16 MFMAs, a lazily moved softmax
                               # reference (csrc/caption_ops.hip::mha_mfma_f32_v2_kernel); A/B: tools/r4_open.sh
-    lane_cu_masks = None      # EXPERIMENT (tools/cu_mask_probe.py, bench.py --lane-masks; never run on the MI355X): CU sets ("0-127", "128-255"
+    lane_cu_masks = None      # EXPERIMENT (bench.py --lane-masks; premises measured, profiles/r3_cu_mask_probe.md; the bench itself not yet): CU sets ("0-127", "128-255"
                               # [, decode]) for the encode lanes' HIP streams (hipExtStreamCreateWithCUMask) — disjoint sets let the HBM-bound
                               # kernels of one micro-batch really run beside the power-bound GEMMs of the other instead of queueing behind them
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM

@@ -26,10 +26,11 @@ def parse_mask(spec, total=256):
     return parse_cu_spec(spec, total)
 
 
+# Measured at the end of round 3 (profiles/r3_cu_mask_probe.md): bit j = CU j / 8 of XCD j % 8, and an XCD whose share of the mask is
+# empty is NOT restricted — strided sets ("0-255:2") are no-ops; a partition gives every XCD a share: contiguous ranges, multiples of 8.
 MASKS = {
-    "all256": "0-255", "low192": "0-191", "low128": "0-127", "high128": "128-255", "even128": "0-255:2", "odd128": "1-255:2",
-    "low64": "0-63", "every4th64": "0-255:4", "word0": "0-31", "word1": "32-63", "word4": "128-159", "word7": "224-255",
-    "high64": "192-255",
+    "all256": "0-255", "low192": "0-191", "low160": "0-159", "low128": "0-127", "high128": "128-255", "high96": "160-255",
+    "low64": "0-63", "high64": "192-255", "word0": "0-31", "even128_noop": "0-255:2",
 }
 
 
@@ -100,7 +101,7 @@ def main(make_stream=None, iters=6):
             out["graph"][name] = {"error": repr(e)[:300]}
     # 3. GEMMs on A, LayerNorms on B: wall time of both queues together against the serial sum
     n_g, n_l = 4, 12
-    for a, b in (("all256", "all256"), ("low192", "high64"), ("low128", "high128"), ("even128", "odd128")):
+    for a, b in (("all256", "all256"), ("low192", "high64"), ("low160", "high96"), ("low128", "high128")):
         try:
             sa = streams[a]
             sb = make_stream(MASKS[b]) if a == b else streams[b]
@@ -117,6 +118,30 @@ def main(make_stream=None, iters=6):
             out["concurrent"][f"{a}|{b}"] = {"wall_ms": round(wall, 3), "serial_unmasked_ms": round(serial, 3), "ratio": round(wall / max(serial, 1e-9), 3)}
         except Exception as e:                                     # noqa: BLE001
             out["concurrent"][f"{a}|{b}"] = {"error": repr(e)[:300]}
+    # 4. the pipeline's shape: two lanes running the SAME mixed queue (GEMM, 3 LayerNorms) x 6, the second lane half a period ahead,
+    # unmasked against symmetric halves — wall time per lane-iteration
+    out["two_mixed_lanes"] = {}
+    for a, b in (("all256", "all256"), ("low128", "high128")):
+        try:
+            sa = streams[a]
+            sb = make_stream(MASKS[b]) if a == b else streams[b]
+            for s_ in (sa, sb):
+                s_.synchronize()
+            t0 = time.perf_counter()
+            for it in range(6):
+                gemm.run(sa)
+                for _ in range(3):
+                    ln.run(sb)
+                for _ in range(3):
+                    ln.run(sa)
+                gemm.run(sb)
+            sa.synchronize(); sb.synchronize()
+            wall = (time.perf_counter() - t0) * 1e3
+            serial = 12 * out["single"]["all256"]["gemm_ms"] + 36 * out["single"]["all256"]["layernorm_ms"]
+            out["two_mixed_lanes"][f"{a}|{b}"] = {"wall_ms": round(wall, 3), "serial_unmasked_ms": round(serial, 3),
+                                                   "ratio": round(wall / max(serial, 1e-9), 3)}
+        except Exception as e:                                     # noqa: BLE001
+            out["two_mixed_lanes"][f"{a}|{b}"] = {"error": repr(e)[:300]}
     print(json.dumps(out, indent=1))
     return out
 

@@ -70,13 +70,13 @@ python - "$OUT/cu_mask_probe.json" <<'PY'
 import json, sys
 try:
     d = json.load(open(sys.argv[1]))
-    for sec in ("single", "graph", "concurrent"):
+    for sec in ("single", "graph", "concurrent", "two_mixed_lanes"):
         for k, v in d[sec].items():
             print("   ", sec, k, v)
 except Exception as e:
     print("no report:", e)
 PY
-for m in "0-127;128-255" "0-255:2;1-255:2"; do
+for m in "0-127;128-255" "0-159;160-255"; do      # contiguous ranges: every XCD keeps a share (profiles/r3_cu_mask_probe.md)
   tag=lanes_$(echo "$m" | tr ';:-' '___')
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --lane-masks "$m" > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
