@@ -55,6 +55,8 @@ def parse_args():
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%8, every XCD needs a share - contiguous ranges; "
                     "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
+    ap.add_argument("--split-masks", default="", help="EXPERIMENT: \"<GEMM CU set>;<other CU set>\" (e.g. \"0-175;176-255\"): encode plans replay eagerly over two "
+                    "CU-masked streams per lane, MFMA-bound ops on the first set, HBM-bound ops on the second (Plan.run_split)")
     ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
                     "or PlanBuilder (window_attn_v2, chan_apply_mfma, mha_v2, reuse_activations, fuse_splitk: not adopted yet); recorded in config.candidates")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
@@ -96,6 +98,11 @@ def main():
         from omniparser_amd.florence import Florence2Captioner as _F2C
         _F2C.lane_cu_masks = tuple(args.lane_masks.split(";"))
         os.environ["OMNI_HIPGRAPH"] = "0"       # graph launches may not honour a stream's CU mask (tools/cu_mask_probe.py measures it)
+    if args.split_masks:
+        from omniparser_amd.florence import Florence2Captioner as _F2C
+        _F2C.split_cu_masks = tuple(args.split_masks.split(";"))
+        assert len(_F2C.split_cu_masks) == 2, "--split-masks takes two CU sets"
+        os.environ["OMNI_HIPGRAPH"] = "0"
     if args.candidates:
         from tools import switch_on
         switch_on(args.candidates.split(","))          # A/B only: boolean switches of Florence2Captioner / PlanBuilder, off by default
@@ -257,6 +264,8 @@ def main():
         out["config"]["candidates"] = args.candidates.split(",")
     if args.lane_masks:
         out["config"]["lane_cu_masks"] = args.lane_masks.split(";")
+    if args.split_masks:
+        out["config"]["split_cu_masks"] = args.split_masks.split(";")
     out["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # plans + weights of this process (torch allocator)
 
     if rank == 0:

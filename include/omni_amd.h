@@ -249,6 +249,11 @@ int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms);
  * and the HBM-bound kernels of another (tools/cu_mask_probe.py measures whether that pays; nothing in the default
  * path uses a masked stream).  The stream is created on the calling thread's current device. */
 int omni_stream_create(const uint32_t* cu_mask, int n_words, void** out_stream);
+/* Eager replay of a plan over TWO streams: its MFMA-bound ops (OMNI_OP_CONV, OMNI_OP_MLP_FUSED) on `stream_gemm`, all other ops on
+ * `stream_other`, program order kept by events at every change of stream.  The plan's inputs must be ready on `stream_other`; on
+ * return `stream_other` is ordered behind the last op.  h_class (may be NULL; omni_plan_num_ops ints): per op its stream class
+ * (1 = gemm) + 2 if an event hand-over precedes it; with both streams NULL nothing is launched and only h_class is filled. */
+int omni_plan_run_split(omni_plan_t* plan, void* stream_gemm, void* stream_other, int* h_class);
 int omni_stream_destroy(void* stream);
 
 /* Host mirror of the GEMM kernels' block -> output-tile permutation (XCD-aware order with an optional N partition

@@ -26,7 +26,7 @@ EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
-    "omni_debug_host_op", "omni_plan_profile", "omni_stream_create", "omni_stream_destroy",
+    "omni_debug_host_op", "omni_plan_profile", "omni_stream_create", "omni_stream_destroy", "omni_plan_run_split",
     "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
     "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
 ]
@@ -89,6 +89,8 @@ def bind(path):
     L.omni_resample_coeffs.restype = c_int
     L.omni_stream_create.argtypes = [POINTER(ctypes.c_uint32), c_int, POINTER(c_void_p)]
     L.omni_stream_create.restype = c_int
+    L.omni_plan_run_split.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_int)]
+    L.omni_plan_run_split.restype = c_int
     L.omni_stream_destroy.argtypes = [c_void_p]
     L.omni_stream_destroy.restype = c_int
     L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
@@ -260,6 +262,18 @@ class Plan:
 
     def run(self, stream=None):
         check(lib().omni_plan_run(self._h, _stream_ptr(stream)))
+
+    def run_split(self, stream_gemm, stream_other):
+        """eager replay over two streams: MFMA-bound ops on `stream_gemm`, the rest on `stream_other` (inputs ready there, results
+        ordered there on return); include/omni_amd.h::omni_plan_run_split"""
+        assert stream_gemm is not None and stream_other is not None
+        check(lib().omni_plan_run_split(self._h, _stream_ptr(stream_gemm), _stream_ptr(stream_other), None))
+
+    def split_schedule(self):
+        """[(stream class 0 / 1, hand-over before the op)] per op — what run_split would do, nothing launched."""
+        arr = (c_int * len(self.ops))()
+        check(lib().omni_plan_run_split(self._h, None, None, arr))
+        return [(v & 1, bool(v & 2)) for v in arr]
 
     def capture(self, stream):
         check(lib().omni_plan_capture(self._h, _stream_ptr(stream)))

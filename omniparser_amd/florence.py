@@ -544,6 +544,10 @@ class Florence2Captioner:
     lane_cu_masks = None      # EXPERIMENT (bench.py --lane-masks; premises measured, profiles/r3_cu_mask_probe.md; the bench itself not yet): CU sets ("0-127", "128-255"
                               # [, decode]) for the encode lanes' HIP streams (hipExtStreamCreateWithCUMask) — disjoint sets let the HBM-bound
                               # kernels of one micro-batch really run beside the power-bound GEMMs of the other instead of queueing behind them
+    split_cu_masks = None     # EXPERIMENT (bench.py --split-masks "0-175;176-255"; not run on the MI355X): (GEMM CU set, other CU set).  Encode
+                              # plans replay eagerly over two streams per lane (Plan.run_split): their MFMA-bound ops on a stream masked to
+                              # the first set, everything else on the lane's own stream, masked to the second — the power-bound GEMMs of one
+                              # micro-batch (95 % of their rate on 192 CUs) beside the HBM-bound kernels of another, by construction
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
     reuse_activations = False  # CANDIDATE (same kernels, same order, different addresses; not run on the MI355X yet): scratch tensors of a
                               # DaViT stage are released at its end and back the tensors of the later stages (PlanBuilder.release) —
@@ -622,7 +626,11 @@ class Florence2Captioner:
     # ---- merged decode (several micro-batches): encode only, cross-KV into rows [row0, row0 + n) of the decode plan
     def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int, stream=None):
         """encode on `stream` (default: the captioner's first stream; the caller made it current)."""
-        (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream or self.stream)
+        stream = stream or self.stream
+        if self.split_cu_masks:
+            cp.encode_plan.run_split(self.gemm_stream(stream), stream)
+        else:
+            (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream)
         for src, dst in zip(cp.cross_kv, dec.cross_kv):
             dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)
 
@@ -636,9 +644,20 @@ class Florence2Captioner:
 
     def _lane_stream(self, k):
         m = self.lane_cu_masks
+        if self.split_cu_masks and k < 2:                  # encode lanes of the split replay: the "other" CU set
+            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[1])))
         if m and k < len(m) and m[k]:
             return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(m[k])))
         return torch.cuda.Stream(device=self.device)
+
+    def gemm_stream(self, lane_stream):
+        """split replay: the GEMM-side stream that belongs to an encode lane's stream (one per lane, masked to the GEMM CU set)."""
+        if not hasattr(self, "_gemm_streams"):
+            self._gemm_streams = {}
+        key = lane_stream.cuda_stream
+        if key not in self._gemm_streams:
+            self._gemm_streams[key] = L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[0])))
+        return self._gemm_streams[key]
 
     @property
     def stream2(self):

@@ -402,3 +402,24 @@ def test_encode_lanes_take_cu_masked_streams_when_asked(emu, monkeypatch):
     cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     _ = cap.stream2, cap.dec_stream
     assert made == [[0xFFFFFFFF] * 4 + [0] * 4, [0x55555555] * 8]
+
+
+def test_split_replay_schedule_keeps_program_order():
+    """omni_plan_run_split's schedule (dry run, no GPU): MFMA-bound ops (conv / linear / fused FFN) on the GEMM stream, the rest on
+    the other stream, an event hand-over exactly where consecutive ops change stream — the induction that keeps program order —
+    starting on the 'other' stream (where the inputs are ready)."""
+    import torch
+    from omniparser_amd.planner import PlanBuilder, View
+    pb = PlanBuilder("cpu", L.F32)
+    x = View(torch.zeros(1, 8, 8, 32), 0, 32)
+    y, z = pb.alloc(1, 8, 8, 32), pb.alloc(1, 8, 8, 32)
+    g = pb.upload(torch.ones(32))
+    w = pb.pack_weight(torch.zeros(32, 32, 1, 1))
+    ln = lambda a, b: pb.add_op(L.make_op(L.OP_LAYERNORM, L.F32, p=[a.ptr, None, g.data_ptr(), g.data_ptr(), b.ptr, None],
+                                          i={0: 64, 1: 1, 3: 32}, f={0: 1e-5}))
+    ln(x, y); pb.conv(y, w, None, z, 1); pb.conv(z, w, None, y, 1); ln(y, z); ln(z, y); pb.conv(y, w, None, z, 1)
+    plan = pb.build()
+    assert plan.split_schedule() == [(0, False), (1, True), (1, False), (0, True), (0, False), (1, True)]
+    lib = L.lib()
+    assert lib.omni_plan_run_split(plan._h, None, None, None) != 0                      # a dry run needs the output array
+    assert lib.omni_plan_run_split(plan._h, ctypes.c_void_p(8), ctypes.c_void_p(8), None) != 0 and b"two different" in lib.omni_last_error()

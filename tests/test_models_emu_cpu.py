@@ -112,6 +112,35 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
             p.encode_plan.run(c.stream)
     assert torch.equal(cp4.img_feat.t, cp1.img_feat.t) and torch.equal(cp4.enc_out.t, cp1.enc_out.t)
     assert all(torch.equal(a.t, b.t) for a, b in zip(cp4.cross_kv, cp1.cross_kv))
+    # Florence2Captioner.split_cu_masks (experiment): the encode plan replayed over two streams (omni_plan_run_split: MFMA-bound ops on
+    # one, the rest on the other, event hand-overs at every change) — every op still runs once and in order: results bit for bit those
+    # of the one-stream replay.  (The emulation runs launches synchronously: what the events guarantee on hardware is the schedule
+    # checked in tests/test_host_cpu.py::test_split_replay_schedule_keeps_program_order.)
+    monkeypatch.undo()
+    import itertools
+    from types import SimpleNamespace
+    from emu_runtime import HostStream
+    handles = itertools.count(0x1000, 0x10)
+    made = []
+
+    class FakeMasked(HostStream):
+        def __init__(self, words):
+            self.cuda_stream = next(handles)
+            made.append(list(words))
+    monkeypatch.setattr(L, "masked_stream", lambda device, words: FakeMasked(words))
+    monkeypatch.setattr(Florence2Captioner, "split_cu_masks", ("0-175", "176-255"))
+    cap5 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cp5 = cap5.plans(1, 64, max_new)
+    dec5 = SimpleNamespace(cross_kv=[SimpleNamespace(t=torch.zeros_like(kv.t)) for kv in cp5.cross_kv])
+    sched = cp5.encode_plan.split_schedule()
+    assert sum(c for c, _ in sched) == sum(op.kind in (L.OP_CONV, L.OP_MLP_FUSED) for op in cp5.encode_plan.ops) and sum(h for _, h in sched) > 50
+    with torch.inference_mode():
+        cp5.reset()
+        cp5.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
+        cap5._encode_into(cp5, 1, dec5, 0, cap5.stream)
+    assert len(made) == 2 and made[0] == L.cu_mask_words(range(176, 256)) and made[1] == L.cu_mask_words(range(176))   # lane stream, its GEMM stream
+    assert torch.equal(cp5.img_feat.t, cp1.img_feat.t) and torch.equal(cp5.enc_out.t, cp1.enc_out.t)
+    assert all(torch.equal(d.t[:1], kv.t[:1]) for d, kv in zip(dec5.cross_kv, cp1.cross_kv))
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):

@@ -88,6 +88,19 @@ except Exception as e:
     print("no result:", e)
 PY
 done
+echo "        ... and the split replay: MFMA-bound ops of every encode plan on a GEMM CU set, the rest on the other set (two lanes, eager)"
+for m in "0-191;192-255" "0-175;176-255" "0-159;160-255"; do
+  tag=split_$(echo "$m" | tr ';:-' '___')
+  ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --split-masks "$m" > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
+  python - "$OUT/bench_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", d["config"].get("split_cu_masks"), d["value"], "screenshots/s", d["ms_per_step"], "ms/step")
+except Exception as e:
+    print("no result:", e)
+PY
+done
 echo "=== B. hardware-queue cliff: kernel traces of --lanes 1 at 4 and 8 hardware queues (K = 3), gap summary per queue"
 for q in 4 8; do
   ( GPU_MAX_HW_QUEUES=$q OMNI_BENCH_WATCHDOG=120 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_hwq$q" -- \
