@@ -70,6 +70,7 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     monkeypatch.setattr(Florence2Captioner, "attn_split_out", False)
     monkeypatch.setattr(Florence2Captioner, "fuse_dwln", False)
     cap2 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cap2._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
     cp2 = cap2.plans(1, 64, max_new)
     assert not any(op.kind == L.OP_DWCONV3_LN for op in cp2.encode_plan.ops)
     assert sum(op.kind == L.OP_SPLIT_CONVERT for op in cp2.encode_plan.ops) > sum(op.kind == L.OP_SPLIT_CONVERT for op in cp.encode_plan.ops)
@@ -86,6 +87,7 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     monkeypatch.setattr(Florence2Captioner, "chan_apply_mfma", True)        # and the candidate channel-attention apply kernel (op i[7])
     monkeypatch.setattr(Florence2Captioner, "mha_v2", True)                 # and the candidate encoder attention (op i[17] in mode 0)
     cap3 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cap3._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
     cp3 = cap3.plans(1, 64, max_new)
     assert sum(op.kind == L.OP_ATTN_ROWS and op.i[12] == 1 and op.i[17] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
     assert sum(op.kind == L.OP_CHAN_ATTN and op.i[7] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
@@ -103,6 +105,7 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     cp1 = cap.plans(1, 64, max_new)              # the default composition at the same row count (tile choices follow the row count)
     monkeypatch.setattr(Florence2Captioner, "reuse_activations", True)
     cap4 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cap4._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
     cp4 = cap4.plans(1, 64, max_new)
     assert cp4.pb.reused_bytes > 0 and cp1.pb.reused_bytes == 0
     with torch.inference_mode():
@@ -130,6 +133,7 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
     monkeypatch.setattr(L, "masked_stream", lambda device, words: FakeMasked(words))
     monkeypatch.setattr(Florence2Captioner, "split_cu_masks", ("0-175", "176-255"))
     cap5 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
+    cap5._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
     cp5 = cap5.plans(1, 64, max_new)
     dec5 = SimpleNamespace(cross_kv=[SimpleNamespace(t=torch.zeros_like(kv.t)) for kv in cp5.cross_kv])
     sched = cp5.encode_plan.split_schedule()
