@@ -166,16 +166,23 @@ def main():
 
     def pack(step_id, li, elems, ids):
         crop_counts.append(sum(parser.stats["crops"]))
+        if li is not None and (args.lane_masks or args.split_masks):
+            # CU-masked streams are blocking streams: an upload on the null stream would wait for every lane's queued work
+            with torch.cuda.stream(det.stream):
+                return pack_records(step_id, li, elems, ids)
         if li is not None:
-            for j in range(B):
-                boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
-                k = boxes.shape[0]
-                capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
-                ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
-                for row, i in zip(ids[j], ic):
-                    if i < k:
-                        capt[i, : row.shape[0]] = row
-                recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
+            pack_records(step_id, li, elems, ids)
+
+    def pack_records(step_id, li, elems, ids):
+        for j in range(B):
+            boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
+            k = boxes.shape[0]
+            capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
+            ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
+            for row, i in zip(ids[j], ic):
+                if i < k:
+                    capt[i, : row.shape[0]] = row
+            recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
 
     def sync_all():
         det.stream.synchronize()

@@ -6,6 +6,7 @@ frame (the reference's list semantics, util/utils.py) -> the crops of ALL frames
 caption micro-batches (ref batch_size=128) -> on-device greedy decode.  Results equal a per-frame
 `get_som_labeled_img(...)[2]` call (same functions underneath); only the packing differs.
 """
+import contextlib
 import os
 from types import SimpleNamespace
 from typing import List, Optional, Sequence
@@ -463,8 +464,12 @@ class ScreenParser:
                 caps = self.caption_finish(handle)
                 elems_all = self.assemble(snap, snap, ocr_els, counts, iw, ih, n_frames)
             ids_out = self._fill_captions(elems_all, caps)
-            self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
-            self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
+            # (experiments with CU-masked lanes: those are BLOCKING streams — hipExtStreamCreateWithCUMask takes no flags — so a read on
+            # the null stream would wait for every lane's queued work; the snapshot was written on the detector's stream: read it there)
+            masked = getattr(self.cap, "lane_cu_masks", None) or getattr(self.cap, "split_cu_masks", None)
+            with (torch.cuda.stream(self.det.stream) if masked else contextlib.nullcontext()):
+                self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
+                self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
 
         try:
