@@ -7,7 +7,8 @@
 #   B. the hardware-queue cliff (one encode lane + the decode stream at GPU_MAX_HW_QUEUES=8: 1034 instead of 709 ms per step)
 #      -> kernel trace of the slow and the fast case, per-queue gap summary (tools/hwq_gaps.py)
 #   C. the suite and the default bench line at the round-3 final commit on a fresh box (what the driver recorded at round end)
-# usage: gpurun --timeout 1700 -- 'bash tools/r4_open.sh'
+# usage: gpurun --timeout 1700 -- 'SECTIONS="A4 A1 A2b" bash tools/r4_open.sh'   then   gpurun --timeout 1700 -- 'SECTIONS="A2 A3 B C" bash tools/r4_open.sh'
+#        (A4 first: the CU-partition benches are the experiment with the largest expected effect)
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
@@ -15,6 +16,9 @@ OUT=gpurun_out/r4open
 mkdir -p "$OUT"
 python tools/make_weights.py --ensure detector > /dev/null 2>&1
 python tools/make_weights.py --ensure caption > /dev/null 2>&1
+# SECTIONS="A1 A4 C" runs only those sections (default: all, ~40 GPU-minutes: split it over two calls)
+want() { [[ -z "${SECTIONS:-}" || " ${SECTIONS} " == *" $1 "* ]]; }
+if want A1; then
 echo "=== A1. candidate kernels on hardware: kernel checks + real 768x768 crops against transformers"
 ( timeout 420 python tools/r4_candidates.py > "$OUT/candidates.json" 2> "$OUT/candidates.err"; echo "exit $?" )
 python - "$OUT/candidates.json" <<'PY'
@@ -28,12 +32,16 @@ try:
 except Exception as e:
     print("no report:", e)
 PY
+fi
+if want A2; then
 echo "=== A2. per-op profile of one 128-crop plan: default, each candidate, both"
 for f in "" "window_attn_v2" "chan_apply_mfma" "mha_v2" "window_attn_v2,chan_apply_mfma,mha_v2"; do
   tag=${f:-default}; tag=${tag//,/+}
   ( timeout 200 python tools/caption_profile.py 128 768 2 $f > "$OUT/per_op_$tag.json" 2> "$OUT/per_op_$tag.txt"; echo "$tag exit $?" )
   grep -E "^--- encode|attn_rows|chan_attn" "$OUT/per_op_$tag.txt" | head -12
 done
+fi
+if want A2b; then
 echo "=== A2b. batch-1 detector (configs[1], launch-bound): default vs fuse_splitk (no splitk_reduce launches)"
 for f in "" "fuse_splitk"; do
   tag=det_${f:-default}
@@ -47,6 +55,8 @@ except Exception as e:
     print("no result:", e)
 PY
 done
+fi
+if want A3; then
 echo "=== A3. bench A/B (K = 6): default, all candidates"
 for f in "" "window_attn_v2,chan_apply_mfma,mha_v2" "reuse_activations" "fuse_splitk"; do   # reuse_activations: same kernels on aliased scratch (config.hbm_peak_allocated_gb)
   tag=${f:-default}; tag=${tag//,/+}
@@ -63,6 +73,8 @@ except Exception as e:
     print("    no line:", e)
 PY
 done
+fi
+if want A4; then
 echo "=== A4. CU-partitioned lanes (experiment): probe (mask mapping, GEMM / LayerNorm scaling with the CU count, graph vs eager under a mask,"
 echo "        GEMM queue beside a LayerNorm queue on disjoint CU sets), then the bench with the two encode lanes on disjoint halves"
 ( timeout 150 python tools/cu_mask_probe.py > "$OUT/cu_mask_probe.json" 2> "$OUT/cu_mask_probe.err"; echo "probe exit $?" )
@@ -101,6 +113,8 @@ except Exception as e:
     print("no result:", e)
 PY
 done
+fi
+if want B; then
 echo "=== B. hardware-queue cliff: kernel traces of --lanes 1 at 4 and 8 hardware queues (K = 3), gap summary per queue"
 for q in 4 8; do
   ( GPU_MAX_HW_QUEUES=$q OMNI_BENCH_WATCHDOG=120 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_hwq$q" -- \
@@ -109,6 +123,8 @@ for q in 4 8; do
   python tools/hwq_gaps.py "$f" > "$OUT/hwq_gaps_$q.json" 2> "$OUT/hwq_gaps_$q.err"; head -c 1500 "$OUT/hwq_gaps_$q.json"; echo
   find "$OUT/trace_hwq$q" -name "*.csv" -size +4M -delete; find "$OUT/trace_hwq$q" -name "*.db" -delete
 done
+fi
+if want C; then
 echo "=== C. pytest tests/ -x -q -m gpu (one process, as the driver runs it) and the default bench line"
 t0=$(date +%s)
 ( timeout 1200 python -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=10 > "$OUT/pytest.log" 2>&1; echo "exit $?" >> "$OUT/pytest.log" )
@@ -116,3 +132,4 @@ echo "($(( $(date +%s) - t0 )) s)"; grep -v "Warning\|warnings.warn\|^$\|_create
 ( OMNI_BENCH_WATCHDOG=200 timeout 900 python bench.py > "$OUT/bench_full.json" 2> "$OUT/bench_full.err"; echo "bench exit $?" )
 tail -c 1200 "$OUT/bench_full.json"; echo
 ls -la "$OUT" | head -40
+fi
