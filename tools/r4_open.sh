@@ -88,7 +88,9 @@ try:
 except Exception as e:
     print("no report:", e)
 PY
-for m in "0-127;128-255" "0-159;160-255"; do      # contiguous ranges: every XCD keeps a share (profiles/r3_cu_mask_probe.md)
+# contiguous ranges: every XCD keeps a share (profiles/r3_cu_mask_probe.md).  Third set = the decode stream: "0-191;0-191;192-255" keeps both
+# encode lanes on 192 CUs (95.5 % of the GEMM rate) and gives the decode steps 64 CUs of their own instead of queueing behind 9 216-block launches
+for m in "0-127;128-255" "0-159;160-255" "0-191;0-191;192-255"; do
   tag=lanes_$(echo "$m" | tr ';:-' '___')
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --lane-masks "$m" > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
