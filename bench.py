@@ -101,7 +101,7 @@ def main():
     if args.split_masks:
         from omniparser_amd.florence import Florence2Captioner as _F2C
         _F2C.split_cu_masks = tuple(args.split_masks.split(";"))
-        assert len(_F2C.split_cu_masks) == 2, "--split-masks takes two CU sets"
+        assert len(_F2C.split_cu_masks) in (2, 3), "--split-masks takes two CU sets (+ an optional third for the decode stream)"
         os.environ["OMNI_HIPGRAPH"] = "0"
     if args.candidates:
         from tools import switch_on

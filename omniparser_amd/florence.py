@@ -646,6 +646,8 @@ class Florence2Captioner:
         m = self.lane_cu_masks
         if self.split_cu_masks and k < 2:                  # encode lanes of the split replay: the "other" CU set
             return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[1])))
+        if self.split_cu_masks and k == 2 and len(self.split_cu_masks) > 2:       # optional third set: the decode stream
+            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[2])))
         if m and k < len(m) and m[k]:
             return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(m[k])))
         return torch.cuda.Stream(device=self.device)

@@ -103,7 +103,7 @@ except Exception as e:
 PY
 done
 echo "        ... and the split replay: MFMA-bound ops of every encode plan on a GEMM CU set, the rest on the other set (two lanes, eager)"
-for m in "0-191;192-255" "0-175;176-255" "0-159;160-255"; do
+for m in "0-191;192-255" "0-175;176-255" "0-159;160-255" "0-175;176-255;176-255"; do      # 4th: the decode stream on the "other" set too
   tag=split_$(echo "$m" | tr ';:-' '___')
   ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --split-masks "$m" > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
   python - "$OUT/bench_$tag.json" <<'PY'
