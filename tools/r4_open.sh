@@ -20,7 +20,7 @@ python tools/make_weights.py --ensure caption > /dev/null 2>&1
 want() { [[ -z "${SECTIONS:-}" || " ${SECTIONS} " == *" $1 "* ]]; }
 if want A1; then
 echo "=== A1. candidate kernels on hardware: kernel checks + real 768x768 crops against transformers"
-( timeout 420 python tools/r4_candidates.py > "$OUT/candidates.json" 2> "$OUT/candidates.err"; echo "exit $?" )
+( timeout 600 python tools/r4_candidates.py > "$OUT/candidates.json" 2> "$OUT/candidates.err"; echo "exit $?" )
 python - "$OUT/candidates.json" <<'PY'
 import json, sys
 try:
