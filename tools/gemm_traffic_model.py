@@ -36,7 +36,8 @@ def main():
     from omniparser_amd import florence as FL
     from tools.make_weights import ensure_via_subprocess
     cdir = ensure_via_subprocess("caption", 0)
-    cap = SimpleNamespace(w=FL.FlorenceWeights(cdir), device=torch.device("cpu"), dtype=L.F32, _wcache={}, use_graph=False, stream=None)
+    cap = SimpleNamespace(w=FL.FlorenceWeights(cdir), device=torch.device("cpu"), dtype=L.F32, _wcache={}, use_graph=False, stream=None,
+                              **{k: v for k, v in vars(FL.Florence2Captioner).items() if isinstance(v, bool)})   # the class's composition switches
     cp = FL._CaptionPlans(cap, 1, 768, 20)
     MB = 128                                   # crops per micro-batch
     rows = []
