@@ -1123,7 +1123,10 @@ def _run_rows(cap, cp, rows, max_new, graph=True):
     snap = {}
     with torch.inference_mode(), torch.cuda.stream(cap.stream):
         cp.reset()
-        run(cp.encode_plan)
+        if getattr(cap, "split_cu_masks", None):       # experiment: encode over two CU-masked streams (tools/r4_candidates.py)
+            cp.encode_plan.run_split(cap.gemm_stream(cap.stream), cap.stream)
+        else:
+            run(cp.encode_plan)
         snap["x_in"] = cp.x_in.t[idx][..., :3].float().cpu()
         for s, v in enumerate(cp.stage_out):
             snap[f"stage{s}"] = v.t[idx].float().cpu()

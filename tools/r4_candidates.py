@@ -62,6 +62,21 @@ def main():
             rec = {"passed": False, "error": repr(e)[:500]}
         ok = ok and rec["passed"]
         out["+".join(names)] = rec
+    # split replay on hardware (Florence2Captioner.split_cu_masks): the encode plan over two CU-masked streams with event hand-overs,
+    # same crops, same oracle — a missing dependency shows as wrong features / ids
+    for n in ALL:
+        setattr(Florence2Captioner, n, False)
+    for masks in (("0-175", "176-255"), ("0-127", "128-255")):
+        Florence2Captioner.split_cu_masks = masks
+        try:
+            rec, cap = G.check_captioner_real_crops(R=768, n=4, seed=0)
+            rec["passed"] = bool(rec["x_in_bitwise"] and rec["ids_equal"] and rec["enc_rel_err"] < 1e-4 and rec["feat_rel_err"] < 1e-4)
+            del cap
+        except Exception as e:                                     # noqa: BLE001
+            rec = {"passed": False, "error": repr(e)[:500]}
+        ok = ok and rec["passed"]
+        out["split_replay " + ";".join(masks)] = rec
+    Florence2Captioner.split_cu_masks = None
     out["all_passed"] = ok
     print(json.dumps(out, indent=1))
     return 0 if ok else 1
