@@ -51,7 +51,8 @@ def parse_args():
                          "detector of step i+1, two encode lanes and the decode of step i overlap; same kernels, same results)")
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(pipeline=True)
-    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2], help="with --pipeline: caption micro-batches in flight at once (HIP streams)")
+    ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4], help="with --pipeline: caption micro-batches in flight at once (HIP streams); "
+                    "3 / 4: experiments (each lane holds its own 128-row encode plans: ~54 GB, ~23 GB with --candidates reuse_activations)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
     ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%8, every XCD needs a share - contiguous ranges; "
                     "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
@@ -138,6 +139,8 @@ def main():
         cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
         parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
         parser.encode_lanes = args.lanes
+        if args.lanes > 2:
+            os.environ.setdefault("OMNI_MAX_CAPTION_PLANS", "12")     # one 128-row plan set per lane + the smaller capacities + two decode plans stay resident
     else:
         dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=B)
 

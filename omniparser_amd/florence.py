@@ -669,6 +669,18 @@ class Florence2Captioner:
             self._stream2 = self._lane_stream(1)
         return self._stream2
 
+    def encode_lane(self, k):
+        """stream of encode lane k: 0 / 1 = `stream` / `stream2` (the default pipeline's two lanes); further lanes (experiments: with
+        the split replay the GEMM stream stays busy only while some lane has a GEMM ready — more micro-batches in flight) on demand."""
+        if k == 0:
+            return self.stream
+        if k == 1:
+            return self.stream2
+        extra = self.__dict__.setdefault("_extra_lanes", {})
+        if k not in extra:
+            extra[k] = self._lane_stream(0) if self.split_cu_masks else torch.cuda.Stream(device=self.device)
+        return extra[k]
+
     @property
     def dec_stream(self):
         """second HIP stream of the captioner: decode steps of batch i (launch-bound GEMMs over a few hundred rows + the HBM-bound

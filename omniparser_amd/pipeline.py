@@ -301,7 +301,7 @@ class ScreenParser:
         merged = len(flat) > self.batch_size and os.environ.get("OMNI_MERGED_DECODE", "1") != "0"
         # overlap (parse_stream): micro-batches alternate between two encode lanes (HIP streams); 128-row plans exist once per lane, the
         # smaller capacities once — a plan's `free_evt` orders its next use, on whichever lane, behind its last one
-        lanes = [cap.stream, cap.stream2][:max(1, self.encode_lanes)] if overlap else [cap.stream]
+        lanes = [cap.encode_lane(k) for k in range(max(1, self.encode_lanes))] if overlap else [cap.stream]
         if overlap and merged:
             self._dec_slot = 1 - getattr(self, "_dec_slot", 1)
         dec = cap.decode_plans(cap.decode_bucket(len(flat)), R, max_new_tokens, slot=self._dec_slot if overlap else 0) if merged else None

@@ -117,6 +117,19 @@ PY
 done
 fi
 if want B; then
+echo "        ... more micro-batches in flight: the GEMM stream idles only while NO lane has a GEMM ready (closed two-server queue: ~0.8 busy with 2 lanes, ~0.9 with 3-4)"
+for l in 3 4; do
+  tag=split_lanes$l
+  ( OMNI_BENCH_WATCHDOG=120 timeout 240 python bench.py --steps 6 --warmup 2 --no-cpu-baseline --no-extra --lanes $l --split-masks "0-175;176-255" --candidates reuse_activations > "$OUT/bench_$tag.json" 2> "$OUT/bench_$tag.err"; echo "$tag exit $?" )
+  python - "$OUT/bench_$tag.json" <<'PY'
+import json, sys
+try:
+    d = json.loads(open(sys.argv[1]).read().strip().splitlines()[-1])
+    print("   ", d["config"].get("split_cu_masks"), d["config"].get("pipeline", "")[-60:], d["value"], "screenshots/s", d["ms_per_step"], "ms/step, HBM", d["config"].get("hbm_peak_allocated_gb"), "GB")
+except Exception as e:
+    print("no result:", e)
+PY
+done
 echo "=== B. hardware-queue cliff: kernel traces of --lanes 1 at 4 and 8 hardware queues (K = 3), gap summary per queue"
 for q in 4 8; do
   ( GPU_MAX_HW_QUEUES=$q OMNI_BENCH_WATCHDOG=120 timeout 300 rocprofv3 --kernel-trace --output-format csv -d "$OUT/trace_hwq$q" -- \
