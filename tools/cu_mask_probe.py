@@ -56,6 +56,17 @@ def build_ops(torch, L, PlanBuilder, View, dev):
     pl.add_op(L.make_op(L.OP_LAYERNORM, L.F32, p=[t.ptr, None, g.data_ptr(), b.data_ptr(), o.ptr, None],
                         i={0: M, 1: 1, 3: N, 5: 0, 6: 0}, f={0: 1e-5}))
     ln = pl.build()
+    # the pipeline's heaviest HBM-bound kernel: depthwise conv + LayerNorm, C = 512 on 48x48 tokens (214 registers: it cannot
+    # co-reside with gemm_dma_kernel blocks the way the light LayerNorm does)
+    pd = PlanBuilder(dev, L.F32)
+    Bd, Hd, Cd = M // (48 * 48), 48, 512
+    xd, y1, hd = pd.alloc(Bd, Hd, Hd, Cd), pd.alloc(Bd, Hd, Hd, Cd), pd.alloc(Bd, Hd, Hd, Cd)
+    xd.t.normal_()
+    wd, bd = pd.upload(torch.randn(3, 3, Cd) * 0.1), pd.upload(torch.zeros(Cd))
+    gd, bb = pd.upload(torch.ones(Cd)), pd.upload(torch.zeros(Cd))
+    pd.add_op(L.make_op(L.OP_DWCONV3_LN, L.F32, p=[xd.ptr, wd.data_ptr(), bd.data_ptr(), hd.ptr, y1.ptr, gd.data_ptr(), bb.data_ptr()],
+                        i={0: Bd, 1: Hd, 2: Hd, 3: Cd, 6: 0}, f={0: 1e-5}))
+    build_ops.dwln = (pd.build(), 3.0 * 4 * Bd * Hd * Hd * Cd)
     return gemm, ln, 2.0 * M * N * K, 2.0 * 4 * M * N
 
 
@@ -78,6 +89,7 @@ def main(make_stream=None, iters=6):
     dev = L.require_device("cuda", "cu_mask_probe")
     make_stream = make_stream or (lambda spec: L.masked_stream(dev, L.cu_mask_words(parse_mask(spec))))
     gemm, ln, flops, ln_bytes = build_ops(torch, L, PlanBuilder, View, dev)
+    dwln, dwln_bytes = build_ops.dwln
     out = {"shape": {"M": M, "K": K, "N": N}, "single": {}, "graph": {}, "concurrent": {}}
     streams = {}
     for name, spec in MASKS.items():
@@ -85,8 +97,10 @@ def main(make_stream=None, iters=6):
             st = streams[name] = make_stream(spec)
             g_ms = timed(torch, st, lambda: gemm.run(st), iters)
             l_ms = timed(torch, st, lambda: ln.run(st), iters)
+            d_ms = timed(torch, st, lambda: dwln.run(st), iters)
             out["single"][name] = {"cus": len(parse_mask(spec)), "gemm_ms": round(g_ms, 4), "gemm_tflops": round(flops / g_ms / 1e9, 1),
-                                   "layernorm_ms": round(l_ms, 4), "layernorm_tbps": round(ln_bytes / l_ms / 1e9, 2)}
+                                   "layernorm_ms": round(l_ms, 4), "layernorm_tbps": round(ln_bytes / l_ms / 1e9, 2),
+                                   "dwconv_ln_ms": round(d_ms, 4), "dwconv_ln_tbps": round(dwln_bytes / d_ms / 1e9, 2)}
         except Exception as e:                                     # noqa: BLE001 — report, keep going
             out["single"][name] = {"error": repr(e)[:300]}
     # 2. does a captured plan replayed on a masked stream stay inside the mask?  (same time as the eager masked launch = yes)
@@ -118,7 +132,7 @@ def main(make_stream=None, iters=6):
             out["concurrent"][f"{a}|{b}"] = {"wall_ms": round(wall, 3), "serial_unmasked_ms": round(serial, 3), "ratio": round(wall / max(serial, 1e-9), 3)}
         except Exception as e:                                     # noqa: BLE001
             out["concurrent"][f"{a}|{b}"] = {"error": repr(e)[:300]}
-    # 4. the pipeline's shape: two lanes running the SAME mixed queue (GEMM, 3 LayerNorms) x 6, the second lane half a period ahead,
+    # 4. the pipeline's shape: two lanes running the SAME mixed queue (GEMM, 2 x depthwise conv + LayerNorm) x 6, the second lane half a period ahead,
     # unmasked against symmetric halves — wall time per lane-iteration
     out["two_mixed_lanes"] = {}
     for a, b in (("all256", "all256"), ("low128", "high128")):
@@ -130,14 +144,14 @@ def main(make_stream=None, iters=6):
             t0 = time.perf_counter()
             for it in range(6):
                 gemm.run(sa)
-                for _ in range(3):
-                    ln.run(sb)
-                for _ in range(3):
-                    ln.run(sa)
+                for _ in range(2):
+                    dwln.run(sb)
+                for _ in range(2):
+                    dwln.run(sa)
                 gemm.run(sb)
             sa.synchronize(); sb.synchronize()
             wall = (time.perf_counter() - t0) * 1e3
-            serial = 12 * out["single"]["all256"]["gemm_ms"] + 36 * out["single"]["all256"]["layernorm_ms"]
+            serial = 12 * out["single"]["all256"]["gemm_ms"] + 24 * out["single"]["all256"]["dwconv_ln_ms"]
             out["two_mixed_lanes"][f"{a}|{b}"] = {"wall_ms": round(wall, 3), "serial_unmasked_ms": round(serial, 3),
                                                    "ratio": round(wall / max(serial, 1e-9), 3)}
         except Exception as e:                                     # noqa: BLE001
