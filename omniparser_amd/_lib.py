@@ -245,7 +245,8 @@ def masked_stream(device, words):
     with torch.cuda.device(device):
         check(lib().omni_stream_create(arr, len(words), ctypes.byref(h)))
     st = torch.cuda.ExternalStream(h.value, device=device)
-    weakref.finalize(st, lib().omni_stream_destroy, c_void_p(h.value))
+    fin = weakref.finalize(st, lib().omni_stream_destroy, c_void_p(h.value))
+    fin.atexit = False            # at interpreter exit the HIP runtime tears its streams down itself (and may already be gone)
     return st
 
 
