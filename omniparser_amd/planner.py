@@ -244,7 +244,8 @@ class PlanBuilder:
         b = None
         if bias is not None:
             b = bias if bias.device == self.device and bias.dtype == torch.float32 else self.upload(bias.detach().float())
-            if b.data_ptr() not in _TENSORS:
+            ent = _TENSORS.get(b.data_ptr())
+            if ent is None or ent[0]() is not b:  # (an entry of a DEAD tensor that lived at this address does not count)
                 _register(b, "const")            # a caller-owned device tensor: exported with the plan like an uploaded one
             self.keep.append(b)
             assert b.numel() == cout

@@ -423,3 +423,25 @@ def test_split_replay_schedule_keeps_program_order():
     lib = L.lib()
     assert lib.omni_plan_run_split(plan._h, None, None, None) != 0                      # a dry run needs the output array
     assert lib.omni_plan_run_split(plan._h, ctypes.c_void_p(8), ctypes.c_void_p(8), None) != 0 and b"two different" in lib.omni_last_error()
+
+
+def test_plan_export_survives_a_dead_tensors_registry_entry_at_the_same_address(tmp_path):
+    """The tensor registry is keyed by base address with weak references.  A caller-owned bias whose address was once a (now dead)
+    registered tensor's must be registered afresh — found as an order-dependent failure of the bundle round-trip test: the stale entry
+    made `conv` skip the registration, the export then purged it and could not resolve the pointer."""
+    import gc
+    import weakref
+    import torch
+    from omniparser_amd import bundle as B, planner
+    from omniparser_amd.planner import PlanBuilder
+    pb = PlanBuilder("cpu", L.F32)
+    x, y = pb.alloc(1, 4, 4, 32, zero=True), pb.alloc(1, 4, 4, 64)
+    w = pb.pack_weight(torch.randn(64, 32, 1, 1))
+    bias = torch.randn(64)
+    dead = torch.zeros(3)
+    planner._TENSORS[bias.data_ptr()] = (weakref.ref(dead), "scratch", 12)      # what an earlier plan's freed tensor leaves behind
+    del dead
+    gc.collect()
+    pb.conv(x, w, bias, y, 1)
+    info = B.write_bundle(tmp_path / "t.omniplan", {"p": pb.ops}, {"x": (x.t, 0, 64)}, {})
+    assert info["ops"] == {"p": 1}
