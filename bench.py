@@ -54,7 +54,7 @@ def parse_args():
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4], help="with --pipeline: caption micro-batches in flight at once (HIP streams); "
                     "3 / 4: experiments (each lane holds its own 128-row encode plans: ~54 GB, ~23 GB with --candidates reuse_activations)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
-    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%8, every XCD needs a share - contiguous ranges; "
+    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%%8, every XCD needs a share - contiguous ranges; "
                     "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
     ap.add_argument("--split-masks", default="", help="EXPERIMENT: \"<GEMM CU set>;<other CU set>\" (e.g. \"0-175;176-255\"): encode plans replay eagerly over two "
                     "CU-masked streams per lane, MFMA-bound ops on the first set, HBM-bound ops on the second (Plan.run_split)")
@@ -172,20 +172,9 @@ def main():
         if li is not None and (args.lane_masks or args.split_masks):
             # CU-masked streams are blocking streams: an upload on the null stream would wait for every lane's queued work
             with torch.cuda.stream(det.stream):
-                return pack_records(step_id, li, elems, ids)
+                return pack_records(recs, B, dev, step_id, li, elems, ids)
         if li is not None:
-            pack_records(step_id, li, elems, ids)
-
-    def pack_records(step_id, li, elems, ids):
-        for j in range(B):
-            boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
-            k = boxes.shape[0]
-            capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
-            ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
-            for row, i in zip(ids[j], ic):
-                if i < k:
-                    capt[i, : row.shape[0]] = row
-            recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
+            pack_records(recs, B, dev, step_id, li, elems, ids)
 
     def sync_all():
         det.stream.synchronize()
@@ -332,6 +321,22 @@ def main():
     if world > 1:
         dist.barrier()
         dist.destroy_process_group()
+
+
+def pack_records(recs, B, dev, step_id, li, elems, ids):
+    """the parsed elements of one step's B screenshots -> rows li*B .. li*B+B-1 of the job's record table (what the all_gather moves):
+    boxes in ratio coordinates, caption ids on the rows of the icons that were captioned, in element order."""
+    import torch
+    from omniparser_amd import dist as OD
+    for j in range(B):
+        boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
+        k = boxes.shape[0]
+        capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
+        ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
+        for row, i in zip(ids[j], ic):
+            if i < k:
+                capt[i, : row.shape[0]] = row
+        recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
 
 
 def child_json(cmd, env, limit_s, keep=None):

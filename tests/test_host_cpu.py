@@ -445,3 +445,26 @@ def test_plan_export_survives_a_dead_tensors_registry_entry_at_the_same_address(
     pb.conv(x, w, bias, y, 1)
     info = B.write_bundle(tmp_path / "t.omniplan", {"p": pb.ops}, {"x": (x.t, 0, 64)}, {})
     assert info["ops"] == {"p": 1}
+
+
+def test_bench_record_packing_round_trips():
+    """bench.py::pack_records (runs inside the timed region of every step): elements + caption ids of a step's screenshots -> the
+    fixed-width records the job's one all_gather moves; unpacked again they hold the boxes and, on the captioned icons' rows, the ids."""
+    import torch
+    import bench
+    from omniparser_amd import dist as OD
+    B = 2
+    recs = torch.zeros(3 * B, OD.REC_W, dtype=torch.int32)
+    elems = [[{"bbox": [0.1, 0.2, 0.3, 0.4], "source": "box_ocr_content_ocr"},
+              {"bbox": [0.5, 0.5, 0.6, 0.7], "source": "box_yolo_content_yolo"},
+              {"bbox": [0.0, 0.1, 0.2, 0.3], "source": "box_yolo_content_ocr"},
+              {"bbox": [0.7, 0.7, 0.9, 0.8], "source": "box_yolo_content_yolo"}],
+             []]
+    ids = [[torch.tensor([2, 0, 11, 12, 2]), torch.tensor([2, 0, 13, 2])], []]
+    bench.pack_records(recs, B, torch.device("cpu"), step_id=5, li=1, elems=elems, ids=ids)
+    item, boxes, conf, cls, cap = OD.unpack_record(recs[2])
+    assert item == 10 and boxes.shape == (4, 4) and torch.allclose(boxes[1], torch.tensor([0.5, 0.5, 0.6, 0.7]))
+    assert cap[1, :5].tolist() == [2, 0, 11, 12, 2] and cap[3, :4].tolist() == [2, 0, 13, 2] and int(cap[0].sum()) == 0 and int(cap[2].sum()) == 0
+    item2, boxes2, _, _, cap2 = OD.unpack_record(recs[3])
+    assert item2 == 11 and boxes2.shape == (0, 4) and cap2.shape[0] == 0
+    assert int(recs[:2].abs().sum()) == 0 and int(recs[4:].abs().sum()) == 0          # only this step's rows were written
