@@ -468,3 +468,15 @@ def test_bench_record_packing_round_trips():
     item2, boxes2, _, _, cap2 = OD.unpack_record(recs[3])
     assert item2 == 11 and boxes2.shape == (0, 4) and cap2.shape[0] == 0
     assert int(recs[:2].abs().sum()) == 0 and int(recs[4:].abs().sum()) == 0          # only this step's rows were written
+
+
+def test_bench_argument_parser_formats_its_help_and_defaults(monkeypatch, capsys):
+    """argparse expands '%' in help strings: a stray one only shows when somebody asks for --help.  Defaults = the driver's contract."""
+    import bench
+    monkeypatch.setattr("sys.argv", ["bench.py", "--help"])
+    with pytest.raises(SystemExit) as e:
+        bench.parse_args()
+    assert e.value.code == 0 and "--lane-masks" in capsys.readouterr().out
+    monkeypatch.setattr("sys.argv", ["bench.py"])
+    a = bench.parse_args()
+    assert (a.gpus, a.mode, a.batch, a.lanes, a.pipeline, a.lane_masks, a.split_masks, a.candidates) == (1, "e2e", 8, 2, True, "", "", "")
