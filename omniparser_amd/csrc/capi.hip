@@ -58,8 +58,107 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
   }
 }
 
+// ---------------------------------------------------------------------------------------------
+// OMNI_CHECK_PTRS: turn a bad address into OMNI_E_ARG instead of a GPU memory-access fault (which aborts the process and, in a
+// test run, hides every later test).  Every non-null p[k] of an op must lie in a device (or managed / host-registered) allocation
+// known to the HIP runtime, and the byte range the op will touch from it must end inside that allocation
+// (hipMemGetAddressRange; with a caching allocator the allocation is the allocator's segment — a wild pointer or a range that
+// runs off the segment is caught, a neighbour inside the same segment is not).  Ranges are computed for the op kinds that hold
+// almost all of a plan's launches (conv / GEMM family, pools, LayerNorm, depthwise conv, split-convert, fused FFN); for the
+// other kinds the first byte is checked.  On by default wherever a device is present — omni_op_launch (the single-op path is
+// never hot) and omni_plan_create (once per plan) — OMNI_CHECK_PTRS=0 turns it off, the host emulation has no device pointers.
+#ifndef OMNI_HOST_EMU
+static bool check_ptrs_enabled() {
+  const char* e = getenv("OMNI_CHECK_PTRS");
+  if (e && e[0] == '0') return false;
+  static int ndev = -1;
+  if (ndev < 0) { int n = 0; ndev = (hipGetDeviceCount(&n) == hipSuccess) ? n : 0; }
+  if (ndev <= 0) { (void)hipGetLastError(); return false; }
+  return true;
+}
+
+static void op_extents(const omni_op_t* op, long long ext[8]) {
+  for (int k = 0; k < 8; ++k) ext[k] = 1;
+  const long long esz = op->dtype == OMNI_F32 ? 4 : 2;
+  const int* i = op->i;
+  auto span = [&](long long rows, long long ld, long long coff, long long c) { return rows > 0 ? ((rows - 1) * ld + coff + c) * esz : 1; };
+  switch (op->kind) {
+    case OMNI_OP_CONV: {
+      const long long B = i[0], H = i[1], W = i[2], Cin = i[3], Cout = i[12], M = B * i[10] * i[11], K = (long long)i[6] * i[7] * Cin;
+      ext[0] = span(B * H * W, i[4], i[5], Cin);
+      ext[1] = Cout * K * (i[20] ? 4 : esz);                       // split formats: two f16 halves per weight
+      ext[2] = Cout * 4;
+      ext[3] = span(M, i[16], i[17], Cout);
+      ext[4] = span(M, i[13], i[14], Cout);
+      ext[5] = i[19] > 0 ? (long long)i[19] * 1024 : 1;
+      ext[6] = i[22] > 0 ? (long long)i[22] * 4 : 1;
+      break;
+    }
+    case OMNI_OP_MLP_FUSED: {
+      const long long rows = (long long)i[0] * i[1], C = i[3], hid = i[12];
+      ext[0] = span(rows, i[4], i[5], C); ext[1] = hid * C * 4; ext[2] = hid * 4; ext[3] = span(rows, i[16], i[17], C);
+      ext[4] = span(rows, i[13], i[14], C); ext[5] = hid * C * 4; ext[6] = C * 4;
+      break;
+    }
+    case OMNI_OP_SPLIT_CONVERT: {
+      const long long rows = (long long)i[0] * i[1];
+      ext[0] = span(rows, i[4], i[5], i[3]); ext[4] = span(rows, i[13], i[14], i[3]);
+      break;
+    }
+    case OMNI_OP_AVGPOOL2: case OMNI_OP_MAXPOOL: case OMNI_OP_RESIZE_NEAREST: {
+      const long long B = i[0], Ho = op->kind == OMNI_OP_AVGPOOL2 ? i[1] - 1 : i[10], Wo = op->kind == OMNI_OP_AVGPOOL2 ? i[2] - 1 : i[11];
+      ext[0] = span(B * i[1] * i[2], i[4], i[5], i[3]); ext[4] = span(B * Ho * Wo, i[13], i[14], i[3]);
+      break;
+    }
+    case OMNI_OP_LAYERNORM: {
+      const long long rows = (long long)i[0] * i[1], C = i[3];
+      ext[0] = rows * C * esz; ext[1] = (long long)(i[5] > 0 ? i[5] : 1) * C * esz; ext[2] = C * 4; ext[3] = C * 4;
+      ext[4] = rows * C * esz; ext[5] = rows * C * esz;
+      break;
+    }
+    case OMNI_OP_DWCONV3: case OMNI_OP_DWCONV3_LN: {
+      const long long n = (long long)i[0] * i[1] * i[2] * i[3] * esz, C = i[3];
+      ext[0] = n; ext[1] = 9 * C * esz; ext[2] = C * 4; ext[4] = n;
+      if (op->kind == OMNI_OP_DWCONV3_LN) { ext[3] = n; ext[5] = C * 4; ext[6] = C * 4; }
+      break;
+    }
+    default: break;
+  }
+  for (int k = 0; k < 8; ++k) if (ext[k] < 1) ext[k] = 1;
+}
+
+static int check_op_ptrs(const omni_op_t* op, int index) {
+  long long ext[8];
+  op_extents(op, ext);
+  for (int k = 0; k < 8; ++k) {
+    const void* ptr = op->p[k];
+    if (!ptr) continue;
+    hipDeviceptr_t base = nullptr;
+    size_t size = 0;
+    hipError_t e = hipMemGetAddressRange(&base, &size, (hipDeviceptr_t)ptr);
+    if (e != hipSuccess || !base) {
+      (void)hipGetLastError();
+      omni_set_error("op %d (kind %d): p[%d] = %p is not inside any device allocation (%s)", index, op->kind, k, ptr,
+                     e != hipSuccess ? hipGetErrorString(e) : "no base");
+      return OMNI_E_ARG;
+    }
+    const long long off = (const char*)ptr - (const char*)base;
+    if (off < 0 || off + ext[k] > (long long)size) {
+      omni_set_error("op %d (kind %d): p[%d] = %p + %lld bytes runs past its allocation [%p, +%zu)", index, op->kind, k, ptr, ext[k],
+                     (void*)base, size);
+      return OMNI_E_ARG;
+    }
+  }
+  return OMNI_OK;
+}
+#else
+static bool check_ptrs_enabled() { return false; }
+static int check_op_ptrs(const omni_op_t*, int) { return OMNI_OK; }
+#endif
+
 extern "C" int omni_op_launch(const omni_op_t* op, void* stream) {
   if (!op) { omni_set_error("omni_op_launch: null op"); return OMNI_E_ARG; }
+  if (check_ptrs_enabled()) { int rc = check_op_ptrs(op, 0); if (rc) return rc; }
   return dispatch(op, (hipStream_t)stream);
 }
 
@@ -82,6 +181,8 @@ extern "C" int omni_plan_create(const omni_op_t* ops, int n_ops, omni_plan_t** o
       return OMNI_E_ARG;
     }
   }
+  if (check_ptrs_enabled())
+    for (int i = 0; i < n_ops; ++i) { int rc = check_op_ptrs(&ops[i], i); if (rc) return rc; }
   omni_plan* p = new omni_plan();
   p->ops.assign(ops, ops + n_ops);
   *out = p;

@@ -2221,7 +2221,7 @@ int by_dtype(int dtype, const char* name, F32 f32, F16 f16) {
 }  // namespace
 
 int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
-  DwArgs a;
+  DwArgs a{};
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
   OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
@@ -2246,7 +2246,7 @@ int omni_launch_dwconv3(const omni_op_t* op, hipStream_t s) {
 }
 
 int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
-  DwLnArgs a;
+  DwLnArgs a{};
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.h = op->p[3]; a.y1 = op->p[4];
   a.g = (const float*)op->p[5]; a.b = (const float*)op->p[6];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3]; a.eps = op->f[0]; a.osplit = op->i[6];
@@ -2272,7 +2272,7 @@ int omni_launch_dwconv3_ln(const omni_op_t* op, hipStream_t s) {
 }
 
 int omni_launch_layernorm(const omni_op_t* op, hipStream_t s) {
-  LnArgs a;
+  LnArgs a{};
   a.x = op->p[0]; a.add = op->p[1]; a.g = (const float*)op->p[2]; a.b = (const float*)op->p[3]; a.y = op->p[4];
   a.rows = ((long long)op->i[0]) * (op->i[1] > 0 ? op->i[1] : 1); a.C = op->i[3]; a.period = op->i[5] > 0 ? op->i[5] : 1;
   a.eps = op->f[0];
@@ -2294,7 +2294,7 @@ int omni_launch_layernorm(const omni_op_t* op, hipStream_t s) {
 }
 
 static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
-  AttnArgs a;
+  AttnArgs a{};
   a.q = op->p[0]; a.k = op->p[1]; a.v = op->p[2]; a.o = op->p[4];
   a.kbias = (const float*)op->p[5]; a.vbias = (const float*)op->p[6];
   a.ldq = op->i[0]; a.ldk = op->i[1]; a.ldv = op->i[2]; a.ldo = op->i[3];
@@ -2347,7 +2347,7 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
 }
 
 static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
-  ChanArgs a;
+  ChanArgs a{};
   a.qkv = op->p[0]; a.o = op->p[4]; a.ws = (float*)op->p[5];
   a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3]; a.G = op->i[4]; a.chunk_tokens = op->i[5]; a.osplit = op->i[6];
   OMNI_REQUIRE(a.qkv && a.o && a.ws && a.B > 0 && a.N > 0 && a.C == a.G * 32 && a.chunk_tokens > 0, "chan_attn: bad arguments");
@@ -2375,7 +2375,7 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
 }
 
 static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
-  DecArgs a;
+  DecArgs a{};
   a.q = op->p[0]; a.knew = op->p[1]; a.vnew = op->p[2]; a.kc = op->p[3]; a.o = op->p[4]; a.vc = op->p[5];
   a.step = (const int*)op->p[6];
   a.ldq = op->i[0]; a.qoff = op->i[1]; a.ldn = op->i[2]; a.koff = op->i[3]; a.voff = op->i[4]; a.ldo = op->i[5];
@@ -2403,7 +2403,7 @@ static int launch_attn_decode(const omni_op_t* op, hipStream_t s) {
 }
 
 static int launch_greedy(const omni_op_t* op, hipStream_t s) {
-  GreedyArgs a;
+  GreedyArgs a{};
   a.logits = op->p[0]; a.bias = (const float*)op->p[1]; a.ids = (int*)op->p[2]; a.finished = (int*)op->p[3];
   a.step = (const int*)op->p[6];
   a.B = op->i[0]; a.V = op->i[1]; a.ldl = op->i[2]; a.T = op->i[3]; a.max_new = op->i[4]; a.ngram = op->i[5];
@@ -2419,7 +2419,7 @@ static int launch_greedy(const omni_op_t* op, hipStream_t s) {
 }
 
 static int launch_crop_resize(const omni_op_t* op, hipStream_t s) {
-  CropArgs a;
+  CropArgs a{};
   a.img = (const unsigned char*)op->p[0]; a.boxes = (const int*)op->p[1]; a.c64 = (unsigned char*)op->p[2];
   a.tmp = (unsigned char*)op->p[3]; a.y = op->p[4]; a.b = (const int*)op->p[5]; a.k = (const int*)op->p[6];
   a.lut = (const float*)op->p[7];
@@ -2441,14 +2441,14 @@ static int launch_crop_resize(const omni_op_t* op, hipStream_t s) {
 static int launch_glue(const omni_op_t* op, hipStream_t s) {
   int rc = OMNI_OK;
   if (op->kind == OMNI_OP_PROJ_PREP) {
-    PrepArgs a; a.x = op->p[0]; a.pos = (const float*)op->p[1]; a.temporal = (const float*)op->p[2]; a.y = op->p[4]; a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3];
+    PrepArgs a{}; a.x = op->p[0]; a.pos = (const float*)op->p[1]; a.temporal = (const float*)op->p[2]; a.y = op->p[4]; a.B = op->i[0]; a.N = op->i[1]; a.C = op->i[3];
     OMNI_REQUIRE(a.x && a.pos && a.temporal && a.y && a.B > 0 && a.N > 0 && a.C > 0, "proj_prep: bad arguments");
     dim3 g((a.C + 255) / 256, a.B);
     rc = by_dtype(op->dtype, "proj_prep",
         [&] { hipLaunchKernelGGL(proj_prep_kernel<float>, g, dim3(256), 0, s, a); },
         [&] { hipLaunchKernelGGL(proj_prep_kernel<half_t>, g, dim3(256), 0, s, a); });
   } else if (op->kind == OMNI_OP_ASSEMBLE) {
-    AsmArgs a; a.img = op->p[0]; a.txt = op->p[1]; a.y = op->p[4]; a.B = op->i[0]; a.n_img = op->i[1]; a.n_txt = op->i[2]; a.C = op->i[3];
+    AsmArgs a{}; a.img = op->p[0]; a.txt = op->p[1]; a.y = op->p[4]; a.B = op->i[0]; a.n_img = op->i[1]; a.n_txt = op->i[2]; a.C = op->i[3];
     OMNI_REQUIRE(a.img && a.txt && a.y && a.B > 0 && a.n_img > 0 && a.n_txt >= 0 && a.C > 0, "assemble: bad arguments");
     long long total = (long long)a.B * (a.n_img + a.n_txt) * a.C;
     dim3 g((unsigned)((total + 255) / 256));
@@ -2456,7 +2456,7 @@ static int launch_glue(const omni_op_t* op, hipStream_t s) {
         [&] { hipLaunchKernelGGL(assemble_kernel<float>, g, dim3(256), 0, s, a); },
         [&] { hipLaunchKernelGGL(assemble_kernel<half_t>, g, dim3(256), 0, s, a); });
   } else {
-    EmbArgs a; a.table = op->p[0]; a.pos = op->p[1]; a.ids = (const int*)op->p[2]; a.y = op->p[4]; a.step = (const int*)op->p[6];
+    EmbArgs a{}; a.table = op->p[0]; a.pos = op->p[1]; a.ids = (const int*)op->p[2]; a.y = op->p[4]; a.step = (const int*)op->p[6];
     a.B = op->i[0]; a.C = op->i[3]; a.T = op->i[4]; a.pos_offset = op->i[5]; a.scale = op->f[0] == 0.0f ? 1.0f : op->f[0];
     OMNI_REQUIRE(a.table && a.pos && a.ids && a.y && a.step && a.B > 0 && a.C > 0, "embed_step: bad arguments");
     dim3 g((a.C + 255) / 256, a.B);
@@ -2494,7 +2494,7 @@ int omni_launch_misc(const omni_op_t* op, hipStream_t s) {
 extern "C" int omni_debug_host_op(const omni_op_t* op, int variant) {
   if (!op) { omni_set_error("debug_host_op: null op"); return OMNI_E_ARG; }
   if (op->kind != OMNI_OP_DWCONV3) { omni_set_error("debug_host_op: kind %d has no host emulation", op->kind); return OMNI_E_ARG; }
-  DwArgs a;
+  DwArgs a{};
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
   OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");

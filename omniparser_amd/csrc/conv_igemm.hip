@@ -713,7 +713,7 @@ void launch_typed(ConvArgs& a, long long ws_bytes, hipStream_t s) {
 }  // namespace
 
 int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
-  ConvArgs a;
+  ConvArgs a{};
   a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.res = op->p[3]; a.y = op->p[4];
   a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.Cin = op->i[3]; a.ldi = op->i[4]; a.in_coff = op->i[5];
   a.KH = op->i[6]; a.KW = op->i[7]; a.stride = op->i[8]; a.pad = op->i[9]; a.Ho = op->i[10]; a.Wo = op->i[11];

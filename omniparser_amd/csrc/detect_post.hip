@@ -274,7 +274,7 @@ __global__ void zero_count_kernel(int* count) { if (threadIdx.x == 0) *count = 0
 }  // namespace
 
 int omni_launch_detect_decode(const omni_op_t* op, hipStream_t s) {
-  DecodeArgs a;
+  DecodeArgs a{};
   a.nc = op->i[0];
   int TH = op->i[1], TW = op->i[2];
   OMNI_REQUIRE(a.nc > 0 && TH > 0 && TW > 0 && TH % 32 == 0 && TW % 32 == 0, "detect_decode: bad nc/size");
@@ -306,7 +306,7 @@ int omni_launch_detect_decode(const omni_op_t* op, hipStream_t s) {
 }
 
 int omni_launch_nms(const omni_op_t* op, hipStream_t s) {
-  NmsArgs a;
+  NmsArgs a{};
   a.cand = (const Cand*)op->p[0]; a.count = (const int*)op->p[1];
   a.sorted = (Cand*)op->p[2]; a.mask = (unsigned long long*)op->p[3];
   a.out_boxes = (float*)op->p[4]; a.out_scores = (float*)op->p[5];

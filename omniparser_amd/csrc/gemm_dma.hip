@@ -354,7 +354,7 @@ __global__ __launch_bounds__(256) void split_convert_kernel(const float* __restr
 // the token matrix instead of 44.
 struct MlpArgs {
   const unsigned char* x; const unsigned char* w1; const unsigned char* w2; const float* b1;
-  GemmArgs ep;                        // epilogue view: bias = b2, res, y, M, ldo, out_coff, ldr, res_coff, oscale = 2^-k2
+  GemmArgs ep{};                        // epilogue view: bias = b2, res, y, M, ldo, out_coff, ldr, res_coff, oscale = 2^-k2
   int ldi, in_coff;
   float osc1;                         // 2^-k1
 };
@@ -520,7 +520,7 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
 
 // OMNI_OP_CONV with i20 == 2 (see include/omni_amd.h): pointwise, pre-split operands.
 int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s) {
-  GemmArgs a;
+  GemmArgs a{};
   a.x = (const unsigned char*)op->p[0]; a.w = (const unsigned char*)op->p[1]; a.bias = (const float*)op->p[2];
   a.res = (const float*)op->p[3]; a.y = (unsigned char*)op->p[4];
   const int B = op->i[0], H = op->i[1], W = op->i[2];
@@ -583,7 +583,7 @@ int omni_launch_split_convert(const omni_op_t* op, hipStream_t s) {
 
 // OMNI_OP_MLP_FUSED (see include/omni_amd.h): y = res + fc2(GELU(fc1(x))) on format-B operands, C = 128.
 int omni_launch_mlp_fused(const omni_op_t* op, hipStream_t s) {
-  MlpArgs a;
+  MlpArgs a{};
   a.x = (const unsigned char*)op->p[0]; a.w1 = (const unsigned char*)op->p[1]; a.b1 = (const float*)op->p[2];
   a.w2 = (const unsigned char*)op->p[5];
   a.ep.x = nullptr; a.ep.w = nullptr; a.ep.bias = (const float*)op->p[6]; a.ep.res = (const float*)op->p[3]; a.ep.y = (unsigned char*)op->p[4];

@@ -211,7 +211,7 @@ static int glue_args_from_op(const omni_op_t* op, GlueArgs& a, const char** why)
 
 // OMNI_OP_GLUE (see include/omni_amd.h)
 int omni_launch_glue(const omni_op_t* op, hipStream_t s) {
-  GlueArgs a;
+  GlueArgs a{};
   const char* why = nullptr;
   if (glue_args_from_op(op, a, &why)) { omni_set_error("%s", why); return OMNI_E_ARG; }
   hipLaunchKernelGGL(glue_kernel, dim3(1), dim3(256), 0, s, a);

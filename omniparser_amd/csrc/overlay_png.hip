@@ -468,7 +468,7 @@ __global__ __launch_bounds__(256) void base64_dyn_kernel(const unsigned char* __
 
 // OMNI_OP_OVERLAY (see include/omni_amd.h)
 int omni_launch_overlay(const omni_op_t* op, hipStream_t s) {
-  OvArgs a;
+  OvArgs a{};
   a.img = (unsigned char*)op->p[0]; a.prim = (const int*)op->p[1]; a.masks = (const unsigned char*)op->p[2];
   a.H = op->i[0]; a.W = op->i[1]; a.n = op->i[2];
   OMNI_REQUIRE(a.img && a.H > 0 && a.W > 0 && a.n >= 0 && (a.n == 0 || a.prim), "overlay: bad arguments");
@@ -480,7 +480,7 @@ int omni_launch_overlay(const omni_op_t* op, hipStream_t s) {
 
 // OMNI_OP_PNG_PACK (see include/omni_amd.h)
 int omni_launch_png_pack(const omni_op_t* op, hipStream_t s) {
-  PngArgs a;
+  PngArgs a{};
   a.img = (const unsigned char*)op->p[0]; a.png = (unsigned char*)op->p[1]; a.part = (unsigned*)op->p[2]; a.b64 = (unsigned char*)op->p[3];
   a.H = op->i[0]; a.W = op->i[1];
   OMNI_REQUIRE(a.img && a.png && a.part && a.H > 0 && a.W > 0 && a.H <= 32768 && a.W <= 32768, "png_pack: bad arguments");
@@ -510,7 +510,7 @@ int omni_launch_png_pack(const omni_op_t* op, hipStream_t s) {
 
 // OMNI_OP_PNG_DEFLATE (see include/omni_amd.h)
 int omni_launch_png_deflate(const omni_op_t* op, hipStream_t s) {
-  DefArgs a;
+  DefArgs a{};
   a.img = (const unsigned char*)op->p[0]; a.png = (unsigned char*)op->p[1]; a.filt = (unsigned char*)op->p[2];
   a.slots = (unsigned char*)op->p[3]; a.meta = (unsigned*)op->p[4]; a.part = (unsigned*)op->p[5]; a.b64 = (unsigned char*)op->p[6];
   a.H = op->i[0]; a.W = op->i[1];

@@ -132,7 +132,7 @@ int launch(const omni_op_t* op, PoolArgs& a, hipStream_t s) {
 }  // namespace
 
 int omni_launch_avgpool2(const omni_op_t* op, hipStream_t s) {
-  PoolArgs a;
+  PoolArgs a{};
   int rc = fill_args(op, a, "avgpool2");
   if (rc) return rc;
   OMNI_REQUIRE(a.H > 1 && a.W > 1, "avgpool2: input too small");
@@ -141,7 +141,7 @@ int omni_launch_avgpool2(const omni_op_t* op, hipStream_t s) {
 }
 
 int omni_launch_maxpool(const omni_op_t* op, hipStream_t s) {
-  PoolArgs a;
+  PoolArgs a{};
   int rc = fill_args(op, a, "maxpool");
   if (rc) return rc;
   OMNI_REQUIRE(a.k > 0 && a.stride > 0 && a.pad >= 0 && a.pad * 2 <= a.k, "maxpool: bad window");
@@ -151,7 +151,7 @@ int omni_launch_maxpool(const omni_op_t* op, hipStream_t s) {
 }
 
 int omni_launch_resize_nearest(const omni_op_t* op, hipStream_t s) {
-  PoolArgs a;
+  PoolArgs a{};
   int rc = fill_args(op, a, "resize_nearest");
   if (rc) return rc;
   OMNI_REQUIRE(a.Ho > 0 && a.Wo > 0, "resize_nearest: bad output size");

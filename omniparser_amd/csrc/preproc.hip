@@ -77,7 +77,7 @@ __global__ __launch_bounds__(256) void resample_v_letterbox_kernel(LbArgs a) {
 }  // namespace
 
 int omni_launch_letterbox(const omni_op_t* op, hipStream_t s) {
-  LbArgs a;
+  LbArgs a{};
   a.img = (const unsigned char*)op->p[0]; a.tmp = (unsigned char*)op->p[1];
   a.xb = (const int*)op->p[2]; a.xk = (const int*)op->p[3];
   a.y = op->p[4];

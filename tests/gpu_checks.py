@@ -318,6 +318,89 @@ def check_mfma_layout():
     return out
 
 
+def check_first_launch_canary():
+    """What the driver's process does first, one step at a time, each step synchronised and reported: torch alone (allocate, fill,
+    copy back), then the library's smallest launch on torch's current (null) stream, then the same launch on an explicit stream.
+    A fault in any step aborts the process — the printed trail says which one it was (printed with flush, so it survives SIGABRT)."""
+    import sys
+    trail = {}
+
+    def step(name, fn):
+        print(f"[canary] {name} ...", end="", file=sys.stderr, flush=True)
+        v = fn()
+        _sync()
+        print(" ok", file=sys.stderr, flush=True)
+        trail[name] = v if v is not None else True
+
+    step("torch_device", lambda: f"{torch.cuda.get_device_name(0)} / current {torch.cuda.current_device()}")
+    step("torch_fill_roundtrip", lambda: float(torch.full((1024,), 3.0, device=DEV).sum().cpu()))
+    pb = PlanBuilder(DEV, L.F32)
+    x = View(torch.ones(1, 4, 4, 32, device=DEV), 0, 32)
+    o1, o2 = pb.alloc(1, 4, 4, 32, zero=True), pb.alloc(1, 4, 4, 32, zero=True)
+    w = pb.pack_weight(torch.eye(32).view(32, 32, 1, 1))
+    pb.conv(x, w, None, o1, 1)
+    pb.conv(x, w, None, o2, 1)
+    step("library_loaded", lambda: L.lib().omni_abi_version())
+    step("pointers", lambda: {k: hex(v) for k, v in (("x", x.ptr), ("w", w.data_ptr()), ("y", o1.ptr), ("ws", pb.ws.data_ptr()))})
+    step("launch_null_stream", lambda: L.launch(pb.ops[0]))
+    assert (o1.t == 1.0).all(), "identity 1x1 conv on the null stream"
+    st = torch.cuda.Stream()
+    st.wait_stream(torch.cuda.current_stream())
+    step("launch_explicit_stream", lambda: (L.launch(pb.ops[1], st), st.synchronize())[0])
+    assert (o2.t == 1.0).all(), "identity 1x1 conv on an explicit stream"
+    return trail
+
+
+def check_bad_pointers_are_errors():
+    """OMNI_CHECK_PTRS (on by default where a device is present): a wild address, a host address and a range that runs off the end
+    of its allocation come back as OmniError (OMNI_E_ARG + omni_last_error), from omni_op_launch AND omni_plan_create — not as a GPU
+    memory-access fault that aborts the process."""
+    import ctypes
+    pb = PlanBuilder(DEV, L.F32)
+    x = View(torch.ones(1, 4, 4, 32, device=DEV), 0, 32)
+    o = pb.alloc(1, 4, 4, 32)
+    w = pb.pack_weight(torch.eye(32).view(32, 32, 1, 1))
+    pb.conv(x, w, None, o, 1)
+    good = pb.ops[0]
+    L.launch(good); _sync()
+    seen = {}
+
+    def clone(**kw):
+        op = L.OmniOp()
+        ctypes.memmove(ctypes.byref(op), ctypes.byref(good), ctypes.sizeof(op))
+        for k, v in kw.items():
+            if k.startswith("p"):
+                op.p[int(k[1:])] = v
+            else:
+                op.i[int(k[1:])] = v
+        return op
+
+    host = np.zeros(16 * 32, np.float32)
+    big = torch.empty(64 << 20, dtype=torch.uint8, device=DEV)          # its own 64 MiB segment of the caching allocator
+    cases = {
+        "wild": clone(p0=0x00007AB000001000),
+        "host": clone(p4=host.ctypes.data),
+        # y = the last 1 KiB of a 64 MiB allocation, M * Cout * 4 = 2 KiB to write
+        "past_end": clone(p4=big.data_ptr() + big.numel() - 1024),
+        "workspace_size_lie": clone(i19=1 << 30),
+    }
+    for name, op in cases.items():
+        for how in ("launch", "plan"):
+            try:
+                if how == "launch":
+                    L.launch(op)
+                else:
+                    L.Plan([good, op])
+            except L.OmniError as e:
+                seen[f"{name}/{how}"] = str(e)[:160]
+            else:
+                raise AssertionError(f"bad pointer case {name!r} was accepted by {how}")
+    _sync()
+    L.launch(good); _sync()                                             # the process is alive and the library still launches
+    assert (o.t == 1.0).all()
+    return seen
+
+
 # ------------------------------------------------------------------------------------------ pools
 def check_pools(dtype=L.F32, seed=0):
     g = torch.Generator().manual_seed(seed)

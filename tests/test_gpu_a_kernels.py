@@ -6,6 +6,20 @@ from omniparser_amd import _lib as L
 pytestmark = pytest.mark.gpu
 
 
+def test_first_launch_canary():
+    """the first device launch of the library in this process, step by step (round 3's driver run died here without a trail)"""
+    import gpu_checks as G
+    trail = G.check_first_launch_canary()
+    assert trail["launch_null_stream"] and trail["launch_explicit_stream"]
+
+
+def test_bad_pointers_are_errors_not_faults():
+    import gpu_checks as G
+    seen = G.check_bad_pointers_are_errors()
+    assert len(seen) == 8, seen
+    assert "not inside any device allocation" in seen["wild/launch"] and "runs past its allocation" in seen["past_end/plan"], seen
+
+
 def test_mfma_fragment_layout():
     import gpu_checks as G
     G.check_mfma_layout()

@@ -480,3 +480,25 @@ def test_bench_argument_parser_formats_its_help_and_defaults(monkeypatch, capsys
     monkeypatch.setattr("sys.argv", ["bench.py"])
     a = bench.parse_args()
     assert (a.gpus, a.mode, a.batch, a.lanes, a.pipeline, a.lane_masks, a.split_masks, a.candidates) == (1, "e2e", 8, 2, True, "", "", "")
+
+
+def test_build_staleness_is_decided_by_content_not_mtime(tmp_path):
+    """omniparser_amd/build.py: an object is stale when the sha256 stamp next to it does not match the content of its sources (+ the
+    compiler flags); touching a file — what a snapshot that does not preserve timestamps does to all of them — changes nothing."""
+    import os
+    from omniparser_amd import build as B
+    src, tgt = tmp_path / "a.hip", tmp_path / "a.o"
+    src.write_text("int x;\n")
+    assert B._stale(tgt, [src])                       # no target
+    tgt.write_bytes(b"obj")
+    assert B._stale(tgt, [src])                       # no stamp
+    B._mark(tgt, [src])
+    assert not B._stale(tgt, [src])
+    os.utime(src, (2_000_000_000, 2_000_000_000))     # newer than the target: irrelevant
+    os.utime(tgt, (1_000_000_000, 1_000_000_000))
+    assert not B._stale(tgt, [src])
+    src.write_text("int y;\n")
+    assert B._stale(tgt, [src])
+    # the shipped library carries a stamp that matches the tree it was built from
+    hdrs = list(B.CSRC.glob("*.h")) + [B.PKG.parent / "include" / "omni_amd.h"]
+    assert B.LIB.exists() and not B._stale(B.LIB, B.sources() + hdrs)
