@@ -52,15 +52,11 @@ def parse_args():
     ap.add_argument("--pipeline", dest="pipeline", action="store_true", help=argparse.SUPPRESS)
     ap.set_defaults(pipeline=True)
     ap.add_argument("--lanes", type=int, default=2, choices=[1, 2, 3, 4], help="with --pipeline: caption micro-batches in flight at once (HIP streams); "
-                    "3 / 4: experiments (each lane holds its own 128-row encode plans: ~54 GB, ~23 GB with --candidates reuse_activations)")
+                    "3 / 4: experiments (each lane holds its own 128-row encode plans, ~25 GB each at 768x768 crops)")
     ap.add_argument("--no-ab", action="store_true", help="skip the child-process measurements (`extra.e2e_r64_f16_reference_cuda_branch`, `extra.annotate_tail`, `extra.stream_*`)")
-    ap.add_argument("--lane-masks", default="", help="EXPERIMENT: CU sets of the encode lanes' streams, ';'-separated (\"0-127;128-255\": bit j = CU j/8 of XCD j%%8, every XCD needs a share - contiguous ranges; "
-                    "optional third set = decode stream); captioner plans then launch eagerly (OMNI_HIPGRAPH=0 for this process)")
-    ap.add_argument("--split-masks", default="", help="EXPERIMENT: \"<GEMM CU set>;<other CU set>\" (e.g. \"0-175;176-255\"): encode plans replay eagerly over two "
-                    "CU-masked streams per lane, MFMA-bound ops on the first set, HBM-bound ops on the second (Plan.run_split)")
-    ap.add_argument("--candidates", default="", help="A/B only: comma-separated boolean composition switches of Florence2Captioner to turn ON "
-                    "or PlanBuilder (window_attn_v2, chan_apply_mfma, mha_v2, reuse_activations, fuse_splitk: not adopted yet); recorded in config.candidates")
     ap.add_argument("--width", type=float, default=1.0, help="debug only: detector channel multiplier (1.0 = YOLOv9-E)")
+    ap.add_argument("--frame", default="1920x1080", help="debug only: synthetic frame size WxH (the metric is quoted on 1920x1080; the CPU test "
+                    "of the N > 1 path runs a small frame on the host emulation)")
     a = ap.parse_args()
     if a.batch is None:
         a.batch = 8 if a.mode == "e2e" else 1
@@ -95,23 +91,13 @@ def main():
     from omniparser_amd.util.yolov9 import YOLOv9Detector
     from tools.make_weights import caption_dir, default_path, ensure_via_subprocess   # imports nothing from oracle/
 
-    if args.lane_masks:
-        from omniparser_amd.florence import Florence2Captioner as _F2C
-        _F2C.lane_cu_masks = tuple(args.lane_masks.split(";"))
-        os.environ["OMNI_HIPGRAPH"] = "0"       # graph launches may not honour a stream's CU mask (tools/cu_mask_probe.py measures it)
-    if args.split_masks:
-        from omniparser_amd.florence import Florence2Captioner as _F2C
-        _F2C.split_cu_masks = tuple(args.split_masks.split(";"))
-        assert len(_F2C.split_cu_masks) in (2, 3), "--split-masks takes two CU sets (+ an optional third for the decode stream)"
-        os.environ["OMNI_HIPGRAPH"] = "0"
-    if args.candidates:
-        from tools import switch_on
-        switch_on(args.candidates.split(","))          # A/B only: boolean switches of Florence2Captioner / PlanBuilder, off by default
     rank, world, local_rank = OD.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    dev = L.require_device(torch.device("cuda", local_rank), "bench.py")       # the MI355X or nothing (no CPU fallback)
     torch.cuda.set_device(local_rank)
-    dev = torch.device("cuda", local_rank)
-    imgsz = 640 if args.imgsz == "640" else (IH, IW)
+    global IW, IH
+    IW, IH = (int(v) for v in args.frame.split("x"))
+    imgsz = int(args.imgsz) if args.imgsz.isdigit() else (IH, IW)
     # stand-in checkpoints are INPUT FILES (the reference downloads its weights): generated once, in a separate
     # process, by tools/make_weights.py — this process never imports oracle/ outside cpu_baseline()
     if rank == 0:
@@ -139,8 +125,6 @@ def main():
         cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
         parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
         parser.encode_lanes = args.lanes
-        if args.lanes > 2:
-            os.environ.setdefault("OMNI_MAX_CAPTION_PLANS", "12")     # one 128-row plan set per lane + the smaller capacities + two decode plans stay resident
     else:
         dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=B)
 
@@ -169,10 +153,6 @@ def main():
 
     def pack(step_id, li, elems, ids):
         crop_counts.append(sum(parser.stats["crops"]))
-        if li is not None and (args.lane_masks or args.split_masks):
-            # CU-masked streams are blocking streams: an upload on the null stream would wait for every lane's queued work
-            with torch.cuda.stream(det.stream):
-                return pack_records(recs, B, dev, step_id, li, elems, ids)
         if li is not None:
             pack_records(recs, B, dev, step_id, li, elems, ids)
 
@@ -235,7 +215,7 @@ def main():
                 "and Florence-2-base-shaped checkpoint",
         "config": {
             "workload": workload, "screenshots_per_step": B,
-            "network_input": "640x640" if args.imgsz == "640" else "1088x1920",
+            "network_input": f"{imgsz}x{imgsz}" if isinstance(imgsz, int) else "1088x1920",
             "conf": CONF, "nms_iou": NMS_IOU, "overlap_iou": OVERLAP_IOU, "max_det": MAX_DET,
             "parallelism": f"replicas x{world}, round-robin shards of steps, 1 all_gather/job",
             "hipgraph": det.use_graph, "mean_elements_per_screenshot": round(kept, 2),
@@ -259,12 +239,8 @@ def main():
         out["config"]["decode"] = ("one 20-step decode over all crops of the batch (cross-attention K/V of every micro-batch copied into one plan)"
                                    if os.environ.get("OMNI_MERGED_DECODE", "1") != "0" else "per micro-batch")
         out["config"]["hand_off"] = "device (detector + hand-off ops in one hipGraph)" if getattr(parser, "device_glue", False) else "host"
-    if args.candidates:
-        out["config"]["candidates"] = args.candidates.split(",")
-    if args.lane_masks:
-        out["config"]["lane_cu_masks"] = args.lane_masks.split(";")
-    if args.split_masks:
-        out["config"]["split_cu_masks"] = args.split_masks.split(";")
+    if args.frame != "1920x1080" or args.width != 1.0:
+        out["config"]["debug"] = {"frame": args.frame, "width": args.width, "note": "NOT the metric's workload (debug / CPU-test sizes)"}
     out["config"]["hbm_peak_allocated_gb"] = round(torch.cuda.max_memory_allocated(dev) / 1e9, 2)   # plans + weights of this process (torch allocator)
 
     if rank == 0:
@@ -286,7 +262,7 @@ def main():
             # this process is done with the GPU: give its activation pools back before the children build their own plans
             try:
                 import gc
-                parser.cap._plans.clear(); det._plans.clear()
+                parser.cap.clear_plans(); det._plans.clear()
                 gc.collect(); torch.cuda.empty_cache()
             except Exception:      # noqa: BLE001
                 pass

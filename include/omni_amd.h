@@ -118,12 +118,10 @@ enum {
    *  i0 ldq i1 ldk i2 ldv i3 ldo i4 qoff i5 koff i6 voff i7 ooff i8 heads i9 nq i10 nk i11 groups
    *  i12 mode i13 H i14 W i15 head_dim (32|64); f0 scale
    *  i16 = 1 (f32 plans, MFMA kernels): write o in format B (see OMNI_OP_CONV i20 = 2) for the LDS-DMA GEMM that follows
-   *  i17 = 1 (f32 plans): the candidate kernels — mode 1, head_dim 32: window kernel with window-relative 32-bit addressing and O^T
-   *  accumulators; mode 0, head_dim 64: double-buffered 64-key stages, 32x32x16 MFMAs, lazily moved softmax reference */
+   *  f32 plans, MFMA kernels (mode 1 with head_dim 32, mode 0 with head_dim 64): row pitches and channel offsets % 4 == 0 */
   OMNI_OP_ATTN_ROWS = 10,
   /* DaViT grouped channel attention (florence2 :223-259): p0 qkv [B*N,3C] p4 o [B*N,C] p5 ws f32[B*G*chunks*1024]
-   *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5)
-   *  i7 = 1 (f32 plans): the candidate apply kernel (split-f16 MFMA instead of f32 VALU) */
+   *  i0 B i1 N i3 C i4 G i5 chunk_tokens i6 = 1: o in format B (f32 plans); f0 scale (0 => N^-0.5) */
   OMNI_OP_CHAN_ATTN = 11,
   /* projector input (florence2 :568-590): y[b] = [mean_n(x+pos+t) ; x+pos+t]; p0 x [B,N,C] p1 pos2d f32[N,C] p2 temporal f32[C] p4 y [B,N+1,C]
    *  i0 B i1 N i3 C */
@@ -214,7 +212,12 @@ typedef struct omni_cand {
 /* NMS scratch `p2` must hold (cap + 1) records: the spare record carries
  * {max coordinate, coordinate-trick flag} of torchvision.ops.batched_nms. */
 
-/* Launch ONE op on `stream` (unit tests, eager mode). */
+/* Launch ONE op on `stream` (unit tests, eager mode).
+ * Pointer check (here and in omni_plan_create, wherever a device is present; OMNI_CHECK_PTRS=0 turns it off): every non-NULL p[k]
+ * must lie in a device allocation known to the HIP runtime, and the byte range the op touches from it (computed for the conv /
+ * GEMM family, pools, LayerNorm, depthwise conv, split-convert and the fused FFN; the first byte for the other kinds) must end
+ * inside that allocation — otherwise OMNI_E_ARG with the op index, slot and address in omni_last_error(), never a GPU
+ * memory-access fault (which would abort the process). */
 int omni_op_launch(const omni_op_t* op, void* stream);
 
 /* Plan: an immutable list of ops replayed per inference; optionally captured
@@ -242,19 +245,6 @@ int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms);
  * sequence.  bench.py derives `roofline.achieved` and the per-kernel-family split of a step from it; the numbers are
  * directly comparable with `rocprofv3 --kernel-trace --stats` of the same replay.  h_ms holds omni_plan_num_ops floats. */
 int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms);
-
-/* A HIP stream for plans, optionally restricted to a set of compute units (hipExtStreamCreateWithCUMask; bit i of the
- * mask = CU i in the HIP runtime's enumeration, n_words 32-bit words; n_words == 0: an ordinary non-blocking stream).
- * For partitioning the chip between concurrently running plans — e.g. the MFMA-bound GEMMs of one caption micro-batch
- * and the HBM-bound kernels of another (tools/cu_mask_probe.py measures whether that pays; nothing in the default
- * path uses a masked stream).  The stream is created on the calling thread's current device. */
-int omni_stream_create(const uint32_t* cu_mask, int n_words, void** out_stream);
-/* Eager replay of a plan over TWO streams: its MFMA-bound ops (OMNI_OP_CONV, OMNI_OP_MLP_FUSED) on `stream_gemm`, all other ops on
- * `stream_other`, program order kept by events at every change of stream.  The plan's inputs must be ready on `stream_other`; on
- * return `stream_other` is ordered behind the last op.  h_class (may be NULL; omni_plan_num_ops ints): per op its stream class
- * (1 = gemm) + 2 if an event hand-over precedes it; with both streams NULL nothing is launched and only h_class is filled. */
-int omni_plan_run_split(omni_plan_t* plan, void* stream_gemm, void* stream_other, int* h_class);
-int omni_stream_destroy(void* stream);
 
 /* Host mirror of the GEMM kernels' block -> output-tile permutation (XCD-aware order with an optional N partition
  * over XCD groups; csrc/conv_igemm.hip::tile_of_block).  Test/diagnostic entry point, no device work: for block

@@ -26,7 +26,7 @@ EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
-    "omni_debug_host_op", "omni_plan_profile", "omni_stream_create", "omni_stream_destroy", "omni_plan_run_split",
+    "omni_debug_host_op", "omni_plan_profile",
     "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
     "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
 ]
@@ -87,12 +87,6 @@ def bind(path):
     L.omni_plan_destroy.restype = None
     L.omni_resample_coeffs.argtypes = [c_int, c_int, c_int, POINTER(c_int32), POINTER(c_int32)]
     L.omni_resample_coeffs.restype = c_int
-    L.omni_stream_create.argtypes = [POINTER(ctypes.c_uint32), c_int, POINTER(c_void_p)]
-    L.omni_stream_create.restype = c_int
-    L.omni_plan_run_split.argtypes = [c_void_p, c_void_p, c_void_p, POINTER(c_int)]
-    L.omni_plan_run_split.restype = c_int
-    L.omni_stream_destroy.argtypes = [c_void_p]
-    L.omni_stream_destroy.restype = c_int
     L.omni_plan_time.argtypes = [c_void_p, c_void_p, c_int, POINTER(c_float)]
     L.omni_plan_time.restype = c_int
     L.omni_plan_profile.argtypes = [c_void_p, c_void_p, POINTER(c_float)]
@@ -210,46 +204,6 @@ def _stream_ptr(stream):
     return c_void_p(stream.cuda_stream)
 
 
-def parse_cu_spec(spec, total=256):
-    """"0-127" | "0-31,64-95" | "0-255:2" -> sorted mask-bit indices.  Measured on the MI355X (profiles/r3_cu_mask_probe.md): bit j is
-    CU j / 8 of XCD j % 8, and an XCD whose share of the mask is empty is not restricted at all — a partition of the chip is a
-    contiguous range in multiples of 8 bits ("0-127" = 16 CUs of every XCD); strided sets restrict nothing."""
-    cus = set()
-    for item in filter(None, str(spec).split(",")):
-        rng, _, step = item.partition(":")
-        a, _, b = rng.partition("-")
-        cus.update(range(int(a), int(b or a) + 1, int(step or 1)))
-    if not cus or min(cus) < 0 or max(cus) >= total:
-        raise ValueError(f"bad CU set {spec!r} (indices 0..{total - 1})")
-    return sorted(cus)
-
-
-def cu_mask_words(cus, total=256):
-    """Set of CU indices (HIP runtime enumeration) -> the 32-bit words hipExtStreamCreateWithCUMask takes."""
-    words = [0] * ((total + 31) // 32)
-    for c in cus:
-        if not 0 <= c < total:
-            raise ValueError(f"CU index {c} outside 0..{total - 1}")
-        words[c // 32] |= 1 << (c % 32)
-    return words
-
-
-def masked_stream(device, words):
-    """A torch stream object over a HIP stream restricted to the CUs of `words` (cu_mask_words); the HIP stream lives as long as
-    the returned object.  Experimental plumbing for partitioning the chip between concurrent plans (tools/cu_mask_probe.py):
-    the default path never creates one."""
-    import torch
-    import weakref
-    arr = (ctypes.c_uint32 * len(words))(*words)
-    h = c_void_p()
-    with torch.cuda.device(device):
-        check(lib().omni_stream_create(arr, len(words), ctypes.byref(h)))
-    st = torch.cuda.ExternalStream(h.value, device=device)
-    fin = weakref.finalize(st, lib().omni_stream_destroy, c_void_p(h.value))
-    fin.atexit = False            # at interpreter exit the HIP runtime tears its streams down itself (and may already be gone)
-    return st
-
-
 class Plan:
     """Immutable op list executed by the C++ plan executor (eager or hipGraph replay)."""
 
@@ -263,18 +217,6 @@ class Plan:
 
     def run(self, stream=None):
         check(lib().omni_plan_run(self._h, _stream_ptr(stream)))
-
-    def run_split(self, stream_gemm, stream_other):
-        """eager replay over two streams: MFMA-bound ops on `stream_gemm`, the rest on `stream_other` (inputs ready there, results
-        ordered there on return); include/omni_amd.h::omni_plan_run_split"""
-        assert stream_gemm is not None and stream_other is not None
-        check(lib().omni_plan_run_split(self._h, _stream_ptr(stream_gemm), _stream_ptr(stream_other), None))
-
-    def split_schedule(self):
-        """[(stream class 0 / 1, hand-over before the op)] per op — what run_split would do, nothing launched."""
-        arr = (c_int * len(self.ops))()
-        check(lib().omni_plan_run_split(self._h, None, None, arr))
-        return [(v & 1, bool(v & 2)) for v in arr]
 
     def capture(self, stream):
         check(lib().omni_plan_capture(self._h, _stream_ptr(stream)))

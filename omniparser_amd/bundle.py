@@ -48,7 +48,7 @@ def write_bundle(path, plans: Dict[str, list], named: Dict[str, tuple], ints: Di
 
     def resolve(ptr):
         k = bisect.bisect_right(bases, ptr) - 1
-        if k < 0 or ptr > live[k][0] + live[k][1]:
+        if k < 0 or ptr >= live[k][0] + live[k][1]:      # one past the end belongs to whatever lies behind, never to this tensor
             raise ValueError(f"device pointer {ptr:#x} does not belong to a PlanBuilder tensor: the plan cannot be exported")
         return k, ptr - live[k][0]
 

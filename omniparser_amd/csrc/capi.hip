@@ -166,12 +166,7 @@ struct omni_plan {
   std::vector<omni_op_t> ops;
   hipGraph_t graph = nullptr;
   hipGraphExec_t exec = nullptr;
-  std::vector<hipEvent_t> split_events;        // omni_plan_run_split: one per change of stream class, created on first use
 };
-
-// omni_plan_run_split: the MFMA-bound ops of a plan (convolutions / linear layers / the fused FFN) go to one stream, everything else
-// (HBM- or latency-bound: LayerNorm, depthwise conv, attention, pooling, ...) to another.
-static inline int op_stream_class(int kind) { return (kind == OMNI_OP_CONV || kind == OMNI_OP_MLP_FUSED) ? 1 : 0; }
 
 extern "C" int omni_plan_create(const omni_op_t* ops, int n_ops, omni_plan_t** out) {
   if (!ops || n_ops <= 0 || !out) { omni_set_error("omni_plan_create: bad arguments"); return OMNI_E_ARG; }
@@ -235,73 +230,9 @@ extern "C" int omni_plan_replay(omni_plan_t* plan, void* stream) {
 
 extern "C" void omni_plan_destroy(omni_plan_t* plan) {
   if (!plan) return;
-  for (hipEvent_t e : plan->split_events) hipEventDestroy(e);
   if (plan->exec) hipGraphExecDestroy(plan->exec);
   if (plan->graph) hipGraphDestroy(plan->graph);
   delete plan;
-}
-
-// Eager replay over TWO streams (see op_stream_class).  Program order is kept by events: whenever consecutive ops sit on different
-// streams the producer's stream records an event behind the earlier op and the consumer's stream waits for it before the later one —
-// by induction every op starts after ALL earlier ops of the plan have completed (same stream: FIFO; other stream: the event), so
-// read-after-write and write-after-read hazards are those of the one-stream replay.  Contract: the plan's inputs are ready on
-// `stream_other` when this is called, and on return `stream_other` is ordered behind the plan's last op (the caller carries on there).
-// With CU-masked streams (omni_stream_create) the GEMMs of one caption micro-batch and the HBM-bound kernels of another run side by
-// side on disjoint CU sets (the GEMM is power-bound: profiles/r3_cu_mask_probe.md).  h_class (optional, omni_plan_num_ops ints):
-// receives per op 0 / 1 = stream class, +2 if an event wait precedes the op — with null streams nothing is launched (dry run for tests).
-extern "C" int omni_plan_run_split(omni_plan_t* plan, void* stream_gemm, void* stream_other, int* h_class) {
-  if (!plan) { omni_set_error("omni_plan_run_split: null plan"); return OMNI_E_ARG; }
-  const bool dry = !stream_gemm && !stream_other;
-  if (!dry && (!stream_gemm || !stream_other || stream_gemm == stream_other)) {
-    omni_set_error("omni_plan_run_split: needs two different non-default streams");
-    return OMNI_E_ARG;
-  }
-  if (dry && !h_class) { omni_set_error("omni_plan_run_split: dry run without an output array"); return OMNI_E_ARG; }
-  hipStream_t st[2] = {(hipStream_t)stream_other, (hipStream_t)stream_gemm};
-  size_t n_ev = 0;
-  auto hand_over = [&](int from, int to) -> int {          // `to` continues behind everything queued on `from` so far
-    if (dry) return OMNI_OK;
-    if (n_ev == plan->split_events.size()) {
-      hipEvent_t e;
-      OMNI_HIP_CHECK(hipEventCreateWithFlags(&e, hipEventDisableTiming));
-      plan->split_events.push_back(e);
-    }
-    hipEvent_t e = plan->split_events[n_ev++];
-    OMNI_HIP_CHECK(hipEventRecord(e, st[from]));
-    OMNI_HIP_CHECK(hipStreamWaitEvent(st[to], e, 0));
-    return OMNI_OK;
-  };
-  int cur = 0;                                             // the inputs are ready on stream_other
-  for (size_t i = 0; i < plan->ops.size(); ++i) {
-    const int c = op_stream_class(plan->ops[i].kind);
-    if (h_class) h_class[i] = c + (c != cur ? 2 : 0);
-    if (c != cur) { int rc = hand_over(cur, c); if (rc) return rc; cur = c; }
-    if (dry) continue;
-    int rc = dispatch(&plan->ops[i], st[c]);
-    if (rc) {
-      char prev[400];
-      strncpy(prev, g_err, sizeof(prev) - 1); prev[sizeof(prev) - 1] = 0;
-      omni_set_error("plan op %zu (kind %d): %s", i, plan->ops[i].kind, prev);
-      return rc;
-    }
-  }
-  if (cur != 0) return hand_over(cur, 0);                   // join: the caller continues on stream_other
-  return OMNI_OK;
-}
-
-extern "C" int omni_stream_create(const uint32_t* cu_mask, int n_words, void** out_stream) {
-  if (!out_stream || n_words < 0 || (n_words > 0 && !cu_mask)) { omni_set_error("omni_stream_create: bad arguments"); return OMNI_E_ARG; }
-  hipStream_t s = nullptr;
-  if (n_words == 0) OMNI_HIP_CHECK(hipStreamCreateWithFlags(&s, hipStreamNonBlocking));
-  else OMNI_HIP_CHECK(hipExtStreamCreateWithCUMask(&s, (uint32_t)n_words, cu_mask));
-  *out_stream = (void*)s;
-  return OMNI_OK;
-}
-
-extern "C" int omni_stream_destroy(void* stream) {
-  if (!stream) { omni_set_error("omni_stream_destroy: null stream"); return OMNI_E_ARG; }
-  OMNI_HIP_CHECK(hipStreamDestroy((hipStream_t)stream));
-  return OMNI_OK;
 }
 
 extern "C" int omni_plan_time(omni_plan_t* plan, void* stream, int iters, float* ms) {

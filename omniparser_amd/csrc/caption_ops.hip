@@ -805,15 +805,9 @@ __global__ __launch_bounds__(192) void window_attn_mfma_kernel(AttnArgs a) {
   }
 }
 
-// Round-3 rewrite of the f32 window kernel.  The kernel above walks global memory in dependent phases (seven staging iterations with a
-// load -> convert -> LDS-write chain each, then per query tile a Q load right in front of its first MFMA) and spends ~870 VALU
-// instructions per 16-query tile on one-value-at-a-time f32 -> (hi, lo) conversions; with three 3-wave blocks per CU it ran at
-// 2.0-2.2 TB/s.  Here (a) every global load of the block is issued before the first use — the wave's three Q tiles, then K (six
-// 16-byte loads per thread) and V (four or eight); (b) V is transposed in registers per (4 keys x 4 channels) item, so V^T goes to
-// LDS as 8-byte writes instead of 2-byte ones; (c) conversions work on PAIRS (v_cvt_pkrtz + packed f32 sub / mul: 3 instructions
-// per value instead of 5), the softmax scale is folded into Q, hi + lo/2048 is one fma.  Same split-f16 x3 MFMA arithmetic; the hi
-// halves are now round-toward-zero (the lo half absorbs the remainder either way), so results agree with the kernel above to f32
-// rounding, not bit for bit.
+// Pair-wise f32 -> (hi, lo) splits of the f32 attention kernels below (v_cvt_pkrtz + packed f32 sub / mul: 3 instructions per value
+// instead of 5 for the one-value-at-a-time form of the generic kernel above).  hi halves are round-toward-zero; the lo half (scaled by
+// 2048) absorbs the remainder either way.
 __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& l) {
   typedef __fp16 hv2 __attribute__((ext_vector_type(2)));
   const hv2 hh = __builtin_amdgcn_cvt_pkrtz(a, b);
@@ -825,174 +819,6 @@ __device__ __forceinline__ void split2(float a, float b, unsigned& h, unsigned& 
 __device__ __forceinline__ void split4v(const f32x4& v, uint2& h, uint2& l) {
   split2(v[0], v[1], h.x, l.x);
   split2(v[2], v[3], h.y, l.y);
-}
-
-// Measured and not kept (profiles/r3_s10_caption_per_op_{default,ab}.txt: 13 % slower on every stage): a variant without padding
-// branches, with 32-bit token offsets and the output tile transposed through LDS for 16-byte stores — the extra LDS round trip and
-// wave synchronisation cost more than the scattered 4-byte stores of this kernel.
-__global__ __launch_bounds__(192) void window_attn_mfma_f32_kernel(AttnArgs a) {
-  constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
-  __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
-  unsigned char* Kh = lds;
-  unsigned char* Kl = lds + NKP * KROW;
-  unsigned char* Vh = lds + 2 * NKP * KROW;
-  unsigned char* Vl = Vh + D * VROW;
-  const int g = blockIdx.z, h = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
-  const float* Qp = (const float*)a.q; const float* Kp = (const float*)a.k; const float* Vp = (const float*)a.v;
-  // window origin (uniform): token row of window-local index i = base + (i / 12) * W + i % 12 unless it falls outside the image
-  const int wpi = a.wy * a.wx;
-  const int b = g / wpi, wrem = g - b * wpi;
-  const int wyi = wrem / a.wx, wxi = wrem - wyi * a.wx;
-  const int r0 = wyi * 12, c0 = wxi * 12;
-  auto row_of = [&](int i) -> long long {
-    const int r = r0 + i / 12, c = c0 + i % 12;
-    return (r >= a.H || c >= a.W) ? -1ll : ((long long)b * a.H + r) * a.W + c;
-  };
-  const int qc = lane & 15, grp = lane >> 4;
-  const f32x4 z4 = {0.f, 0.f, 0.f, 0.f};
-  // ---- 1. all global loads of the block
-  f32x4 qraw[3][2];
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const long long qrow = row_of((wave + 3 * t) * 16 + qc);
-    const float* qp = Qp + (qrow >= 0 ? qrow : 0) * a.ldq + a.qoff + h * D + grp * 8;
-    qraw[t][0] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp) : z4;
-    qraw[t][1] = qrow >= 0 ? *reinterpret_cast<const f32x4*>(qp + 4) : z4;
-  }
-  f32x4 kraw[6];
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {                       // item e = (key, 4-channel group): 144 * 8 = 6 * 192
-    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
-    const long long row = row_of(key);
-    if (row >= 0) kraw[j] = *reinterpret_cast<const f32x4*>(Kp + row * a.ldk + a.koff + h * D + d0);
-    else kraw[j] = a.kbias ? f32x4{a.kbias[h * D + d0], a.kbias[h * D + d0 + 1], a.kbias[h * D + d0 + 2], a.kbias[h * D + d0 + 3]} : z4;
-  }
-  f32x4 vraw[2][4];
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {                       // item e = (key quad, 4-channel group): 36 * 8 = 288 = 192 + 96
-    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
-    if (e < 288) {
-#pragma unroll
-      for (int u = 0; u < 4; ++u) {
-        const long long row = row_of(kq * 4 + u);
-        if (row >= 0) vraw[j][u] = *reinterpret_cast<const f32x4*>(Vp + row * a.ldv + a.voff + h * D + d0);
-        else vraw[j][u] = a.vbias ? f32x4{a.vbias[h * D + d0], a.vbias[h * D + d0 + 1], a.vbias[h * D + d0 + 2], a.vbias[h * D + d0 + 3]} : z4;
-      }
-    }
-  }
-  // ---- 2. LDS image: K rows (hi | lo), V^T rows (hi | lo), keys 144..159 zero
-#pragma unroll
-  for (int j = 0; j < 6; ++j) {
-    const int e = tid + 192 * j, key = e >> 3, d0 = (e & 7) * 4;
-    uint2 kh, kl;
-    split4v(kraw[j], kh, kl);
-    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = kh;
-    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = kl;
-  }
-  if (tid < 128) {                                    // padding keys 144..159: 16 keys x 8 channel groups
-    const int key = 144 + (tid >> 3), d0 = (tid & 7) * 4;
-    const uint2 zh = {0u, 0u};
-    *reinterpret_cast<uint2*>(Kh + key * KROW + d0 * 2) = zh;
-    *reinterpret_cast<uint2*>(Kl + key * KROW + d0 * 2) = zh;
-  } else {                                            // V^T columns 144..159 of all 32 rows (hi and lo): 64 threads x 16 halves
-    const int r = tid - 128;                          // 0..63: (hi | lo, d)
-    unsigned char* p = (r < 32 ? Vh : Vl) + (r & 31) * VROW + 144 * 2;
-    const u32x4 z = {0u, 0u, 0u, 0u};
-    *reinterpret_cast<u32x4*>(p) = z;
-    *reinterpret_cast<u32x4*>(p + 16) = z;
-  }
-#pragma unroll
-  for (int j = 0; j < 2; ++j) {
-    const int e = tid + 192 * j, kq = e >> 3, d0 = (e & 7) * 4;
-    if (e < 288) {
-#pragma unroll
-      for (int dd = 0; dd < 4; ++dd) {                // channel d0 + dd: its four keys 4kq .. 4kq+3
-        uint2 vh, vl;
-        split4v(f32x4{vraw[j][0][dd], vraw[j][1][dd], vraw[j][2][dd], vraw[j][3][dd]}, vh, vl);
-        *reinterpret_cast<uint2*>(Vh + (d0 + dd) * VROW + kq * 8) = vh;
-        *reinterpret_cast<uint2*>(Vl + (d0 + dd) * VROW + kq * 8) = vl;
-      }
-    }
-  }
-  __syncthreads();
-
-  const float inv2048 = 1.0f / 2048.0f;
-#pragma unroll
-  for (int t = 0; t < 3; ++t) {
-    const int qt = wave + 3 * t;
-    u32x4 qhu, qlu;                                   // Q fragment (8 halves each), pre-multiplied by the softmax scale
-    {
-      const f32x4 q0 = qraw[t][0] * a.scale, q1 = qraw[t][1] * a.scale;
-      uint2 h0, l0, h1, l1;
-      split4v(q0, h0, l0);
-      split4v(q1, h1, l1);
-      qhu = u32x4{h0.x, h0.y, h1.x, h1.y};
-      qlu = u32x4{l0.x, l0.y, l1.x, l1.y};
-    }
-    const h16x8 qh = __builtin_bit_cast(h16x8, qhu), ql = __builtin_bit_cast(h16x8, qlu);
-    float sc[40];
-    float mx = -INFINITY;
-#pragma unroll
-    for (int kt = 0; kt < 10; ++kt) {
-      const unsigned char* kr = Kh + (kt * 16 + qc) * KROW + grp * 16;
-      h16x8 kh = *reinterpret_cast<const h16x8*>(kr);
-      h16x8 kl = *reinterpret_cast<const h16x8*>(kr + NKP * KROW);
-      f32x4 accM = {0.f, 0.f, 0.f, 0.f}, accC = {0.f, 0.f, 0.f, 0.f};
-      accM = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, qh, accM, 0, 0, 0);
-      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kh, ql, accC, 0, 0, 0);
-      accC = __builtin_amdgcn_mfma_f32_16x16x32_f16(kl, qh, accC, 0, 0, 0);
-#pragma unroll
-      for (int r = 0; r < 4; ++r) {
-        const int key = kt * 16 + grp * 4 + r;
-        float sv = __builtin_fmaf(accC[r], inv2048, accM[r]);
-        sv = key < 144 ? sv : -INFINITY;
-        sc[kt * 4 + r] = sv;
-        mx = fmaxf(mx, sv);
-      }
-    }
-    mx = fmaxf(mx, __shfl_xor(mx, 16));
-    mx = fmaxf(mx, __shfl_xor(mx, 32));
-    float sum = 0.0f;
-#pragma unroll
-    for (int e = 0; e < 40; ++e) { sc[e] = __expf(sc[e] - mx); sum += sc[e]; }
-    sum += __shfl_xor(sum, 16);
-    sum += __shfl_xor(sum, 32);
-    f32x4 oM[2], oC[2];
-#pragma unroll
-    for (int dt = 0; dt < 2; ++dt) { oM[dt] = z4; oC[dt] = z4; }
-#pragma unroll
-    for (int j = 0; j < 5; ++j) {
-      uint2 h0, l0, h1, l1;
-      split4v(f32x4{sc[8 * j + 0], sc[8 * j + 1], sc[8 * j + 2], sc[8 * j + 3]}, h0, l0);
-      split4v(f32x4{sc[8 * j + 4], sc[8 * j + 5], sc[8 * j + 6], sc[8 * j + 7]}, h1, l1);
-      const h16x8 ph = __builtin_bit_cast(h16x8, u32x4{h0.x, h0.y, h1.x, h1.y});
-      const h16x8 pl = __builtin_bit_cast(h16x8, u32x4{l0.x, l0.y, l1.x, l1.y});
-#pragma unroll
-      for (int dt = 0; dt < 2; ++dt) {
-        const unsigned char* vr = Vh + (dt * 16 + qc) * VROW + (32 * j + 4 * grp) * 2;
-        const uint2 a0 = *reinterpret_cast<const uint2*>(vr), a1 = *reinterpret_cast<const uint2*>(vr + 32);
-        const uint2 b0 = *reinterpret_cast<const uint2*>(vr + D * VROW), b1 = *reinterpret_cast<const uint2*>(vr + D * VROW + 32);
-        const h16x8 vh = __builtin_bit_cast(h16x8, u32x4{a0.x, a0.y, a1.x, a1.y});
-        const h16x8 vl = __builtin_bit_cast(h16x8, u32x4{b0.x, b0.y, b1.x, b1.y});
-        oM[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vh, oM[dt], 0, 0, 0);
-        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(ph, vl, oC[dt], 0, 0, 0);
-        oC[dt] = __builtin_amdgcn_mfma_f32_16x16x32_f16(pl, vh, oC[dt], 0, 0, 0);
-      }
-    }
-#pragma unroll
-    for (int r = 0; r < 4; ++r) {
-      const int ql_ = grp * 4 + r;
-      const float rs = __shfl(sum, ql_);
-      const long long orow = row_of(qt * 16 + ql_);
-      if (orow >= 0) {
-        const float inv = 1.0f / rs;
-#pragma unroll
-        for (int dt = 0; dt < 2; ++dt)
-          store_out<float>(a.o, orow, a.ldo, a.ooff + h * D + dt * 16 + qc, __builtin_fmaf(oC[dt][r], inv2048, oM[dt][r]) * inv, a.osplit);
-      }
-    }
-  }
 }
 
 // split2 with the remainder as one mixed-precision fma per value (v_fma_mix_f32 reads the f16 hi half directly: no v_cvt_f32_f16, no
@@ -1010,8 +836,8 @@ __device__ __forceinline__ void split4m(const f32x4& v, uint2& h, uint2& l) {
   split2m(v[2], v[3], h.y, l.y);
 }
 
-// Candidate successor of window_attn_mfma_f32_kernel (op->i[17] = 1; written after the last GPU session of round 3: verified on the
-// host emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above issues 2 319 VALU instructions
+// The f32 window kernel (adopted in round 4: 2.45 vs 3.69 ms per launch at 4.7 M tokens, 3.7-3.9 TB/s instead of 2.4-2.6;
+// profiles/r4_s2_per_op_*.txt).  Its round-3 predecessor issued 2 319 VALU instructions
 // per wave for 171 MFMAs (profiles/r3_static_isa_report.txt): it is bound by its vector ALU, not by HBM (2.1-2.3 TB/s) or the matrix
 // pipe.  Same LDS image, same split-f16 x3 arithmetic, same blocks; what changes is where the VALU instructions went:
 //   * token addressing: ~30 calls of row_of() per thread (two divisions by 12, a 64-bit row index, a 64-bit multiply by the row
@@ -1024,7 +850,7 @@ __device__ __forceinline__ void split4m(const f32x4& v, uint2& h, uint2& l) {
 //   * scores: the 10th key tile (keys 144..159) is padding for every window — not computed; log2(e) is folded into the Q scale so an
 //     exponential is v_sub + v_exp; merges, maxima and sums are written on pairs (packed f32 instructions).
 // Results agree with the kernel above to f32 rounding (the exponentials see scores scaled before the split instead of after).
-__global__ __launch_bounds__(192, 2) void window_attn_mfma_f32_v2_kernel(AttnArgs a) {
+__global__ __launch_bounds__(192, 2) void window_attn_mfma_f32_kernel(AttnArgs a) {
   constexpr int D = 32, NKP = 160, KROW = 80, VROW = 336;
   __shared__ __attribute__((aligned(16))) unsigned char lds[2 * NKP * KROW + 2 * D * VROW];
   unsigned char* Kh = lds;
@@ -1365,8 +1191,8 @@ __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
 }
 
 
-// Candidate successor of mha_mfma_kernel<float> (op->i[17] = 1 in mode 0; written after the last GPU session of round 3: verified on
-// the host emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above stages 32 keys at a time
+// f32 plans (adopted in round 4: 4.07 vs 6.84 ms for the six encoder layers of a 128-crop batch, 198 vs 118 TF/s; profiles/r4_s2_per_op_*.txt).
+// The generic kernel above (f16 plans) stages 32 keys at a time
 // with 4-byte loads, converts one value per instruction, writes V^T to LDS two bytes at a time and brackets every 32 keys with two
 // block barriers and no load in flight across them: at 585 keys a block spends its 19 iterations mostly waiting (1.0 ms per launch
 // at 134.6 GFLOP = 132 TF/s of useful work; the MFMA work alone is ~0.25 ms).  Here:
@@ -1381,7 +1207,7 @@ __global__ __launch_bounds__(256, 2) void mha_mfma_kernel(AttnArgs a) {
 //     few times per row instead of once per block; p = exp2(s - ref) <= 256 stays well inside f16 / f32 range and the final
 //     division by the row sum makes the result independent of the reference;
 //   * each lane owns ONE query and 4 consecutive channels per accumulator quad: 16-byte f32 / 8-byte hi and lo stores.
-__global__ __launch_bounds__(256, 2) void mha_mfma_f32_v2_kernel(AttnArgs a) {
+__global__ __launch_bounds__(256, 2) void mha_mfma_f32_kernel(AttnArgs a) {
   constexpr int D = 64, KB = 64;
   constexpr int KROW = 144;                     // bytes per staged K row: 64 halves + 16 pad (16-byte fragment reads, conflict-free)
   constexpr int VROW = 136;                     // bytes per staged V^T row: 64 halves + 8 pad (8-byte fragment reads, conflict-free)
@@ -1738,63 +1564,16 @@ __global__ __launch_bounds__(256) void chan_softmax_kernel(ChanArgs a) {
   for (int e = 0; e < 4; ++e) p0[i * 32 + j0 + e] = sa[i][j0 + e];     // A over the chunk-0 partial of this (image, group)
 }
 
-// apply: one token per lane, the 32x32 attention matrix of the (image, group) in LDS (broadcast 16-byte reads), 4 output channels per
-// store.  Measured and not kept (profiles/r3_s10_caption_per_op_{default,ab}.txt: 15 % slower): the same product on
-// v_mfma_f32_32x32x2_f32 with v loaded straight into the column operand (16 strided dword loads per 32-token tile).
-__global__ __launch_bounds__(256) void chan_apply_v4_kernel(ChanArgs a) {
-  __shared__ __attribute__((aligned(16))) float sa[32][36];
-  const int g = blockIdx.y, b = blockIdx.z;
-  {
-    const float* A = a.ws + ((long long)b * a.G + g) * a.chunks * 1024;
-    const int i = threadIdx.x >> 3, j0 = (threadIdx.x & 7) * 4;
-    *reinterpret_cast<f32x4*>(&sa[i][j0]) = *reinterpret_cast<const f32x4*>(A + i * 32 + j0);
-  }
-  __syncthreads();
-  const int n = blockIdx.x * 256 + threadIdx.x;
-  if (n >= a.N) return;
-  const float* vrow = (const float*)a.qkv + ((long long)b * a.N + n) * 3 * a.C + 2 * a.C + g * 32;
-  float v[32];
-#pragma unroll
-  for (int q = 0; q < 8; ++q) {
-    const f32x4 t = *reinterpret_cast<const f32x4*>(vrow + q * 4);
-    v[q * 4 + 0] = t[0]; v[q * 4 + 1] = t[1]; v[q * 4 + 2] = t[2]; v[q * 4 + 3] = t[3];
-  }
-  float* orow = (float*)a.o + ((long long)b * a.N + n) * a.C + g * 32;
-  unsigned char* srow = (unsigned char*)a.o + (((long long)b * a.N + n) * a.C) * 4;
-#pragma unroll 2
-  for (int i4 = 0; i4 < 32; i4 += 4) {
-    float s4[4];
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      float s = 0.f;
-#pragma unroll
-      for (int j = 0; j < 32; ++j) s = fmaf(sa[i4 + e][j], v[j], s);
-      s4[e] = s;
-    }
-    if (a.osplit) {
-      uint2 hi, lo;
-      omni_split4(s4, hi, lo);
-      unsigned char* p = srow + omni_split_off(g * 32 + i4);
-      *reinterpret_cast<uint2*>(p) = hi;
-      *reinterpret_cast<uint2*>(p + 32) = lo;
-    } else {
-      *reinterpret_cast<f32x4*>(orow + i4) = f32x4{s4[0], s4[1], s4[2], s4[3]};
-    }
-  }
-}
-
-
-// Candidate successor of chan_apply_v4_kernel (op->i[7] = 1; written after the last GPU session of round 3: verified on the host
-// emulation only, NOT yet timed on the MI355X — tools/r4_open.sh holds the A/B).  The kernel above spends 1 024 v_fma_f32 and 256
-// broadcast ds_read_b128 per wave for 64 tokens: ~4 100 VALU cycles and as many LDS cycles per 16 KB of HBM traffic — it is bound by
-// its vector ALU and the LDS pipe (2.0-2.5 TB/s measured), not by HBM.  The f32 MFMA variant measured in round 3 (32x32x2: 16 x 64
-// cycles per 32-token tile, dword column loads) was slower still.  Here the product runs on the f16 matrix pipe with the split-f16 x3
-// arithmetic of the attention kernels (hi * hi into one accumulator, hi * lo' + lo' * hi into a second, lo' = 2048 lo):
+// apply on the f16 matrix pipe (adopted in round 4: 2.55 vs 3.13 ms per launch at 4.7 M tokens x 128 channels, 3.5-3.8 TB/s instead
+// of 2.9-3.1; profiles/r4_s2_per_op_{default,candidates}.txt — its predecessor, one token per lane with the 32x32 matrix broadcast from
+// LDS, spent 1 024 v_fma_f32 + 256 ds_read_b128 per wave for 64 tokens and was bound by its vector ALU and the LDS pipe; an f32-MFMA
+// variant (32x32x2, dword column loads) measured in round 3 was slower still).  Split-f16 x3 arithmetic of the attention kernels
+// (hi * hi into one accumulator, hi * lo' + lo' * hi into a second, lo' = 2048 lo):
 //   out^T[i][n] = sum_j A[i][j] v[n][j]:  the (image, group)'s 32x32 matrix is the ROW operand — split ONCE per wave into four
 //   fragment registers sets; the token tile is the column operand — lane (n, kg) loads 2 x 32 contiguous bytes of token n's row
 //   (16-byte loads, every byte used once) and splits its 16 values in registers; 6 MFMAs (32x32x16) per 32 tokens; the accumulator
 //   quad q of a lane is 4 consecutive channels 8 q + 4 kg of ONE token: 16-byte f32 stores / 8-byte hi and lo stores.
-// ~130 VALU instructions and 192 MFMA cycles per 32 tokens instead of 2 048 + 2 048 cycles: the kernel becomes a streaming one.
+// ~130 VALU instructions and 192 MFMA cycles per 32 tokens: a streaming kernel.
 __global__ __launch_bounds__(256, 2) void chan_apply_mfma_split_kernel(ChanArgs a) {
   const int g = blockIdx.y, b = blockIdx.z;
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6;
@@ -2313,24 +2092,20 @@ static int launch_attn_rows(const omni_op_t* op, hipStream_t s) {
     OMNI_REQUIRE(a.groups % (a.wy * a.wx) == 0, "attn_rows: groups must be B * windows");
   } else { a.wy = a.wx = 0; }
   int rc;
+  const bool aligned4 = a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 &&
+                        a.qoff % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0 && a.ooff % 4 == 0;
   OMNI_REQUIRE(!a.osplit || (a.mode == 1 && D == 32) || (a.mode == 0 && D == 64), "attn_rows: split output exists on the MFMA kernels only");
   if (a.mode == 1 && D == 32) {       // 12x12 window attention on the matrix cores (split-f16)
     dim3 grid(1, a.heads, a.groups);
-    // op->i[17] = 1: the candidate kernel (vectorised rows: needs 4-element aligned row pitches and channel offsets)
-    const bool v2 = op->i[17] == 1 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 &&
-                    a.qoff % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0 && a.ooff % 4 == 0;
+    OMNI_REQUIRE(op->dtype != OMNI_F32 || aligned4, "attn_rows: the f32 window kernel reads 16-byte rows (pitches and channel offsets %% 4 == 0)");
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { if (v2) hipLaunchKernelGGL(window_attn_mfma_f32_v2_kernel, grid, dim3(192), 0, s, a);
-            else hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a); },
+      [&] { hipLaunchKernelGGL(window_attn_mfma_f32_kernel, grid, dim3(192), 0, s, a); },
       [&] { hipLaunchKernelGGL((window_attn_mfma_kernel<half_t>), grid, dim3(192), 0, s, a); });
   } else if (a.mode == 0 && D == 64) {   // BART encoder MHA on the matrix cores (flash-style, split-f16)
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
-    // op->i[17] = 1: the candidate kernel (16-byte rows: 4-element aligned pitches and offsets)
-    const bool v2 = op->i[17] == 1 && a.ldq % 4 == 0 && a.ldk % 4 == 0 && a.ldv % 4 == 0 && a.ldo % 4 == 0 &&
-                    a.qoff % 4 == 0 && a.koff % 4 == 0 && a.voff % 4 == 0 && a.ooff % 4 == 0;
+    OMNI_REQUIRE(op->dtype != OMNI_F32 || aligned4, "attn_rows: the f32 MHA kernel reads 16-byte rows (pitches and channel offsets %% 4 == 0)");
     rc = by_dtype(op->dtype, "attn_rows",
-      [&] { if (v2) hipLaunchKernelGGL(mha_mfma_f32_v2_kernel, grid, dim3(256), 0, s, a);
-            else hipLaunchKernelGGL((mha_mfma_kernel<float>), grid, dim3(256), 0, s, a); },
+      [&] { hipLaunchKernelGGL(mha_mfma_f32_kernel, grid, dim3(256), 0, s, a); },
       [&] { hipLaunchKernelGGL((mha_mfma_kernel<half_t>), grid, dim3(256), 0, s, a); });
   } else {
     dim3 grid((a.nq + 127) / 128, a.heads, a.groups);
@@ -2359,8 +2134,7 @@ static int launch_chan_attn(const omni_op_t* op, hipStream_t s) {
   if (op->dtype == OMNI_F32 && a.chunk_tokens % 8 == 0 && a.C % 4 == 0) {
     hipLaunchKernelGGL(chan_scores_mfma_kernel, g1, dim3(256), 0, s, a);
     hipLaunchKernelGGL(chan_softmax_kernel, dim3(a.G, a.B), dim3(256), 0, s, a);
-    if (op->i[7] == 1) hipLaunchKernelGGL(chan_apply_mfma_split_kernel, g2, dim3(256), 0, s, a);   // candidate (see the kernel)
-    else hipLaunchKernelGGL(chan_apply_v4_kernel, g2, dim3(256), 0, s, a);
+    hipLaunchKernelGGL(chan_apply_mfma_split_kernel, g2, dim3(256), 0, s, a);
     OMNI_HIP_CHECK(hipGetLastError());
     return OMNI_OK;
   }

@@ -39,8 +39,7 @@ struct ConvArgs {
   int M, K, ktiles, cin_tiles;
   int splits, kt_per_split, mtiles, ntiles, xcd_order, xcd_n;
   float* ws;
-  unsigned* cnt;          // split-K tickets per output tile (zero between launches) — only read by the FR = true kernels below.  (This slot
-                          // held the host-only workspace size until the FR variant: the kernel arguments of every other kernel are unchanged.)
+  void* reserved;         // (kernel-argument layout kept: the slot held a host-only workspace size, then a round-4 candidate's pointer)
   float scale;
 };
 
@@ -353,14 +352,11 @@ __device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& 
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
-// FR (candidate, off by default — op p[6] / PlanBuilder.fuse_splitk): split-K WITHOUT the second launch.  Every split writes its
-// partial tile to the workspace as before, then takes a ticket of its output tile (device-scope atomic behind a release fence); the
-// split that draws the last ticket adds up ALL partials of the tile from the workspace in the fixed order z = 0 .. splits - 1 and
-// applies bias / scale / activation / residual — instruction for instruction the arithmetic of splitk_reduce_kernel, so the result
-// is bit-identical to the two-launch path whichever split finishes last.  It also leaves the ticket counter at zero for the next
-// launch (hipGraph replays included).  What it saves is a launch per split-K conv: ~230 of the batch-1 detector's ~500 kernels
-// (4.5 ms for 189 GFLOP: launch-bound) and 36 of a decode step's ~110.
-template <int BM, int BN, int NW, bool PW, bool FR = false>
+// Measured and not kept (round 4, profiles/r4_s2_candidates_ab.txt): split-K without the second launch — the split that draws the last
+// ticket of an output tile adds up all partials inside the conv kernel.  Bit-identical, ~230 fewer launches per batch-1 detector
+// pass, and 4.5x SLOWER end to end (20.4 vs 4.5 ms per screenshot; caption bench 775 vs 692 ms per step): the fences and the
+// single block's serial walk over all splits cost far more than a 3 us reduce launch.
+template <int BM, int BN, int NW, bool PW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
   // NW waves as 2 (M) x NW/2 (N)
   constexpr int RB = 128, ROWB = RB + 16, VPR = 8, RPP = NW * 8;
@@ -523,35 +519,6 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
         }
       }
     }
-    if constexpr (FR) {
-      __shared__ int s_last;
-      __threadfence();                                   // release: this split's partials are visible device-wide before its ticket
-      __syncthreads();
-      if (tid == 0) {
-        unsigned* c = a.cnt + (mt * a.ntiles + nt);
-        const bool last = atomicAdd(c, 1u) + 1u == (unsigned)a.splits;
-        if (last) *c = 0u;                               // every split of the tile has drawn: zero again for the next launch
-        s_last = last ? 1 : 0;
-      }
-      __syncthreads();
-      if (!s_last) return;
-      __threadfence();                                   // acquire: the other splits' partials (written by other CUs, through L2)
-      const long long total = (long long)a.M * a.Cout;
-      const float* __restrict__ R = reinterpret_cast<const float*>(a.res);
-      float* __restrict__ Y = reinterpret_cast<float*>(a.y);
-      for (int e = tid; e < BM * BN; e += NW * 64) {
-        const int m = m0 + e / BN, n = n0 + e % BN;
-        if (m >= a.M || n >= a.Cout) continue;
-        const long long idx = (long long)m * a.Cout + n;
-        float v = 0.0f;
-        for (int z = 0; z < a.splits; ++z) v += a.ws[(long long)z * total + idx];
-        v += a.bias ? a.bias[n] : 0.0f;
-        if (a.scale != 0.0f) v *= a.scale;
-        v = act_apply(v, a.act);
-        if (R) v += R[(long long)m * a.ldr + a.res_coff + n];
-        Y[(long long)m * a.ldo + a.out_coff + n] = v;
-      }
-    }
     return;
   }
   auto run = [&](auto tag) {
@@ -583,12 +550,6 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   // 128x128: 8 waves (64x32 per wave, 4 waves/SIMD; measured 191-229 TF/s vs 172-209 for 4 waves of 64x64); smaller
   // tiles: 4 waves.  Round-1 variants that lost (two-slice register prefetch, weights straight to registers, 256x128,
   // 64-wide K slices, weight-only LDS-DMA) are recorded in DESIGN.md and profiles/r2_gemm_diag.md, not kept here.
-  constexpr int NWV = (BM == 128 && BN == 128) ? 8 : 4;
-  if (a.splits > 1 && a.cnt) {      // candidate: the split that finishes last reduces (see conv_split_kernel, FR)
-    if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, NWV, true, true>), grid, dim3(NWV * 64), 0, s, a);
-    else hipLaunchKernelGGL((conv_split_kernel<BM, BN, NWV, false, true>), grid, dim3(NWV * 64), 0, s, a);
-    return;
-  }
   if constexpr (BM == 128 && BN == 128) {
     if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, true>), grid, dim3(512), 0, s, a);
     else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 8, false>), grid, dim3(512), 0, s, a);
@@ -722,8 +683,6 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   a.scale = op->f[0];
   a.ws = (float*)op->p[5];
   const long long ws_bytes = a.ws ? (long long)op->i[19] * 1024 : 0;   // i19 = workspace size in KiB
-  a.cnt = (unsigned*)op->p[6];                           // candidate: split-K tickets (i22 counters, zero) -> no reduce launch (split-f16 path)
-  OMNI_REQUIRE(!a.cnt || op->i[22] >= 512, "conv: the split-K ticket buffer holds %d counters, needs >= 512", op->i[22]);
   a.splits = 1; a.kt_per_split = 0;
   const int V = op->dtype == OMNI_F32 ? 4 : 8;
   OMNI_REQUIRE(op->dtype == OMNI_F32 || op->dtype == OMNI_F16, "conv: bad dtype %d", op->dtype);

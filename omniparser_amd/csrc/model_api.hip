@@ -60,6 +60,23 @@ float bits_f32(long long v) {
   return f;
 }
 
+// every named tensor / integer an entry point uses must exist (and be large enough) BEFORE the first launch: a stale, truncated or
+// mismatched bundle is OMNI_E_ARG at create time, never an out-of-bounds device write or a null-pointer HIP call later
+struct NeedT { const char* name; long long min_bytes; };
+int require_named(const omni_model* m, const char* who, const NeedT* need, size_t n_need, const char* const* ints, size_t n_ints) {
+  for (size_t k = 0; k < n_ints; ++k)
+    if (!m->ints.count(ints[k])) { omni_set_error("%s: the bundle has no integer '%s'", who, ints[k]); return OMNI_E_ARG; }
+  for (size_t k = 0; k < n_need; ++k) {
+    long long nb = 0;
+    if (!named_ptr(m, need[k].name, &nb)) { omni_set_error("%s: the bundle has no tensor '%s'", who, need[k].name); return OMNI_E_ARG; }
+    if (nb < need[k].min_bytes) {
+      omni_set_error("%s: tensor '%s' holds %lld bytes, the bundle's own sizes need %lld", who, need[k].name, nb, need[k].min_bytes);
+      return OMNI_E_ARG;
+    }
+  }
+  return OMNI_OK;
+}
+
 int run_plan(omni_model* m, const char* name) {
   auto it = m->plans.find(name);
   if (it == m->plans.end()) { omni_set_error("model has no plan '%s'", name); return OMNI_E_ARG; }
@@ -84,6 +101,11 @@ extern "C" int omni_model_load(const char* path, omni_model_t** out) {
   char magic[8];
   if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "OMNIPLN1", 8) != 0) { fclose(f); omni_set_error("omni_model_load: %s is not a plan bundle", path); return OMNI_E_ARG; }
   const uint32_t nt = r.get<uint32_t>(), np = r.get<uint32_t>(), nn = r.get<uint32_t>(), ni = r.get<uint32_t>();
+  if (!r.ok || nt > (1u << 20) || np > 1024u || nn > 4096u || ni > 4096u) {
+    fclose(f);
+    omni_set_error("omni_model_load: %s has an implausible header (%u tensors, %u plans, %u names, %u ints)", path, nt, np, nn, ni);
+    return OMNI_E_ARG;
+  }
   omni_model* m = new omni_model();
   struct TRec { uint64_t nbytes; uint32_t role, pad; uint64_t off; };
   std::vector<TRec> recs(nt);
@@ -112,6 +134,14 @@ extern "C" int omni_model_load(const char* path, omni_model_t** out) {
   int rc = OMNI_OK;
   auto fail = [&](int code) { fclose(f); omni_model_destroy(m); return code; };
   if (!r.ok) { omni_set_error("omni_model_load: %s is truncated", path); return fail(OMNI_E_ARG); }
+  for (const auto& kv : m->named) {                         // a named tensor is a byte range INSIDE one tensor of the bundle
+    const omni_model::Named& nd = kv.second;
+    if (nd.tensor < 0 || (uint32_t)nd.tensor >= nt || nd.off < 0 || nd.nbytes < 0 || (uint64_t)nd.off + (uint64_t)nd.nbytes > recs[nd.tensor].nbytes) {
+      omni_set_error("omni_model_load: named tensor '%s' (tensor %d, offset %lld, %lld bytes) is out of range", kv.first.c_str(), nd.tensor,
+                     nd.off, nd.nbytes);
+      return fail(OMNI_E_ARG);
+    }
+  }
   if (hipStreamCreateWithFlags(&m->stream, hipStreamNonBlocking) != hipSuccess) { omni_set_error("omni_model_load: hipStreamCreate failed"); return fail(OMNI_E_HIP); }
   // tensors: allocate, zero, upload constants (staged through a 16 MiB host buffer)
   m->tensors.assign(nt, nullptr);
@@ -149,7 +179,7 @@ extern "C" int omni_model_load(const char* path, omni_model_t** out) {
       ops[j].kind = o.kind; ops[j].dtype = o.dtype;
       for (int q = 0; q < 8; ++q) {
         if (o.p[q].t < 0) continue;
-        if ((uint32_t)o.p[q].t >= nt || o.p[q].off < 0 || (uint64_t)o.p[q].off > recs[o.p[q].t].nbytes) {
+        if ((uint32_t)o.p[q].t >= nt || o.p[q].off < 0 || (uint64_t)o.p[q].off >= std::max<uint64_t>(recs[o.p[q].t].nbytes, 1)) {
           omni_set_error("omni_model_load: plan '%s' op %zu pointer %d is out of range", pl.first.c_str(), j, q);
           return fail2(OMNI_E_ARG);
         }
@@ -210,11 +240,25 @@ extern "C" int omni_model_run(omni_model_t* m, const char* plan_name) {
 extern "C" int omni_detector_create(const char* bundle_path, omni_model_t** out) {
   int rc = omni_model_load(bundle_path, out);
   if (rc) return rc;
-  if (model_int(*out, "model") != 1 || !named_ptr(*out, "img") || !named_ptr(*out, "out_boxes")) {
+  if (model_int(*out, "model") != 1 || !(*out)->plans.count("detect")) {
     omni_model_destroy(*out); *out = nullptr;
     omni_set_error("omni_detector_create: %s is not a detector bundle", bundle_path);
     return OMNI_E_ARG;
   }
+  static const char* const ints[] = {"batch", "img_w", "img_h", "max_det"};
+  rc = require_named(*out, "omni_detector_create", nullptr, 0, ints, 4);
+  if (rc == OMNI_OK) {
+    const long long batch = model_int(*out, "batch"), W = model_int(*out, "img_w"), H = model_int(*out, "img_h"), md = model_int(*out, "max_det");
+    if (batch <= 0 || W <= 0 || H <= 0 || md <= 0 || batch > 4096 || W > 65536 || H > 65536 || md > 65536) {
+      omni_set_error("omni_detector_create: implausible sizes (batch %lld, %lld x %lld, max_det %lld)", batch, W, H, md);
+      rc = OMNI_E_ARG;
+    } else {
+      const NeedT need[] = {{"img", batch * H * W * 3}, {"out_count", batch * 4}, {"out_boxes", batch * md * 16}, {"out_scores", batch * md * 4},
+                            {"out_cls", batch * md * 4}};
+      rc = require_named(*out, "omni_detector_create", need, 5, nullptr, 0);
+    }
+  }
+  if (rc) { omni_model_destroy(*out); *out = nullptr; return rc; }
   return OMNI_OK;
 }
 
@@ -239,11 +283,30 @@ extern "C" int omni_detector_infer(omni_model_t* det, const uint8_t* images_rgb,
 extern "C" int omni_captioner_create(const char* bundle_path, omni_model_t** out) {
   int rc = omni_model_load(bundle_path, out);
   if (rc) return rc;
-  if (model_int(*out, "model") != 2 || !named_ptr(*out, "x_in") || !named_ptr(*out, "ids") || !(*out)->plans.count("encode") || !(*out)->plans.count("step")) {
+  if (model_int(*out, "model") != 2 || !(*out)->plans.count("encode") || !(*out)->plans.count("step")) {
     omni_model_destroy(*out); *out = nullptr;
     omni_set_error("omni_captioner_create: %s is not a captioner bundle", bundle_path);
     return OMNI_E_ARG;
   }
+  static const char* const ints[] = {"capacity", "R", "T", "max_new", "start_token", "dtype", "ksize", "ldo",
+                                     "mean0", "mean1", "mean2", "std0", "std1", "std2"};
+  rc = require_named(*out, "omni_captioner_create", nullptr, 0, ints, sizeof(ints) / sizeof(ints[0]));
+  if (rc == OMNI_OK) {
+    const long long B = model_int(*out, "capacity"), R = model_int(*out, "R"), T = model_int(*out, "T"), ks = model_int(*out, "ksize"),
+                    ldo = model_int(*out, "ldo"), dt = model_int(*out, "dtype"), esz = dt == OMNI_F32 ? 4 : 2;
+    if (B <= 0 || R <= 0 || T <= 0 || ks < 0 || (ks == 0) != (R == 64) || ldo < 3 || B > 65536 || R > 8192 || T > 4096 || ks > 64 || (dt != OMNI_F32 && dt != OMNI_F16) ||
+        model_int(*out, "max_new") < 0 || model_int(*out, "max_new") >= T) {
+      omni_set_error("omni_captioner_create: implausible sizes (capacity %lld, R %lld, T %lld, ksize %lld, ldo %lld, dtype %lld)", B, R, T, ks, ldo, dt);
+      rc = OMNI_E_ARG;
+    } else {
+      // R == 64: the crop op's bicubic pass is skipped (ksize 0) and its tables / row buffer are absent
+      const NeedT need[] = {{"ids", B * T * 4}, {"finished", B * 4}, {"step", 4}, {"boxes", B * 16}, {"c64", B * 64 * 64 * 3},
+                            {"x_in", B * R * R * ldo * esz}, {"lut", 256 * 4},
+                            {"tmp", B * 64 * R * 3}, {"bic_bounds", R * 2 * 4}, {"bic_coef", R * ks * 4}};
+      rc = require_named(*out, "omni_captioner_create", need, ks ? 10 : 7, nullptr, 0);
+    }
+  }
+  if (rc) { omni_model_destroy(*out); *out = nullptr; return rc; }
   return OMNI_OK;
 }
 
@@ -265,10 +328,14 @@ extern "C" int omni_captioner_caption(omni_model_t* cap, const uint8_t* image_rg
   for (int s = 0; s < n && rc == OMNI_OK; s += B) {
     const int m = n - s < B ? n - s : B;
     // state reset (florence.py::_CaptionPlans.reset), crop rectangles, crop pre-processing, encode, max_new decode steps
-    hipMemcpyAsync(named_ptr(cap, "ids"), ids0.data(), ids0.size() * 4, hipMemcpyHostToDevice, cap->stream);
-    hipMemsetAsync(named_ptr(cap, "finished"), 0, (size_t)B * 4, cap->stream);
-    hipMemsetAsync(named_ptr(cap, "step"), 0, 4, cap->stream);
-    hipMemcpyAsync(named_ptr(cap, "boxes"), h_boxes_px + (size_t)s * 4, (size_t)m * 16, hipMemcpyHostToDevice, cap->stream);
+    if (hipMemcpyAsync(named_ptr(cap, "ids"), ids0.data(), ids0.size() * 4, hipMemcpyHostToDevice, cap->stream) != hipSuccess ||
+        hipMemsetAsync(named_ptr(cap, "finished"), 0, (size_t)B * 4, cap->stream) != hipSuccess ||
+        hipMemsetAsync(named_ptr(cap, "step"), 0, 4, cap->stream) != hipSuccess ||
+        hipMemcpyAsync(named_ptr(cap, "boxes"), h_boxes_px + (size_t)s * 4, (size_t)m * 16, hipMemcpyHostToDevice, cap->stream) != hipSuccess) {
+      omni_set_error("omni_captioner_caption: state reset failed: %s", hipGetErrorString(hipGetLastError()));
+      rc = OMNI_E_HIP;
+      break;
+    }
     omni_op_t op;
     memset(&op, 0, sizeof(op));
     op.kind = OMNI_OP_CROP_RESIZE;

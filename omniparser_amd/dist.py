@@ -22,7 +22,8 @@ def init_from_env(backend: str = None):
     rank = int(os.environ.get("RANK", "0"))
     local_rank = int(os.environ.get("LOCAL_RANK", "0"))
     if world > 1 and not dist.is_initialized():
-        backend = backend or ("nccl" if torch.cuda.is_available() else "gloo")
+        # OMNI_DIST_BACKEND: the CPU tests run the N > 1 path of bench.py on gloo (tests/test_bench_world2_cpu.py)
+        backend = backend or os.environ.get("OMNI_DIST_BACKEND") or ("nccl" if torch.cuda.is_available() else "gloo")
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         os.environ.setdefault("MASTER_PORT", "29511")
         kw = {}

@@ -401,16 +401,14 @@ class _CaptionPlans(_StepPlans):
                             L.OP_ATTN_ROWS, dt,
                             p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr, qb.data_ptr() + 4 * C, qb.data_ptr() + 8 * C],
                             i={0: 3 * C, 1: 3 * C, 2: 3 * C, 3: C, 4: 0, 5: C, 6: 2 * C, 7: 0, 8: w.heads[s], 9: 144, 10: 144,
-                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if (attn_split and grp["dma"]) else 0,
-                               17: 1 if (cap.window_attn_v2 and dt == L.F32) else 0},
+                               11: B * nw, 12: 1, 13: H, 14: H, 15: C // w.heads[s], 16: 1 if (attn_split and grp["dma"]) else 0},
                             f={0: (C // w.heads[s]) ** -0.5}))
                         att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "window_attn.proj", att, B_, res=B_)
                     else:
                         linear(pre + "channel_attn.qkv", hbuf, qkv)
                         pb.add_op(L.make_op(L.OP_CHAN_ATTN, dt, p=[qkv.ptr, None, None, None, att.ptr, cws.data_ptr()],
-                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if (attn_split and grp["dma"]) else 0,
-                                               7: 1 if (cap.chan_apply_mfma and dt == L.F32) else 0}))
+                                            i={0: B, 1: N, 3: C, 4: w.groups[s], 5: chunk_tokens, 6: 1 if (attn_split and grp["dma"]) else 0}))
                         att.fmt = "split" if (attn_split and grp["dma"]) else "f32"
                         linear(pre + "channel_attn.proj", att, B_, res=B_)
                     dwconv_ln(pre + "conv2", pre + "norm2", B_, A_, hbuf)
@@ -487,8 +485,7 @@ class _CaptionPlans(_StepPlans):
             linear(None, xin, qkv, keys=[pre + "self_attn.q_proj", pre + "self_attn.k_proj", pre + "self_attn.v_proj"])
             pb.add_op(L.make_op(L.OP_ATTN_ROWS, dt, p=[qkv.ptr, qkv.ptr, qkv.ptr, None, att.ptr],
                                 i={0: 3 * D, 1: 3 * D, 2: 3 * D, 3: D, 4: 0, 5: D, 6: 2 * D, 7: 0, 8: nh, 9: S, 10: S, 11: B,
-                                   12: 0, 15: 64, 16: 1 if (attn_split and dma_enc) else 0,
-                                   17: 1 if (cap.mha_v2 and dt == L.F32) else 0}, f={0: 64 ** -0.5}))
+                                   12: 0, 15: 64, 16: 1 if (attn_split and dma_enc) else 0}, f={0: 64 ** -0.5}))
             att.fmt = "split" if (attn_split and dma_enc) else "f32"
             linear(pre + "self_attn.out_proj", att, tmp, res=xa)
             layernorm(pre + "self_attn_layer_norm", tmp, xa, split=xs)
@@ -531,28 +528,11 @@ class Florence2Captioner:
     # plan composition switches (class attributes: the tests build the round-2 composition by overriding them)
     fuse_dwln = True          # x + dwconv(x) -> LayerNorm as one strip kernel (DaViT stages 0-2)
     attn_split_out = True     # attention kernels write format B for the projection GEMM themselves
-    window_attn_v2 = False    # CANDIDATE, not timed on the MI355X yet (written after round 3's last GPU minute): the f32 window-attention
-                              # kernel with 32-bit window-relative addressing, O^T accumulators (vector stores, no shuffles) and mixed-precision
-                              # fma splits — 1 490 instead of 2 841 VALU instructions per wave (csrc/caption_ops.hip::window_attn_mfma_f32_v2_kernel);
-                              # emulated checks green incl. cut windows; A/B: tools/r4_open.sh
-    chan_apply_mfma = False   # CANDIDATE, not timed on the MI355X yet: the channel-attention apply on the f16 matrix pipe (split-f16 x3, the
-                              # 32x32 matrix as the MFMA row operand, 16-byte token loads / stores, no LDS) — ~330 instead of ~1 700 VALU
-                              # instructions per 64 tokens (csrc/caption_ops.hip::chan_apply_mfma_split_kernel); A/B: tools/r4_open.sh
-    mha_v2 = False            # CANDIDATE, not timed on the MI355X yet: the encoder's attention with 64-key double-buffered LDS stages (loads
-                              # of the next keys in flight under the arithmetic, one barrier per 64 keys), 32x32x16 MFMAs, a lazily moved softmax
-                              # reference (csrc/caption_ops.hip::mha_mfma_f32_v2_kernel); A/B: tools/r4_open.sh
-    lane_cu_masks = None      # EXPERIMENT (bench.py --lane-masks; premises measured, profiles/r3_cu_mask_probe.md; the bench itself not yet): CU sets ("0-127", "128-255"
-                              # [, decode]) for the encode lanes' HIP streams (hipExtStreamCreateWithCUMask) — disjoint sets let the HBM-bound
-                              # kernels of one micro-batch really run beside the power-bound GEMMs of the other instead of queueing behind them
-    split_cu_masks = None     # EXPERIMENT (bench.py --split-masks "0-175;176-255"; not run on the MI355X): (GEMM CU set, other CU set).  Encode
-                              # plans replay eagerly over two streams per lane (Plan.run_split): their MFMA-bound ops on a stream masked to
-                              # the first set, everything else on the lane's own stream, masked to the second — the power-bound GEMMs of one
-                              # micro-batch (95 % of their rate on 192 CUs) beside the HBM-bound kernels of another, by construction
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
-    reuse_activations = False  # CANDIDATE (same kernels, same order, different addresses; not run on the MI355X yet): scratch tensors of a
-                              # DaViT stage are released at its end and back the tensors of the later stages (PlanBuilder.release) —
-                              # a 128-crop plan at 768x768 holds ~0.2 GB per crop instead of ~0.4; with it `stage_out[:3]` are no
-                              # longer valid after the encode plan (the bisection taps of tools/r3_bisect.py need it off)
+    reuse_activations = True  # scratch tensors of a DaViT stage are released at its end and back the tensors of the later stages
+                              # (PlanBuilder.release): same kernels, same order, different addresses — a rank's plan sets hold 89 GB
+                              # instead of 176 GB of HBM at the same speed (profiles/r4_s2_candidates_ab.txt).  With it `stage_out[:3]` are
+                              # no longer valid after the encode plan: the bisection taps (tools/r3_bisect.py) turn it off
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
         device = L.require_device(device, "Florence2Captioner")
@@ -584,7 +564,7 @@ class Florence2Captioner:
     def bucket(n: int) -> int:
         """plan capacity for a micro-batch of n crops (rows beyond n are computed and ignored): powers of two plus 96 — the bench
         step's 349 crops are 128 + 128 + 93, and a 96-row plan for that tail computes 8 % fewer rows per step than a third 128-row
-        one.  Every capacity is one more resident plan (60 GB of activations at 128 rows, 768x768 crops; at most OMNI_MAX_CAPTION_PLANS
+        one.  Every capacity is one more resident plan (60 GB of activations at 128 rows, 768x768 crops; at most OMNI_CAPTION_PLAN_GB
         stay resident), which is why the ladder is not finer; OMNI_CAPTION_BUCKETS overrides it."""
         for b in _BUCKETS:
             if n <= b:
@@ -596,41 +576,74 @@ class Florence2Captioner:
         """row capacity of the merged decode plan for n crops: multiples of 128 (the unused tail rows are computed and ignored)."""
         return max(128, (n + 127) // 128 * 128)
 
+    # ---- resident plan sets: ONE cache for encode and decode plans, bounded by BYTES (and, secondarily, by count), LRU, never
+    # evicting what the batch being issued has already taken.  A 128-row plan set at 768x768 crops holds ~60 GB of activations, a
+    # 384-row decode plan ~8 GB: a bound counted in plans either thrashes on a stream with varying crop counts (every eviction is a
+    # device-wide synchronise + a ~60 GB rebuild + a graph capture) or lets the resident set grow past the HBM.
+    def begin_batch(self):
+        """Called by the pipeline before it takes the plans of one caption batch: everything taken from here on is pinned until the
+        next call (at most 2 lane plans + 1 remainder plan + 1 decode plan)."""
+        self._epoch = getattr(self, "_epoch", 0) + 1
+
+    def plan_cache_bytes(self) -> int:
+        return sum(m[0] for k, m in self.__dict__.get("_plan_meta", {}).items() if k in self._plans)
+
+    def clear_plans(self):
+        """drop every resident plan set (the caller has synchronised the captioner's streams)"""
+        self._plans.clear()
+        self.__dict__.get("_plan_meta", {}).clear()
+
+    def _cached_plan(self, key, build):
+        meta = self.__dict__.setdefault("_plan_meta", {})
+        epoch = getattr(self, "_epoch", 0)
+        if key in self._plans:
+            self._plans[key] = self._plans.pop(key)            # most recently used last
+            meta[key][1] = epoch
+            return self._plans[key]
+        max_bytes = int(float(os.environ.get("OMNI_CAPTION_PLAN_GB", "200")) * 2 ** 30)
+        max_plans = int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "16"))
+        base = key[:4] if key[0] == "dec" else key[:3]         # the key without its slot: twins have the same size
+        sizes = self.__dict__.setdefault("_plan_sizes", {})    # bytes of every plan set ever built (survives eviction): the estimate
+        est = sizes.get(base, 0)                               # for the one about to be built (0 = unknown: the count bound applies)
+        def over():
+            return len(self._plans) >= max_plans or (self._plans and self.plan_cache_bytes() + est > max_bytes)
+        while over():
+            victim = next((k for k in self._plans if meta[k][1] != epoch), None)
+            if victim is None:
+                break                                          # everything resident belongs to the batch being issued
+            torch.cuda.synchronize(self.device)                # work of any of the captioner's streams may still use the evicted plan's buffers
+            self._plans.pop(victim)
+            meta.pop(victim)
+            self.plan_evictions = getattr(self, "plan_evictions", 0) + 1
+        on_gpu = self.device.type == "cuda" and torch.cuda.is_available()
+        before = torch.cuda.memory_allocated(self.device) if on_gpu else 0
+        import contextlib
+        with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
+            obj = build()
+        self._plans[key] = obj
+        meta[key] = [max(0, (torch.cuda.memory_allocated(self.device) if on_gpu else 0) - before), epoch]
+        sizes[base] = meta[key][0]
+        return obj
+
     @torch.inference_mode()
     def decode_plans(self, B, R, max_new, slot=0) -> _DecodePlans:
         """slot: the pipelined stream (pipeline.py::parse_stream) decodes batch i on its own HIP stream while batch i+1 encodes, so it
         alternates between two decode plans (8 GB of cross-attention K/V each at 384 rows, 768x768 crops)."""
         key = ("dec", B, R, max_new) if slot == 0 else ("dec", B, R, max_new, slot)
-        if key not in self._plans:
-            with torch.cuda.device(self.device):
-                self._plans[key] = _DecodePlans(self, B, R, max_new)
-        else:
-            self._plans[key] = self._plans.pop(key)
-        return self._plans[key]
+        return self._cached_plan(key, lambda: _DecodePlans(self, B, R, max_new))
 
     @torch.inference_mode()
     def plans(self, B, R, max_new, slot=0) -> _CaptionPlans:
         """slot 1 = a second, independent set of buffers of the same capacity: the pipelined stream (pipeline.py::parse_stream) keeps two
         128-crop micro-batches in flight on two HIP streams (60 GB of activations each at 768x768)."""
         key = (B, R, max_new) if slot == 0 else (B, R, max_new, slot)
-        if key in self._plans:
-            self._plans[key] = self._plans.pop(key)
-            return self._plans[key]
-        while len(self._plans) >= int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "6")):   # LRU bound on activation pools
-            torch.cuda.synchronize(self.device)             # work of any of the captioner's streams may still use the evicted plan's buffers
-            self._plans.pop(next(iter(self._plans)))
-        with torch.cuda.device(self.device):
-            self._plans[key] = _CaptionPlans(self, B, R, max_new)
-        return self._plans[key]
+        return self._cached_plan(key, lambda: _CaptionPlans(self, B, R, max_new))
 
     # ---- merged decode (several micro-batches): encode only, cross-KV into rows [row0, row0 + n) of the decode plan
     def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int, stream=None):
         """encode on `stream` (default: the captioner's first stream; the caller made it current)."""
         stream = stream or self.stream
-        if self.split_cu_masks:
-            cp.encode_plan.run_split(self.gemm_stream(stream), stream)
-        else:
-            (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream)
+        (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream)
         for src, dst in zip(cp.cross_kv, dec.cross_kv):
             dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)
 
@@ -643,23 +656,10 @@ class Florence2Captioner:
         return dec.ids[:n].clone()                 # stream-ordered snapshot (read back by the caller)
 
     def _lane_stream(self, k):
-        m = self.lane_cu_masks
-        if self.split_cu_masks and k < 2:                  # encode lanes of the split replay: the "other" CU set
-            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[1])))
-        if self.split_cu_masks and k == 2 and len(self.split_cu_masks) > 2:       # optional third set: the decode stream
-            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[2])))
-        if m and k < len(m) and m[k]:
-            return L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(m[k])))
+        # Measured and not kept (round 4, profiles/r4_s2_candidates_ab.txt): CU-masked lane streams (hipExtStreamCreateWithCUMask) and a
+        # two-stream replay with the GEMMs on one CU set and the HBM-bound kernels on the other — 754-1079 ms per bench step against
+        # 692 on plain streams, for every partition tried.
         return torch.cuda.Stream(device=self.device)
-
-    def gemm_stream(self, lane_stream):
-        """split replay: the GEMM-side stream that belongs to an encode lane's stream (one per lane, masked to the GEMM CU set)."""
-        if not hasattr(self, "_gemm_streams"):
-            self._gemm_streams = {}
-        key = lane_stream.cuda_stream
-        if key not in self._gemm_streams:
-            self._gemm_streams[key] = L.masked_stream(self.device, L.cu_mask_words(L.parse_cu_spec(self.split_cu_masks[0])))
-        return self._gemm_streams[key]
 
     @property
     def stream2(self):
@@ -670,15 +670,14 @@ class Florence2Captioner:
         return self._stream2
 
     def encode_lane(self, k):
-        """stream of encode lane k: 0 / 1 = `stream` / `stream2` (the default pipeline's two lanes); further lanes (experiments: with
-        the split replay the GEMM stream stays busy only while some lane has a GEMM ready — more micro-batches in flight) on demand."""
+        """stream of encode lane k: 0 / 1 = `stream` / `stream2` (the default pipeline's two lanes); further lanes on demand."""
         if k == 0:
             return self.stream
         if k == 1:
             return self.stream2
         extra = self.__dict__.setdefault("_extra_lanes", {})
         if k not in extra:
-            extra[k] = self._lane_stream(0) if self.split_cu_masks else torch.cuda.Stream(device=self.device)
+            extra[k] = self._lane_stream(k)
         return extra[k]
 
     @property

@@ -302,6 +302,7 @@ class ScreenParser:
         # overlap (parse_stream): micro-batches alternate between two encode lanes (HIP streams); 128-row plans exist once per lane, the
         # smaller capacities once — a plan's `free_evt` orders its next use, on whichever lane, behind its last one
         lanes = [cap.encode_lane(k) for k in range(max(1, self.encode_lanes))] if overlap else [cap.stream]
+        cap.begin_batch()              # the plan sets this batch takes from the captioner's cache stay resident until the next batch
         if overlap and merged:
             self._dec_slot = 1 - getattr(self, "_dec_slot", 1)
         dec = cap.decode_plans(cap.decode_bucket(len(flat)), R, max_new_tokens, slot=self._dec_slot if overlap else 0) if merged else None
@@ -464,12 +465,8 @@ class ScreenParser:
                 caps = self.caption_finish(handle)
                 elems_all = self.assemble(snap, snap, ocr_els, counts, iw, ih, n_frames)
             ids_out = self._fill_captions(elems_all, caps)
-            # (experiments with CU-masked lanes: those are BLOCKING streams — hipExtStreamCreateWithCUMask takes no flags — so a read on
-            # the null stream would wait for every lane's queued work; the snapshot was written on the detector's stream: read it there)
-            masked = getattr(self.cap, "lane_cu_masks", None) or getattr(self.cap, "split_cu_masks", None)
-            with (torch.cuda.stream(self.det.stream) if masked else contextlib.nullcontext()):
-                self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
-                self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
+            self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
 
         try:

@@ -59,8 +59,19 @@ _TENSORS = {}
 
 
 def _register(t: torch.Tensor, role: str) -> torch.Tensor:
-    if t.numel():
-        _TENSORS[t.data_ptr()] = (weakref.ref(t), role, t.numel() * t.element_size())
+    if not t.numel():
+        return t
+    nbytes = t.numel() * t.element_size()
+    ent = _TENSORS.get(t.data_ptr())
+    if ent is not None:
+        old = ent[0]()
+        # a LIVE entry at this base address that already covers the range stays (e.g. `t` is the first slice of a registered table:
+        # overwriting the table's entry with the slice's shorter range would orphan every pointer into the rest of it)
+        if old is not None and old.data_ptr() == t.data_ptr() and ent[2] >= nbytes and old is not t:
+            return t
+    if len(_TENSORS) > 4096 and len(_TENSORS) % 1024 == 0:
+        live_tensors()                                     # purge entries of dead tensors now and then (the registry is process-global)
+    _TENSORS[t.data_ptr()] = (weakref.ref(t), role, nbytes)
     return t
 
 
@@ -77,10 +88,6 @@ def live_tensors():
 
 
 class PlanBuilder:
-    # CANDIDATE (not run on the MI355X yet): split-K convs of the split-f16 path reduce inside the conv kernel — the split that
-    # finishes last for an output tile adds up the partials (csrc/conv_igemm.hip::conv_split_kernel, FR) — instead of launching
-    # splitk_reduce_kernel: bit-identical results, ~230 fewer launches per batch-1 detector pass, 36 fewer per decode step
-    fuse_splitk = False
     workspace_on_host = False    # plans on CPU tensors get no split-K workspace (the plan interpreter needs none); the host emulation
                                  # of the kernels (tests/emu) sets it so that split-K launches are what the MI355X runs
 
@@ -95,7 +102,6 @@ class PlanBuilder:
         self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
-        self.cnt = None          # split-K ticket counters (fuse_splitk), shared by all convs of the plan like the workspace
         self.reuse = False       # lifetime reuse of released scratch tensors (see `release`)
         self._free, self._released, self._pins = [], set(), []
         self.reused_bytes = 0    # bytes handed out from released tensors instead of fresh allocations
@@ -251,18 +257,14 @@ class PlanBuilder:
             assert b.numel() == cout
         if self.ws is None and (self.device.type == "cuda" or self.workspace_on_host):
             self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
-        if self.fuse_splitk and self.ws is not None and self.cnt is None:
-            self.cnt = self.raw((1024,), torch.int32, zero=True)
         op = L.make_op(
             L.OP_CONV, self.dtype,
             p=[x.ptr, w_packed.data_ptr(), b.data_ptr() if b is not None else None,
-               res.ptr if res is not None else None, out.ptr, self.ws.data_ptr() if self.ws is not None else None,
-               self.cnt.data_ptr() if self.cnt is not None else None],
+               res.ptr if res is not None else None, out.ptr, self.ws.data_ptr() if self.ws is not None else None],
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
-               19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0,
-               22: self.cnt.numel() if self.cnt is not None else 0},
+               19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0},
             f={0: scale, 1: getattr(w_packed, "omni_oscale", 0.0) if wfmt == 2 else 0.0})
         self.ops.append(op)
         self.keep.append(w_packed)

@@ -19,8 +19,14 @@ FLAGS = ["-x", "c++", "-std=c++20", "-O2", "-mavx2", "-mf16c", "-pthread", "-fPI
 def build(verbose=False) -> Path:
     srcs = sorted(CSRC.glob("*.hip"))
     deps = srcs + sorted(CSRC.glob("*.h")) + [HERE / "fakehip" / "hip" / "hip_runtime.h", ROOT / "include" / "omni_amd.h", Path(__file__)]
-    newest = max(d.stat().st_mtime for d in deps)
-    if OUT.exists() and OUT.stat().st_mtime >= newest:
+    # staleness by CONTENT (sha256 stamp next to the library), like omniparser_amd/build.py: an mtime comparison calls a library fresh
+    # that a concurrent build finished AFTER an edit but compiled from the sources BEFORE it
+    import hashlib
+    h = hashlib.sha256(" ".join(FLAGS).encode())
+    for d in sorted(map(str, deps)):
+        h.update(os.path.basename(d).encode() + b"\0" + Path(d).read_bytes())
+    digest, stamp = h.hexdigest(), OUT.with_name(OUT.name + ".sha256")
+    if OUT.exists() and stamp.exists() and stamp.read_text().strip() == digest:
         return OUT
     OBJ.mkdir(exist_ok=True)
     procs = []
@@ -34,6 +40,7 @@ def build(verbose=False) -> Path:
         if verbose:
             print("compiled", s.name)
     subprocess.run([CLANG, "-shared", "-pthread", "-o", str(OUT), *[str(OBJ / (s.stem + ".o")) for s in srcs]], check=True)
+    stamp.write_text(digest + "\n")
     return OUT
 
 

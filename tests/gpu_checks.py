@@ -98,63 +98,6 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
 
 
 
-FUSED_SPLITK_CASES = [
-    # split-f16 path (Cin % 32 == 0, K >= 128) with few output tiles: the launcher splits along K
-    (1, 20, 20, 1024, 1024, 1, 1, 1024, 0, 1024, 0, False, L.ACT_GELU),   # 7 x 16 tiles of 64x64, 7 splits
-    (1, 20, 20, 512, 200, 3, 1, 512, 0, 256, 32, True, L.ACT_SILU),       # 3x3, ragged N tile, residual, channel-slice output
-    (2, 1, 1, 768, 768, 1, 1, 768, 0, 768, 0, True, L.ACT_NONE),          # a decode-step projection: M = 2
-    (3, 9, 9, 256, 96, 1, 1, 256, 0, 96, 0, False, L.ACT_NONE),
-]
-
-
-def check_conv_fused_splitk(seed=0, cases=None, replays=3):
-    """PlanBuilder.fuse_splitk (candidate): the split that finishes last for an output tile reduces the partials inside the conv
-    kernel.  Against the two-launch path (conv + splitk_reduce_kernel) on the same operands: outputs equal BIT FOR BIT (same
-    summation order whichever split is last), over several launches of the same op (the ticket counters return to zero), and the
-    fused kernel is really the one that ran (with poisoned tickets nobody reduces: the output keeps its fill value)."""
-    g = torch.Generator().manual_seed(seed)
-    out = {}
-    for case in (cases or FUSED_SPLITK_CASES):
-        B, H, W, Cin, Cout, k, s, ild, ioff, old, ooff, use_res, act = case
-        p = k // 2
-        x = torch.randn(B, Cin, H, W, generator=g)
-        w = torch.randn(Cout, Cin, k, k, generator=g) / math.sqrt(Cin * k * k)
-        b = torch.randn(Cout, generator=g)
-        Ho, Wo = (H + 2 * p - k) // s + 1, (W + 2 * p - k) // s + 1
-        res = torch.randn(B, Cout, Ho, Wo, generator=g) if use_res else None
-        xv = _nhwc(x, torch.float32, ild, ioff)
-        rv = _nhwc(res, torch.float32, Cout + 4, 4) if use_res else None
-        outs = []
-        for fuse in (False, True):
-            pb = PlanBuilder(DEV, L.F32)
-            pb.fuse_splitk = fuse
-            assert pb.split, "the fused reduction lives on the split-f16 path (OMNI_CONV_SPLIT=1)"
-            ov = View(torch.full((B, Ho, Wo, old), 7.0, dtype=torch.float32, device=DEV), ooff, Cout)
-            wp = pb.pack_weight(w)
-            assert getattr(wp, "omni_fmt", 0) == 1, case
-            pb.conv(xv, wp, b, ov, k, s, act=act, res=rv)
-            op = pb.ops[0]
-            assert bool(op.p[6]) == fuse and (op.i[22] >= 512) == fuse
-            for _ in range(replays if fuse else 1):
-                ov.t.fill_(7.0)
-                L.launch(op)
-                _sync()
-                outs.append(ov.t.clone().cpu())
-            if fuse:
-                assert int(pb.cnt.abs().sum()) == 0, f"split-K tickets not back at zero: {case}"
-                pb.cnt.fill_(1 << 20)                    # poisoned tickets: no split ever draws the last one
-                ov.t.fill_(7.0)
-                L.launch(op)
-                _sync()
-                assert (ov.t == 7.0).all(), f"{case}: the output was written although no split could be last - the launcher did not split or did not take the fused kernel"
-                pb.cnt.zero_()
-        ref = outs[0]
-        assert (ref[..., ooff:ooff + Cout] != 7.0).any()
-        for o in outs[1:]:
-            assert torch.equal(o.view(torch.int32), ref.view(torch.int32)), f"fused split-K differs from the two-launch path: {case}"
-        out[str(case)] = "bit-identical x%d" % replays
-    return out
-
 
 # ------------------------------------------------------------------------------------------ pre-split LDS-DMA GEMM
 GEMM_DMA_CASES = [
@@ -882,7 +825,7 @@ def _cmp(a, b, tol, what):
     return e
 
 
-def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(0,), mha_variants=(0,)):
+def check_caption_ops(dtype=L.F32, seed=0):
     g = torch.Generator().manual_seed(seed)
     tdt = torch.float32 if dtype == L.F32 else torch.float16
     tol = 2e-5 if dtype == L.F32 else 5e-3
@@ -928,51 +871,45 @@ def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(
                                                 i={0: rows, 1: 1, 3: Cc, 5: period}, f={0: 1e-5}))
         res[f"layernorm{Cc}"] = _cmp(gq["y"], c["y"], tol * 5, f"layernorm C={Cc}")
     # plain attention (encoder shape, odd S) and window attention with padding (H=W=16 -> 2x2 windows)
-    # mha_variants: 0 = the shipped MFMA kernel, 1 = its candidate successor (op i[17], f32 plans).  S = 77: two key blocks of the
-    # candidate, the second one partial with a fully masked half; 5: one partial block; 200: partial query tile, four key blocks
-    for variant in (mha_variants if dtype == L.F32 else (0,)):
-        tag = "" if variant == 0 else f"_v{variant + 1}"
-        for (Bq, S, heads) in ((2, 77, 12),) + (((1, 5, 2), (1, 200, 3)) if variant else ()):
-            D = 64
-            Cm = heads * D
-            t = {"qkv": R(Bq * S, 3 * Cm).to(tdt), "o": torch.zeros(Bq * S, Cm, dtype=tdt)}
-            mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype, p=[P("qkv"), P("qkv"), P("qkv"), None, P("o")],
-                                             i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
-                                                11: Bq, 12: 0, 15: D, 16: osplit, 17: variant}, f={0: D ** -0.5})
-            c, gq = _op_pair(t, lambda P: mk(P, 0))
-            res[f"attn_plain{tag}" + ("" if S == 77 else f"_{S}")] = _cmp(gq["o"], c["o"], tol * 5, f"attn_rows plain S={S} variant {variant}")
-            if variant:
-                cs, gs = _op_pair(t, lambda P: mk(P, 1))
-                _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"attn_rows plain split out S={S} variant {variant}")
-                assert (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
-                # scores far apart (rows whose maximum moves by much more than the lazy-rescale threshold between key blocks)
-                t2 = {"qkv": t["qkv"].clone(), "o": torch.zeros_like(t["o"])}
-                t2["qkv"][:, :Cm] *= 6.0
-                c2, g2 = _op_pair(t2, lambda P: mk(P, 0))
-                res[f"attn_plain{tag}_{S}_sharp"] = _cmp(g2["o"], c2["o"], tol * 5, f"attn_rows plain sharp S={S} variant {variant}")
-    # window_variants: 0 = the shipped f32 window kernel, 1 = its candidate successor (op i[17]; f32 plans only).  12 = no padding
-    # (every real stage at 768x768), 16 / 24 / 2 = cut windows, 13 = one row / column of a second window
-    for variant in (window_variants if dtype == L.F32 else (0,)):
-        tag = "" if variant == 0 else f"_v{variant + 1}"
-        for (Hh, heads, D) in ((16, 4, 32), (24, 4, 32), (2, 8, 32)) + (((12, 2, 32), (13, 1, 32)) if variant else ()):
-            Cm = heads * D
-            Bq = 2
-            nw = ((Hh + 11) // 12) ** 2
-            t = {"qkv": R(Bq * Hh * Hh, 3 * Cm).to(tdt), "bias": R(3 * Cm), "o": torch.zeros(Bq * Hh * Hh, Cm, dtype=tdt)}
-            mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype,
-                                             p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
-                                             i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
-                                                11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D, 16: osplit, 17: variant}, f={0: D ** -0.5})
-            c, gq = _op_pair(t, lambda P: mk(P, 0))
-            res[f"attn_window{tag}_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh} variant {variant}")
-            if dtype == L.F32 and Cm % 16 == 0:
-                # the f32 window-attention kernel's format-B output
-                cs, gs = _op_pair(t, lambda P: mk(P, 1))
-                assert torch.equal(gs["o"].view(torch.uint8), cs["o"].view(torch.uint8)) or \
-                    _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"window attention split out H={Hh} variant {variant}") is not None
-                if variant:
-                    # the candidate's two output formats hold the same numbers: format B is the split of the f32 rows, bit for bit
-                    assert torch.equal(split_decode(gs["o"]), gq["o"]) or (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
+    # f32 plans (mha_mfma_f32_kernel, 64-key blocks): S = 77: two key blocks, the second one partial with a fully masked half; 5: one
+    # partial block; 200: partial query tile, four key blocks.  f16 plans: the generic MFMA kernel at S = 77
+    f32 = dtype == L.F32
+    for (Bq, S, heads) in ((2, 77, 12),) + (((1, 5, 2), (1, 200, 3)) if f32 else ()):
+        D = 64
+        Cm = heads * D
+        t = {"qkv": R(Bq * S, 3 * Cm).to(tdt), "o": torch.zeros(Bq * S, Cm, dtype=tdt)}
+        mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype, p=[P("qkv"), P("qkv"), P("qkv"), None, P("o")],
+                                         i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: S, 10: S,
+                                            11: Bq, 12: 0, 15: D, 16: osplit}, f={0: D ** -0.5})
+        c, gq = _op_pair(t, lambda P: mk(P, 0))
+        res["attn_plain" + ("" if S == 77 else f"_{S}")] = _cmp(gq["o"], c["o"], tol * 5, f"attn_rows plain S={S}")
+        if f32:
+            cs, gs = _op_pair(t, lambda P: mk(P, 1))
+            _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"attn_rows plain split out S={S}")
+            assert (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
+            # scores far apart (rows whose maximum moves by much more than the lazy-rescale threshold between key blocks)
+            t2 = {"qkv": t["qkv"].clone(), "o": torch.zeros_like(t["o"])}
+            t2["qkv"][:, :Cm] *= 6.0
+            c2, g2 = _op_pair(t2, lambda P: mk(P, 0))
+            res[f"attn_plain_{S}_sharp"] = _cmp(g2["o"], c2["o"], tol * 5, f"attn_rows plain sharp S={S}")
+    # window attention: 12 = no padding (every real stage at 768x768), 16 / 24 / 2 = cut windows, 13 = one row / column of a second window
+    for (Hh, heads, D) in ((16, 4, 32), (24, 4, 32), (2, 8, 32)) + (((12, 2, 32), (13, 1, 32)) if f32 else ()):
+        Cm = heads * D
+        Bq = 2
+        nw = ((Hh + 11) // 12) ** 2
+        t = {"qkv": R(Bq * Hh * Hh, 3 * Cm).to(tdt), "bias": R(3 * Cm), "o": torch.zeros(Bq * Hh * Hh, Cm, dtype=tdt)}
+        mk = lambda P, osplit: L.make_op(L.OP_ATTN_ROWS, dtype,
+                                         p=[P("qkv"), P("qkv"), P("qkv"), None, P("o"), P("bias", 4 * Cm), P("bias", 8 * Cm)],
+                                         i={0: 3 * Cm, 1: 3 * Cm, 2: 3 * Cm, 3: Cm, 4: 0, 5: Cm, 6: 2 * Cm, 7: 0, 8: heads, 9: 144, 10: 144,
+                                            11: Bq * nw, 12: 1, 13: Hh, 14: Hh, 15: D, 16: osplit}, f={0: D ** -0.5})
+        c, gq = _op_pair(t, lambda P: mk(P, 0))
+        res[f"attn_window_{Hh}"] = _cmp(gq["o"], c["o"], tol * 5, f"window attention H={Hh}")
+        if f32 and Cm % 16 == 0:
+            # the f32 window-attention kernel's format-B output: the split of the f32 rows
+            cs, gs = _op_pair(t, lambda P: mk(P, 1))
+            assert torch.equal(gs["o"].view(torch.uint8), cs["o"].view(torch.uint8)) or \
+                _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 5, f"window attention split out H={Hh}") is not None
+            assert torch.equal(split_decode(gs["o"]), gq["o"]) or (split_decode(gs["o"]) - gq["o"]).abs().max() <= 1e-6 * gq["o"].abs().max()
     # channel attention
     Bq, N, G = 2, 2500, 4
     Cm = G * 32
@@ -984,21 +921,17 @@ def check_caption_ops(dtype=L.F32, seed=0, window_variants=(0,), chan_variants=(
     if dtype == L.F32:
         # f32 plans: MFMA scores + one softmax per (image, group) + MFMA apply, and the format-B output; a token count that is a
         # multiple of the 32-token MFMA trip (the real shapes) and a tiny one (R = 64)
-        # chan_variants: 0 = the shipped VALU apply kernel, 1 = the candidate split-f16 MFMA apply (op i[7]); N = 2500 / 300 / 16 end in
-        # partial 32-token tiles, partial waves and partial blocks
-        for variant in chan_variants:
-            tag = "" if variant == 0 else f"_v{variant + 1}"
-            for (Bq2, N2) in ((2, 2500), (1, 4096), (3, 16)) + (((2, 300),) if variant else ()):
-                ch2 = (N2 + 1023) // 1024
-                t2 = {"qkv": R(Bq2 * N2, 3 * Cm).to(tdt), "o": torch.zeros(Bq2 * N2, Cm, dtype=tdt), "ws": torch.zeros(Bq2 * G * ch2 * 1024)}
-                mk = lambda P, osplit: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
-                                                 i={0: Bq2, 1: N2, 3: Cm, 4: G, 5: 1024, 6: osplit, 7: variant})
-                c2, g_new = _op_pair(t2, lambda P: mk(P, 0))
-                res[f"chan_attn{tag}_{N2}"] = _cmp(g_new["o"], c2["o"], tol * 10, f"channel attention N={N2} variant {variant}")
-                cs, gs = _op_pair(t2, lambda P: mk(P, 1))
-                _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 10, f"channel attention split out N={N2} variant {variant}")
-                if variant:
-                    assert (split_decode(gs["o"]) - g_new["o"]).abs().max() <= 1e-6 * g_new["o"].abs().max()    # both formats: the same numbers
+        # N = 2500 / 300 / 16 end in partial 32-token tiles, partial waves and partial blocks of the MFMA apply kernel
+        for (Bq2, N2) in ((2, 2500), (1, 4096), (3, 16), (2, 300)):
+            ch2 = (N2 + 1023) // 1024
+            t2 = {"qkv": R(Bq2 * N2, 3 * Cm).to(tdt), "o": torch.zeros(Bq2 * N2, Cm, dtype=tdt), "ws": torch.zeros(Bq2 * G * ch2 * 1024)}
+            mk = lambda P, osplit: L.make_op(L.OP_CHAN_ATTN, dtype, p=[P("qkv"), None, None, None, P("o"), P("ws")],
+                                             i={0: Bq2, 1: N2, 3: Cm, 4: G, 5: 1024, 6: osplit})
+            c2, g_new = _op_pair(t2, lambda P: mk(P, 0))
+            res[f"chan_attn_{N2}"] = _cmp(g_new["o"], c2["o"], tol * 10, f"channel attention N={N2}")
+            cs, gs = _op_pair(t2, lambda P: mk(P, 1))
+            _cmp(split_decode(gs["o"]), split_decode(cs["o"]), tol * 10, f"channel attention split out N={N2}")
+            assert (split_decode(gs["o"]) - g_new["o"]).abs().max() <= 1e-6 * g_new["o"].abs().max()    # both formats: the same numbers
     # proj_prep / assemble
     Bq, N, Cm = 2, 36, 256
     t = {"x": R(Bq, N, Cm).to(tdt), "pos": R(N, Cm), "tmp": R(Cm), "y": torch.zeros(Bq, N + 1, Cm, dtype=tdt)}
@@ -1206,13 +1139,12 @@ def _run_rows(cap, cp, rows, max_new, graph=True):
     snap = {}
     with torch.inference_mode(), torch.cuda.stream(cap.stream):
         cp.reset()
-        if getattr(cap, "split_cu_masks", None):       # experiment: encode over two CU-masked streams (tools/r4_candidates.py)
-            cp.encode_plan.run_split(cap.gemm_stream(cap.stream), cap.stream)
-        else:
-            run(cp.encode_plan)
+        run(cp.encode_plan)
         snap["x_in"] = cp.x_in.t[idx][..., :3].float().cpu()
         for s, v in enumerate(cp.stage_out):
-            snap[f"stage{s}"] = v.t[idx].float().cpu()
+            # Florence2Captioner.reuse_activations (default): the buffers of stages 0-2 back later tensors — only the last stage's tap is valid
+            if not cap.reuse_activations or s == len(cp.stage_out) - 1:
+                snap[f"stage{s}"] = v.t[idx].float().cpu()
         snap["img_feat"] = cp.img_feat.t[idx][:, :, 0, :].float().cpu()
         snap["enc_out"] = cp.enc_out.t[idx][:, :, 0, :].float().cpu()
         for t in range(max_new):
@@ -1224,7 +1156,7 @@ def _run_rows(cap, cp, rows, max_new, graph=True):
     return snap
 
 
-def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, standin=None):
+def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, standin=None, all_taps=False):
     """The SAME real crops through a `small`-row plan (n / small passes) and through ONE `large`-row plan (the checked crops at both
     ends of the batch, every other row filled with other real crops): every intermediate tensor of a crop must not depend on the
     plan capacity or on its row.  GPU vs GPU, no CPU oracle: seconds, and it bisects by construction (first divergent tensor)."""
@@ -1232,6 +1164,8 @@ def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, sta
     from omniparser_amd.synth import synthetic_screenshot
     from tools.make_weights import CAPTION_STANDIN, ensure_caption_checkpoint
     cap = Florence2Captioner(ensure_caption_checkpoint(0, standin or CAPTION_STANDIN), "cuda", precision="f32", resolution=R)
+    if all_taps:
+        cap.reuse_activations = False                  # every stage keeps its own buffers: stage0..2 taps exist (bisection)
     frame = torch.from_numpy(synthetic_screenshot(seed, 1920, 1080)).to(DEV)
     boxes = real_crop_boxes(seed, large)
     half = n // 2
@@ -1251,6 +1185,8 @@ def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, sta
     out = {"R": R, "n": n, "capacities": [small, large], "rows_large": rows_large}
     first = None
     for k in ("x_in", "stage0", "stage1", "stage2", "stage3", "img_feat", "enc_out", "logits1"):
+        if k not in sm:
+            continue                                   # taps of released stage buffers (reuse_activations)
         a, b = sm[k], big[k]
         d = (a - b).abs().max().item()
         out[k] = {"max_abs": d, "rel": d / max(b.abs().max().item(), 1e-30), "bitwise": bool(torch.equal(a, b))}
@@ -1278,7 +1214,7 @@ def check_captioner_real_crops(R=768, n=4, seed=0, max_new=20, capacity=None, st
     img = synthetic_screenshot(seed, 1920, 1080)
     boxes = real_crop_boxes(seed, n)
     key = (R, n, seed, max_new, standin or CAPTION_STANDIN)
-    if key not in _REAL_CROPS_ORACLE:                  # the CPU side is the same for every device-side variant (tools/r4_candidates.py)
+    if key not in _REAL_CROPS_ORACLE:                  # the CPU side is the same for every device-side variant
         model = build_random_captioner(0, chan_qk_scale=standin_scale(standin))
         pv = np.stack([PR.caption_pixel_values(img, b, R, CLIP_MEAN, CLIP_STD) for b in boxes])
         pix = torch.from_numpy(pv).permute(0, 3, 1, 2).contiguous()

@@ -27,7 +27,7 @@ def test_florence_plan_matches_transformers_r64(ckpt):
 
 
 def test_activation_reuse_plan_matches_transformers_and_halves_the_scratch_bytes(ckpt, monkeypatch, tmp_path):
-    """Florence2Captioner.reuse_activations (candidate, off by default): the scratch tensors of a DaViT stage are released at its end
+    """Florence2Captioner.reuse_activations (default since round 4): the scratch tensors of a DaViT stage are released at its end
     and back the tensors allocated later (PlanBuilder.release / free list).  The interpreter runs the op list on those aliased
     buffers: a live-range mistake shows as wrong features / ids against transformers.  Bytes: < 0.5 x the default plan's scratch."""
     import caption_checks as CC
@@ -44,9 +44,11 @@ def test_activation_reuse_plan_matches_transformers_and_halves_the_scratch_bytes
     g = torch.Generator().manual_seed(5)
     pix = torch.randn(2, 3, 64, 64, generator=g)
     feats, enc, ids = CC.hf_reference(model, pix, 20)
-    cap0, cp0 = CC.build_cpu_plans(d, 2, 64)
-    monkeypatch.setattr(FL.Florence2Captioner, "reuse_activations", True)
-    cap, cp = CC.build_cpu_plans(d, 2, 64)
+    assert FL.Florence2Captioner.reuse_activations is True
+    monkeypatch.setattr(FL.Florence2Captioner, "reuse_activations", False)
+    cap0, cp0 = CC.build_cpu_plans(d, 2, 64)                 # every stage owns its buffers
+    monkeypatch.undo()
+    cap, cp = CC.build_cpu_plans(d, 2, 64)                   # the default
     assert cp.pb.reuse and cp.pb.reused_bytes > 0 and not cp0.pb.reuse
     assert [(o.kind, tuple(o.i)) for o in cp.encode_plan.ops] == [(o.kind, tuple(o.i)) for o in cp0.encode_plan.ops]   # same ops, other addresses
     assert scratch_bytes(cp) < 0.5 * scratch_bytes(cp0), (scratch_bytes(cp), scratch_bytes(cp0))
@@ -59,7 +61,7 @@ def test_activation_reuse_plan_matches_transformers_and_halves_the_scratch_bytes
     assert (f2 - feats).abs().max() < 2e-3 * feats.abs().max()
     assert (e2 - enc).abs().max() < 2e-3 * enc.abs().max()
     assert torch.equal(i2[:, : ids.shape[1]], ids), (i2, ids)
-    f0, e0, i0 = CC.run_interp(cap0, cp0, pix, 20)          # same ops on the same data: bit for bit what the default plan computes
+    f0, e0, i0 = CC.run_interp(cap0, cp0, pix, 20)          # same ops on the same data: bit for bit what the plan without reuse computes
     assert torch.equal(f2, f0) and torch.equal(e2, e0) and torch.equal(i2, i0)
     # plan export (model-level C entry points): pointers into carved tensors resolve against the registered blocks they were carved from
     from omniparser_amd import bundle as BN

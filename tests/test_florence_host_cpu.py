@@ -119,3 +119,53 @@ def test_batch_decode_through_tokenizer_json(tmp_path):
     raw = proc.batch_decode(torch.tensor(rows[:1]), skip_special_tokens=False)[0]
     assert "<s>" in raw and "</s>" in raw and "<pad>" in raw
     assert FlorenceProcessor(None).batch_decode(torch.tensor(rows[1:2]))[0].startswith("tok")      # no tokenizer file: ids as text
+
+
+def test_plan_cache_is_bounded_by_bytes_and_never_evicts_the_pending_batch(monkeypatch):
+    """Florence2Captioner._cached_plan: one LRU for encode and decode plan sets, bounded by bytes; the plan sets the batch
+    being issued has taken are pinned; decode plans follow the same policy; a twin's size is the estimate for the next slot."""
+    import types
+    import torch
+    from omniparser_amd.florence import Florence2Captioner as F
+    cap = F.__new__(F)
+    cap.device = torch.device("cpu")
+    cap._plans = {}
+    synced = []
+    monkeypatch.setattr(torch.cuda, "synchronize", lambda *a, **k: synced.append(1))
+    monkeypatch.setenv("OMNI_CAPTION_PLAN_GB", "100")
+    GB = 2 ** 30
+    built = []
+
+    def take(key, gb):
+        def build():
+            built.append(key)
+            return types.SimpleNamespace(key=key)
+        obj = cap._cached_plan(key, build)
+        cap._plan_meta[key][0] = gb * GB                      # what memory_allocated would have measured on the device
+        cap._plan_sizes[key[:4] if key[0] == "dec" else key[:3]] = gb * GB
+        return obj
+
+    cap.begin_batch()
+    a = take((128, 768, 20), 40)
+    b = take((128, 768, 20, 1), 40)                           # twin: 80 GB resident
+    d = take(("dec", 384, 768, 20), 8)
+    assert cap.plan_cache_bytes() == 88 * GB and not synced
+    # same batch: a third 128-row lane does not fit (88 + 40 > 100), but everything resident is pinned -> built anyway, nothing evicted
+    c = take((128, 768, 20, 2), 40)
+    assert len(cap._plans) == 4 and not synced
+    # next batch: touching a and d pins them; the cache is over its bound (128 GB resident), so taking a new 96-row plan (size unknown,
+    # estimate 0) evicts the least recently used UNPINNED set (b) and stops as soon as the resident sets fit again
+    cap.begin_batch()
+    assert take((128, 768, 20), 40) is a and take(("dec", 384, 768, 20), 8) is d and len(built) == 4
+    e = take((96, 768, 20), 30)
+    assert list(cap._plans) == [(128, 768, 20, 2), (128, 768, 20), ("dec", 384, 768, 20), (96, 768, 20)] and len(synced) == 1
+    # ... its twin (estimate 30 GB, 118 resident) evicts c; a, d, e belong to this batch and stay although the bound is exceeded
+    take((96, 768, 20, 1), 30)
+    assert list(cap._plans) == [(128, 768, 20), ("dec", 384, 768, 20), (96, 768, 20), (96, 768, 20, 1)]
+    assert len(synced) == 2 and cap.plan_evictions == 2 and cap.plan_cache_bytes() == (40 + 8 + 30 + 30) * GB
+    # decode plans are evicted like any other set once they are the oldest unpinned entries
+    cap.begin_batch()
+    take((64, 768, 20), 90)                                   # over the bound already: a goes (108 -> 68 GB fits with the estimate 0)
+    assert list(cap._plans)[0] == ("dec", 384, 768, 20)
+    take((64, 768, 20, 1), 90)                                # estimate 90 -> evicts d, e, e' (all unpinned), keeps the pinned 64-row set
+    assert list(cap._plans) == [(64, 768, 20), (64, 768, 20, 1)]

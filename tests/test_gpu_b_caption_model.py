@@ -71,7 +71,10 @@ def test_plan_capacity_invariance_r768():
     print(out)
     assert out["x_in"]["bitwise"], out
     assert out["ids_equal"], out
-    for k in ("stage0", "stage1", "stage2", "stage3", "img_feat", "enc_out"):
+    # default composition (Florence2Captioner.reuse_activations): the buffers of stages 0-2 are re-used by later tensors, their taps do not
+    # exist; `check_plan_capacity(..., all_taps=True)` builds the plans without reuse to bisect a failure stage by stage
+    assert "stage3" in out and "stage0" not in out, list(out)
+    for k in ("stage3", "img_feat", "enc_out"):
         assert out[k]["rel"] <= 1e-5, (k, out)
     assert out["logits1"]["max_abs"] <= 1e-4, out
 

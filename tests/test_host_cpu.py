@@ -381,50 +381,6 @@ def test_device_lock_makes_the_models_gpu_current_in_every_thread(monkeypatch):
         assert not plain._lock.acquire(blocking=False)   # non-reentrant flavour really excludes
 
 
-def test_encode_lanes_take_cu_masked_streams_when_asked(emu, monkeypatch):
-    """Florence2Captioner.lane_cu_masks (experiment, None by default): the encode lanes' streams come from L.masked_stream with the
-    CU sets given as "a-b[:step]" lists; a lane without a set (here the decode stream) keeps an ordinary stream.  The HIP call itself
-    (omni_stream_create -> hipExtStreamCreateWithCUMask) is exported and refuses bad arguments without a GPU."""
-    import ctypes
-    import torch
-    from conftest import small_vocab_caption_checkpoint
-    from omniparser_amd.florence import Florence2Captioner
-    assert L.parse_cu_spec("0-7:2,32-33") == [0, 2, 4, 6, 32, 33]
-    assert L.cu_mask_words([0, 31, 32, 255]) == [0x80000001, 1, 0, 0, 0, 0, 0, 0x80000000]
-    with pytest.raises(ValueError):
-        L.parse_cu_spec("0-256")
-    h = ctypes.c_void_p()
-    assert L.lib().omni_stream_create(None, 2, ctypes.byref(h)) != 0 and b"omni_stream_create" in L.lib().omni_last_error()
-    made = []
-    monkeypatch.setattr(L, "masked_stream", lambda device, words: (made.append(list(words)), torch.cuda.Stream())[1])
-    assert Florence2Captioner.lane_cu_masks is None
-    monkeypatch.setattr(Florence2Captioner, "lane_cu_masks", ("0-127", "0-255:2"))
-    cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
-    _ = cap.stream2, cap.dec_stream
-    assert made == [[0xFFFFFFFF] * 4 + [0] * 4, [0x55555555] * 8]
-
-
-def test_split_replay_schedule_keeps_program_order():
-    """omni_plan_run_split's schedule (dry run, no GPU): MFMA-bound ops (conv / linear / fused FFN) on the GEMM stream, the rest on
-    the other stream, an event hand-over exactly where consecutive ops change stream — the induction that keeps program order —
-    starting on the 'other' stream (where the inputs are ready)."""
-    import torch
-    from omniparser_amd.planner import PlanBuilder, View
-    pb = PlanBuilder("cpu", L.F32)
-    x = View(torch.zeros(1, 8, 8, 32), 0, 32)
-    y, z = pb.alloc(1, 8, 8, 32), pb.alloc(1, 8, 8, 32)
-    g = pb.upload(torch.ones(32))
-    w = pb.pack_weight(torch.zeros(32, 32, 1, 1))
-    ln = lambda a, b: pb.add_op(L.make_op(L.OP_LAYERNORM, L.F32, p=[a.ptr, None, g.data_ptr(), g.data_ptr(), b.ptr, None],
-                                          i={0: 64, 1: 1, 3: 32}, f={0: 1e-5}))
-    ln(x, y); pb.conv(y, w, None, z, 1); pb.conv(z, w, None, y, 1); ln(y, z); ln(z, y); pb.conv(y, w, None, z, 1)
-    plan = pb.build()
-    assert plan.split_schedule() == [(0, False), (1, True), (1, False), (0, True), (0, False), (1, True)]
-    lib = L.lib()
-    assert lib.omni_plan_run_split(plan._h, None, None, None) != 0                      # a dry run needs the output array
-    assert lib.omni_plan_run_split(plan._h, ctypes.c_void_p(8), ctypes.c_void_p(8), None) != 0 and b"two different" in lib.omni_last_error()
-
-
 def test_plan_export_survives_a_dead_tensors_registry_entry_at_the_same_address(tmp_path):
     """The tensor registry is keyed by base address with weak references.  A caller-owned bias whose address was once a (now dead)
     registered tensor's must be registered afresh — found as an order-dependent failure of the bundle round-trip test: the stale entry
@@ -476,10 +432,11 @@ def test_bench_argument_parser_formats_its_help_and_defaults(monkeypatch, capsys
     monkeypatch.setattr("sys.argv", ["bench.py", "--help"])
     with pytest.raises(SystemExit) as e:
         bench.parse_args()
-    assert e.value.code == 0 and "--lane-masks" in capsys.readouterr().out
+    assert e.value.code == 0 and "--lanes" in capsys.readouterr().out
     monkeypatch.setattr("sys.argv", ["bench.py"])
     a = bench.parse_args()
-    assert (a.gpus, a.mode, a.batch, a.lanes, a.pipeline, a.lane_masks, a.split_masks, a.candidates) == (1, "e2e", 8, 2, True, "", "", "")
+    assert (a.gpus, a.mode, a.batch, a.lanes, a.pipeline) == (1, "e2e", 8, 2, True)
+    assert not any(hasattr(a, k) for k in ("lane_masks", "split_masks", "candidates"))      # round-4: the losing experiments and their switches are gone
 
 
 def test_build_staleness_is_decided_by_content_not_mtime(tmp_path):

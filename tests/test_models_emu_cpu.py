@@ -20,31 +20,6 @@ def test_detector_through_reference_api_matches_oracle_box_for_box(emu):
     assert out["ops"] > 250
 
 
-def test_detector_with_fused_splitk_equals_the_default_plan_bit_for_bit(emu, monkeypatch):
-    """PlanBuilder.fuse_splitk (candidate): every split-K conv of the detector reduces inside the conv kernel (the split that finishes
-    last), no splitk_reduce launch — boxes and scores of a frame equal the default plan's bit for bit, and the plan really holds
-    split-K convs with ticket counters."""
-    from PIL import Image
-    from omniparser_amd.planner import PlanBuilder
-    from omniparser_amd.synth import synthetic_screenshot
-    from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import EXACT_FRAMES, ensure_blob
-    blob = ensure_blob(seed=0, nc=1, width=0.25)
-    pil = Image.fromarray(synthetic_screenshot(EXACT_FRAMES[(0.25, 320)][0], 640, 480))
-    res = []
-    for fuse in (False, True):
-        monkeypatch.setattr(PlanBuilder, "fuse_splitk", fuse)
-        monkeypatch.setenv("OMNI_VERIFY_IMPORT", "0")
-        det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
-        r = [det.predict(pil, conf=0.05, imgsz=320, iou=0.1)[0] for _ in range(2)][-1]       # second pass: the counters were left at zero
-        dp = det.get_plan(640, 480, 320, 0.05, 0.1, 300)
-        convs = [op for op in dp.plan.ops if op.kind == L.OP_CONV]
-        assert all(bool(op.p[6]) == fuse for op in convs if op.p[5])
-        res.append((r.boxes.xyxy.clone(), r.boxes.conf.clone()))
-    assert res[0][0].shape[0] > 10
-    assert torch.equal(res[0][0], res[1][0]) and torch.equal(res[0][1], res[1][1])
-
-
 def test_captioner_token_exact_r64(emu, monkeypatch):
     """Florence2Captioner.generate (DaViT tower, projector, BART encoder / decoder with KV cache, greedy loop: every captioner kernel)
     vs transformers on the CPU: image features, encoder output, greedy ids.  Three decode steps: a single-row lm_head (768 x 51289,
@@ -80,34 +55,18 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
         cp2.encode_plan.run(cap2.stream)
     assert G.rel_err(cp2.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
     assert G.rel_err(cp2.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
-    # the candidate kernels (Florence2Captioner.window_attn_v2 / chan_apply_mfma / mha_v2) inside the default composition: at 64x64 every stage
-    # has cut windows (16, 8, 4, 2 tokens per side) and token counts 256, 64, 16, 4 per channel-attention group; same features, encode pass only
-    monkeypatch.undo()
-    monkeypatch.setattr(Florence2Captioner, "window_attn_v2", True)
-    monkeypatch.setattr(Florence2Captioner, "chan_apply_mfma", True)        # and the candidate channel-attention apply kernel (op i[7])
-    monkeypatch.setattr(Florence2Captioner, "mha_v2", True)                 # and the candidate encoder attention (op i[17] in mode 0)
-    cap3 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
-    cap3._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
-    cp3 = cap3.plans(1, 64, max_new)
-    assert sum(op.kind == L.OP_ATTN_ROWS and op.i[12] == 1 and op.i[17] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
-    assert sum(op.kind == L.OP_CHAN_ATTN and op.i[7] == 1 for op in cp3.encode_plan.ops) == sum(cap3.w.depths)
-    assert sum(op.kind == L.OP_ATTN_ROWS and op.i[12] == 0 and op.i[17] == 1 for op in cp3.encode_plan.ops) == cap3.w.enc_layers
-    with torch.inference_mode():
-        cp3.reset()
-        cp3.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
-        cp3.encode_plan.run(cap3.stream)
-    assert G.rel_err(cp3.img_feat.t[:1, :, 0, :].float(), feats) < 1e-4
-    assert G.rel_err(cp3.enc_out.t[:1, :, 0, :].float(), enc) < 1e-4
-    assert G.rel_err(cp3.enc_out.t[:1, :, 0, :].float(), cp.enc_out.t[:1, :, 0, :].float()) < 2e-5
-    # Florence2Captioner.reuse_activations (candidate): the default kernels on aliased scratch buffers (a stage's tensors back the later
-    # stages') — the same ops in the same order on the same data: features and encoder output bit for bit those of the default plan
+    # the default plan's attention kernels at 64x64: every stage has cut windows (16, 8, 4, 2 tokens per side) and token counts
+    # 256, 64, 16, 4 per channel-attention group (covered by the feature comparison above).
+    # Florence2Captioner.reuse_activations (default): the same kernels on aliased scratch buffers (a stage's tensors back the later
+    # stages') — the same ops in the same order on the same data: features and encoder output bit for bit those of a plan whose
+    # stages each own their buffers
     monkeypatch.undo()
     cp1 = cap.plans(1, 64, max_new)              # the default composition at the same row count (tile choices follow the row count)
-    monkeypatch.setattr(Florence2Captioner, "reuse_activations", True)
+    monkeypatch.setattr(Florence2Captioner, "reuse_activations", False)
     cap4 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     cap4._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
     cp4 = cap4.plans(1, 64, max_new)
-    assert cp4.pb.reused_bytes > 0 and cp1.pb.reused_bytes == 0
+    assert cp1.pb.reused_bytes > 0 and cp4.pb.reused_bytes == 0
     with torch.inference_mode():
         for c, p in ((cap, cp1), (cap4, cp4)):
             p.reset()
@@ -115,36 +74,6 @@ def test_captioner_token_exact_r64(emu, monkeypatch):
             p.encode_plan.run(c.stream)
     assert torch.equal(cp4.img_feat.t, cp1.img_feat.t) and torch.equal(cp4.enc_out.t, cp1.enc_out.t)
     assert all(torch.equal(a.t, b.t) for a, b in zip(cp4.cross_kv, cp1.cross_kv))
-    # Florence2Captioner.split_cu_masks (experiment): the encode plan replayed over two streams (omni_plan_run_split: MFMA-bound ops on
-    # one, the rest on the other, event hand-overs at every change) — every op still runs once and in order: results bit for bit those
-    # of the one-stream replay.  (The emulation runs launches synchronously: what the events guarantee on hardware is the schedule
-    # checked in tests/test_host_cpu.py::test_split_replay_schedule_keeps_program_order.)
-    monkeypatch.undo()
-    import itertools
-    from types import SimpleNamespace
-    from emu_runtime import HostStream
-    handles = itertools.count(0x1000, 0x10)
-    made = []
-
-    class FakeMasked(HostStream):
-        def __init__(self, words):
-            self.cuda_stream = next(handles)
-            made.append(list(words))
-    monkeypatch.setattr(L, "masked_stream", lambda device, words: FakeMasked(words))
-    monkeypatch.setattr(Florence2Captioner, "split_cu_masks", ("0-175", "176-255"))
-    cap5 = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
-    cap5._wcache = cap._wcache                  # same checkpoint: packed weights are shared, not packed again
-    cp5 = cap5.plans(1, 64, max_new)
-    dec5 = SimpleNamespace(cross_kv=[SimpleNamespace(t=torch.zeros_like(kv.t)) for kv in cp5.cross_kv])
-    sched = cp5.encode_plan.split_schedule()
-    assert sum(c for c, _ in sched) == sum(op.kind in (L.OP_CONV, L.OP_MLP_FUSED) for op in cp5.encode_plan.ops) and sum(h for _, h in sched) > 50
-    with torch.inference_mode():
-        cp5.reset()
-        cp5.x_in.t[:1, :, :, :3] = pix.permute(0, 2, 3, 1)
-        cap5._encode_into(cp5, 1, dec5, 0, cap5.stream)
-    assert len(made) == 2 and made[0] == L.cu_mask_words(range(176, 256)) and made[1] == L.cu_mask_words(range(176))   # lane stream, its GEMM stream
-    assert torch.equal(cp5.img_feat.t, cp1.img_feat.t) and torch.equal(cp5.enc_out.t, cp1.enc_out.t)
-    assert all(torch.equal(d.t[:1], kv.t[:1]) for d, kv in zip(dec5.cross_kv, cp1.cross_kv))
 
 
 def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):

@@ -46,8 +46,11 @@ def main():
     flags = sys.argv[4].split(",") if len(sys.argv) > 4 else []     # "nomlp": fc1 / fc2 of the C = 128 stage as two launches
     if "nomlp" in flags:
         Florence2Captioner.fuse_mlp = False
-    from tools import switch_on                                      # candidates: "window_attn_v2", "chan_apply_mfma", "fuse_splitk", ...
-    switch_on([f for f in flags if f != "nomlp"])
+    for f in flags:                                                  # any other boolean composition switch of Florence2Captioner, "name" or "name=0"
+        if f != "nomlp":
+            name, _, val = f.partition("=")
+            assert isinstance(vars(Florence2Captioner).get(name), bool), f"unknown composition switch {name!r}"
+            setattr(Florence2Captioner, name, val != "0")
     ensure_via_subprocess("caption", seed=0)
     cap = Florence2Captioner(caption_dir(0), "cuda", precision="f32", resolution=R)
     cap.use_graph = False           # eager plans: every op is timed on its own
