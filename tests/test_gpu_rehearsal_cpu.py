@@ -74,3 +74,22 @@ def test_bench_path_check_rehearsed(rehearsal, monkeypatch):
     assert out["exact_frames"] == 1 and out["score_ties"][0] >= 1 and out["crop_coords_off_by_one"] == 0
     assert out["caption_crops_checked"] >= 8 and out["frames_touched"] == [0, 1] and len(out["micro_batches_touched"]) >= 2
     assert all(out["crop_tensor_bitwise"]) and out["matched_fraction"] == [1.0, 1.0]
+
+
+def test_rehearse_reference_image_end_to_end(rehearsal, monkeypatch):
+    """tests/test_gpu_j_reference_images.py's check on word.png (1919x1079 RGBA, the reference's own fixture): RGBA -> RGB, odd-size
+    letterbox, real-image crops, the capped CPU captioner (captions beyond the budget are not compared) — at 64x64 crops and quarter
+    width, the oracle standing in for both device models."""
+    from pathlib import Path
+    from PIL import Image
+    import gpu_checks as G
+    from omniparser_amd import florence as F
+    from omniparser_amd.synth import synthetic_ocr
+    from tools.make_weights import build_random_captioner
+    rehearsal(0.25)
+    model = build_random_captioner(0)
+    monkeypatch.setattr(F, "Florence2Captioner", lambda cdir, device, precision="f32", resolution=64: G._OracleCaptioner(model, resolution))
+    img = Image.open(Path(__file__).parent / "golden" / "ref_imgs" / "word.png")
+    out = G.check_end_to_end(width=0.25, R=64, image=img, ocr=synthetic_ocr(7, img.size[0], img.size[1], 40), max_crops_checked=3)
+    assert out["size"] == [1919, 1079] and out["n_gpu"] == out["n_ref"] and out["min_iou"] >= 0.999
+    assert out["captioned"] == 3 and out["identical_crops_token_exact"] == 3, out
