@@ -36,7 +36,6 @@ struct GemmArgs {
   int ldi, in_coff, ldo, out_coff, ldr, res_coff;
   int mtiles, ntiles, xcd_order, xcd_n;
   float oscale;                       // 2^-k of the weight pre-scale
-  int vblocks;                        // virtual grid (tile_grid): a launch of fewer blocks walks it with stride gridDim.x (persistent blocks)
 };
 
 // Epilogue shared by the kernels below.
@@ -138,7 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 // slice: +2-5 % on the K >= 512 shapes (profiles/r3_s3_gemm_bench.txt).  Measured and NOT kept (within +-5 % of this kernel, removed
 // from the library after commit f6047af; profiles/r3_s7_gemm_bench_sched2_w4.txt, r3_s8_gemm_bench_k16.txt): the barrier in front of
 // the last unit of a slice, a 4-wave 256x256 tile, a 4-wave 256x128 tile with 16-wide K slices and two blocks per CU.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0, bool PERSIST = false>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -156,14 +155,12 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave % WN;
-  // Persistent blocks: a launch of G < vblocks blocks walks the virtual grid with stride G (G % 8 == 0 keeps a block on the XCD its
-  // virtual ids map to, and the blocks resident at any moment work on consecutive virtual ids — the same L2 neighbourhood as the
-  // dispatch order of a full grid).  One 8-wave block owns all registers of a CU, so G caps the CUs this GEMM can occupy and leaves
-  // the rest of the chip to whatever else is queued (the HBM-bound kernels of the other encode lane).  G == vblocks: one pass.
-  // (a separate instantiation: the loop costs ~20 VGPRs, which the one-pass kernels of the default path do not pay)
-  for (int vb = blockIdx.x; vb < (PERSIST ? a.vblocks : (int)blockIdx.x + 1); vb += PERSIST ? (int)gridDim.x : 1) {
+  // Measured and not kept (round 4, profiles/r4_s3_persistent_gemm_ab.txt): persistent blocks walking the tile grid with stride G, to cap
+  // the CUs a GEMM occupies and leave the rest to the other lane's HBM-bound kernels.  Bit-identical results; G = 256: 665 vs 672 ms
+  // per bench step (noise), G = 224 / 192 / 160 / 128: 669 / 687 / 700 / 725 — the GEMM alone slows by 5 / 11 / 22 / 41 % and the
+  // overlap wins back only part of it.  The loop also cost ~20 VGPRs.
   int mt, nt;
-  if (!tile_of_block(vb, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) continue;
+  if (!tile_of_block(blockIdx.x, a.mtiles, a.ntiles, a.xcd_order, a.xcd_n, mt, nt)) return;
   // block-uniform by construction; said explicitly so that the buffer resources below are built in SGPRs (the division inside
   // tile_of_block runs on the VALU, and a resource the compiler believes divergent costs a waterfall loop per LDS-DMA instruction)
   const int m0 = __builtin_amdgcn_readfirstlane(mt) * BM, n0 = __builtin_amdgcn_readfirstlane(nt) * BN;
@@ -314,8 +311,6 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 
   // ---- epilogue (gemm_epilogue above): bias / activation / 2^-k in registers, rows transposed through the idle LDS ring
   gemm_epilogue<BM, BN, WM, WN, TM, TN, NSTAGE * STAGE, ACT, OSPLIT, RES>(acc, a, lds, m0, n0, wave, lane);
-  if constexpr (PERSIST) { if (vb + (int)gridDim.x < a.vblocks) __syncthreads(); }   // the next tile's first DMA pieces overwrite the epilogue's staging rows
-  }
 #endif
 }
 
@@ -508,18 +503,10 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.ntiles = a.N / BN;
   a.xcd_order = (a.mtiles >= 64 && a.ntiles > 1) ? 1 : 0;
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
-  a.vblocks = (int)tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n);
-  // OMNI_GEMM_GRID=G (multiple of 8; experiment knob, read once): at most G persistent blocks per GEMM launch
-  static const int cap = [] { const char* e = getenv("OMNI_GEMM_GRID"); const int g = e ? atoi(e) : 0; return g > 0 ? (g + 7) / 8 * 8 : 0; }();
-  dim3 grid(cap && cap < a.vblocks ? cap : a.vblocks), block(WM * WN * 64);
+  dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
   constexpr int SCHED = (BM == 256 && BN == 256) ? 1 : 0;      // front-loaded DMA issue on the 256x256 tile (see gemm_dma_kernel)
-  const bool persist = cap && cap < a.vblocks;
-#define OMNI_GD(ACT_, OS_, RES_)                                                                                                       \
-  do {                                                                                                                                 \
-    if (persist) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED, true>), grid, block, 0, s, a);     \
-    else hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED, false>), grid, block, 0, s, a);            \
-  } while (0)
+#define OMNI_GD(ACT_, OS_, RES_) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED>), grid, block, 0, s, a)
   if (act == OMNI_ACT_NONE && !osplit && !res) OMNI_GD(OMNI_ACT_NONE, false, false);
   else if (act == OMNI_ACT_NONE && !osplit && res) OMNI_GD(OMNI_ACT_NONE, false, true);
   else if (act == OMNI_ACT_NONE && osplit && !res) OMNI_GD(OMNI_ACT_NONE, true, false);
