@@ -1458,7 +1458,8 @@ def compare_frame_elements(f, elems_g, crops_g, el_r, cr_r, dbg, listed_exact, o
     out["matched_fraction"].append(round(1.0 - missing / max(len(el_r), 1), 4))
 
 
-def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=1):
+def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=1, seeds=None,
+                     detector_only=False):
     """Parity of the EXACT composition bench.py times (BASELINE configs[2]): ScreenParser.parse_batch on a batch of
     1920x1080 screenshots — batch detector plan, full-width YOLOv9-E, product glue, crops of all frames packed into 128-crop
     caption micro-batches at RxR, deferred id read-back — against the oracle pipeline (oracle.detector_ref.predict per frame
@@ -1480,7 +1481,9 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     cap = Florence2Captioner(cdir, "cuda", precision="f32", resolution=R)
     sp = ScreenParser(det, cap, box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640)
     from omniparser_amd.synth import BENCH_SEEDS
-    seeds = BENCH_SEEDS[:n_frames] if width == 1.0 else tuple(range(n_frames))     # the benched batch itself at full width
+    if seeds is None:
+        seeds = BENCH_SEEDS[:n_frames] if width == 1.0 else tuple(range(n_frames))     # the benched batch itself at full width
+    assert len(seeds) == n_frames
     imgs = [synthetic_screenshot(s, IW, IH) for s in seeds]
     frames = [torch.from_numpy(a).to(DEV) for a in imgs]
     ocr = [synthetic_ocr(s, IW, IH, 40) for s in seeds]
@@ -1531,6 +1534,9 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     if out["exact_frames"] < min(min_exact, n_frames):
         detector_problems.append(f"only {out['exact_frames']} frames compared element for element")
     assert not detector_problems, (detector_problems[:6], out)
+    out["seeds"] = list(seeds)
+    if detector_only:           # the non-curated frame set: detector + hand-off statements only (captions are checked on the benched set)
+        return out
     # ---- caption ids: crops on both sides of frame boundaries inside one micro-batch, and around a micro-batch boundary
     flat = [(f, k) for f in range(n_frames) for k in range(len(crops_g[f]))]
     chosen = []

@@ -74,6 +74,10 @@ def test_bench_path_check_rehearsed(rehearsal, monkeypatch):
     assert out["exact_frames"] == 1 and out["score_ties"][0] >= 1 and out["crop_coords_off_by_one"] == 0
     assert out["caption_crops_checked"] >= 8 and out["frames_touched"] == [0, 1] and len(out["micro_batches_touched"]) >= 2
     assert all(out["crop_tensor_bitwise"]) and out["matched_fraction"] == [1.0, 1.0]
+    # the non-curated frame set of tests/test_gpu_z_bench_path.py (explicit seeds, detector + hand-off statements only)
+    out = G.check_bench_path(R=64, width=0.5, n_frames=2, seeds=(5, 6), min_exact=0, detector_only=True)
+    assert out["seeds"] == [5, 6] and all(out["expected_from_device_candidates"]) and "caption_crops_checked" not in out
+    assert min(out["matched_fraction"]) >= 0.95
 
 
 def test_rehearse_reference_image_end_to_end(rehearsal, monkeypatch):

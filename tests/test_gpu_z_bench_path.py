@@ -15,3 +15,17 @@ def test_bench_path_parity_batch8_full_width_r768():
     # the oracle's own list, and the pipelined composition reproduced parse_batch on all three batches
     assert out["exact_frames"] == 8 and out["stream_batches_equal_parse_batch"] == 3, out
     print(out)
+
+
+def test_bench_path_uncurated_frames_seeds_0_to_7():
+    """SURVEY 8d's frames (seeds 0..7, NOT chosen for the absence of NMS ties; the benched set above is 8 of the 9 tie-free seeds among
+    0..109): on EVERY frame the device's candidates are the oracle's (same anchors and classes, scores within 1e-5, boxes within
+    2e-3 px) and the frame's elements / crop rectangles are exactly the reference post-processing of the device's own candidates;
+    against the oracle's OWN list: element for element on the frames where its NMS takes no decision on a tie, and at least 95 % of
+    its elements matched at IoU >= 0.999 on the others (one exchange per tie)."""
+    import gpu_checks as G
+    out = G.check_bench_path(R=768, width=1.0, n_frames=8, seeds=tuple(range(8)), min_exact=0, detector_only=True)
+    print(out)
+    assert all(out["expected_from_device_candidates"]) and len(out["expected_from_device_candidates"]) == 8, out
+    assert out["exact_frames"] >= 2 and min(out["matched_fraction"]) >= 0.95, out          # rounds 1-2: seeds 0 and 1 are tie-free
+    assert out["cand_max_score_diff"] <= 1e-5 and out["cand_max_box_diff_px"] <= 2e-3, out
