@@ -93,6 +93,10 @@ def main():
 
     rank, world, local_rank = OD.init_from_env()
     assert world == args.gpus, f"--gpus {args.gpus} but WORLD_SIZE={world}"
+    if world > 1:
+        # N processes share the host: without a cap every rank's CPU-side torch ops (hand-off tables, record packing, tokenizer glue)
+        # spawn one worker per core of the whole box and the ranks thrash each other
+        torch.set_num_threads(max(1, (os.cpu_count() or world) // world))
     dev = L.require_device(torch.device("cuda", local_rank), "bench.py")       # the MI355X or nothing (no CPU fallback)
     torch.cuda.set_device(local_rank)
     global IW, IH
