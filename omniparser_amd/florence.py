@@ -57,6 +57,90 @@ def _legacy_to_native(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def expected_native_keys(cfg: dict) -> Dict[str, tuple]:
+    """Every tensor a Florence-2 checkpoint in the native transformers layout must hold, with its shape, derived from config.json alone
+    (hf:models/florence2/modeling_florence2.py module tree).  `FlorenceWeights` audits a checkpoint against it at load:
+    a missing, unexpected or mis-shaped tensor is an error that names the offenders — never a silently random layer."""
+    vc, tc = cfg["vision_config"], cfg["text_config"]
+    dims, depths = vc["embed_dim"], vc["depths"]
+    ratio = vc.get("mlp_ratio", 4.0)
+    out = {}
+    vt = "model.vision_tower."
+    cin = vc.get("in_channels", 3)
+    for i, C in enumerate(dims):
+        k = vc["patch_size"][i]
+        out[f"{vt}convs.{i}.conv.weight"] = (C, cin, k, k)
+        out[f"{vt}convs.{i}.conv.bias"] = (C,)
+        nd = cin if vc["patch_prenorm"][i] else C
+        out[f"{vt}convs.{i}.norm.weight"] = out[f"{vt}convs.{i}.norm.bias"] = (nd,)
+        hid = int(C * ratio)
+        for j in range(depths[i]):
+            for blk, attn in (("spatial_block", "window_attn"), ("channel_block", "channel_attn")):
+                b = f"{vt}blocks.{i}.{j}.{blk}."
+                for cv in ("conv1", "conv2"):
+                    out[b + cv + ".weight"] = (C, 1, 3, 3)
+                    out[b + cv + ".bias"] = (C,)
+                for nm in ("norm1", "norm2"):
+                    out[b + nm + ".weight"] = out[b + nm + ".bias"] = (C,)
+                out[b + attn + ".qkv.weight"] = (3 * C, C)
+                out[b + attn + ".qkv.bias"] = (3 * C,)
+                out[b + attn + ".proj.weight"] = (C, C)
+                out[b + attn + ".proj.bias"] = (C,)
+                out[b + "ffn.fc1.weight"] = (hid, C)
+                out[b + "ffn.fc1.bias"] = (hid,)
+                out[b + "ffn.fc2.weight"] = (C, hid)
+                out[b + "ffn.fc2.bias"] = (C,)
+        cin = C
+    mp = "model.multi_modal_projector."
+    P, D = vc["projection_dim"], tc["d_model"]
+    out[mp + "image_projection.weight"] = (P, dims[-1])
+    out[mp + "image_proj_norm.weight"] = out[mp + "image_proj_norm.bias"] = (P,)
+    out[mp + "image_position_embed.row_embeddings.weight"] = out[mp + "image_position_embed.column_embeddings.weight"] = \
+        (vc.get("max_position_embeddings", 50), dims[-1] // 2)
+    out[mp + "visual_temporal_embed.pos_idx_to_embed"] = (vc.get("max_temporal_embeddings", 100), dims[-1])
+    lm = "model.language_model."
+    out[lm + "shared.weight"] = (tc["vocab_size"], D)
+    for side, n_layers, ffn in (("encoder", tc["encoder_layers"], tc["encoder_ffn_dim"]), ("decoder", tc["decoder_layers"], tc["decoder_ffn_dim"])):
+        out[f"{lm}{side}.embed_positions.weight"] = (tc["max_position_embeddings"] + 2, D)
+        out[f"{lm}{side}.layernorm_embedding.weight"] = out[f"{lm}{side}.layernorm_embedding.bias"] = (D,)
+        for l in range(n_layers):
+            b = f"{lm}{side}.layers.{l}."
+            attns = ("self_attn",) if side == "encoder" else ("self_attn", "encoder_attn")
+            for a in attns:
+                for pj in ("q_proj", "k_proj", "v_proj", "out_proj"):
+                    out[b + f"{a}.{pj}.weight"] = (D, D)
+                    out[b + f"{a}.{pj}.bias"] = (D,)
+                out[b + f"{a}_layer_norm.weight"] = out[b + f"{a}_layer_norm.bias"] = (D,)
+            out[b + "fc1.weight"] = (ffn, D); out[b + "fc1.bias"] = (ffn,)
+            out[b + "fc2.weight"] = (D, ffn); out[b + "fc2.bias"] = (D,)
+            out[b + "final_layer_norm.weight"] = out[b + "final_layer_norm.bias"] = (D,)
+    return out
+
+
+# tensors a checkpoint MAY carry beyond the list above: the tied output embedding, the (all-zero) logits bias, the encoder / decoder
+# copies of the shared embedding that older exports duplicate
+_OPTIONAL_KEYS = {"lm_head.weight": lambda cfg: (cfg["text_config"]["vocab_size"], cfg["text_config"]["d_model"]),
+                  "final_logits_bias": lambda cfg: (1, cfg["text_config"]["vocab_size"]),
+                  "model.language_model.encoder.embed_tokens.weight": lambda cfg: (cfg["text_config"]["vocab_size"], cfg["text_config"]["d_model"]),
+                  "model.language_model.decoder.embed_tokens.weight": lambda cfg: (cfg["text_config"]["vocab_size"], cfg["text_config"]["d_model"])}
+
+
+def audit_checkpoint(sd: Dict[str, torch.Tensor], cfg: dict) -> None:
+    """Strict audit of a (native-layout) state dict against config.json: raises ValueError naming what is wrong."""
+    want = expected_native_keys(cfg)
+    missing = sorted(k for k in want if k not in sd)
+    unexpected = sorted(k for k in sd if k not in want and k not in _OPTIONAL_KEYS)
+    shapes = sorted(f"{k}: {tuple(sd[k].shape)} != {want[k]}" for k in want if k in sd and tuple(sd[k].shape) != tuple(want[k]))
+    shapes += sorted(f"{k}: {tuple(sd[k].shape)} != {_OPTIONAL_KEYS[k](cfg)}" for k in _OPTIONAL_KEYS
+                     if k in sd and tuple(sd[k].shape) != tuple(_OPTIONAL_KEYS[k](cfg)))
+    if missing or unexpected or shapes:
+        show = lambda l: ", ".join(l[:6]) + (f" ... (+{len(l) - 6})" if len(l) > 6 else "")
+        raise ValueError("Florence-2 checkpoint does not match its config.json: "
+                         + "; ".join(p for p in (f"{len(missing)} missing [{show(missing)}]" if missing else "",
+                                                 f"{len(unexpected)} unexpected [{show(unexpected)}]" if unexpected else "",
+                                                 f"{len(shapes)} mis-shaped [{show(shapes)}]" if shapes else "") if p))
+
+
 class FlorenceWeights:
     def __init__(self, model_dir):
         from safetensors.torch import load_file
@@ -73,6 +157,7 @@ class FlorenceWeights:
             sd.update(load_file(str(f)))
         if any(k.startswith("vision_tower.") for k in sd):
             sd = _legacy_to_native(sd)
+        audit_checkpoint(sd, self.cfg)           # strict: every tensor the config implies, with its shape, nothing unknown
         self.sd = {k: v.float() for k, v in sd.items()}
         if "lm_head.weight" not in self.sd:
             self.sd["lm_head.weight"] = self.sd["model.language_model.shared.weight"]

@@ -169,3 +169,42 @@ def test_plan_cache_is_bounded_by_bytes_and_never_evicts_the_pending_batch(monke
     assert list(cap._plans)[0] == ("dec", 384, 768, 20)
     take((64, 768, 20, 1), 90)                                # estimate 90 -> evicts d, e, e' (all unpinned), keeps the pinned 64-row set
     assert list(cap._plans) == [(64, 768, 20), (64, 768, 20, 1)]
+
+
+def test_checkpoint_audit_is_strict(ckpt_dir, tmp_path):
+    """the loader audits a checkpoint against config.json — the expected key list equals the tensors of the native
+    transformers module tree (the stand-in checkpoint is a saved transformers model), a legacy-named (`trust_remote_code`) checkpoint
+    passes after the rename, and a missing / unexpected / mis-shaped tensor is an error that names it."""
+    import json
+    import shutil
+    from safetensors.torch import load_file, save_file
+    from omniparser_amd.florence import FlorenceWeights, _OPTIONAL_KEYS, audit_checkpoint, expected_native_keys
+    cfg = json.loads((ckpt_dir / "config.json").read_text())
+    native = load_file(str(ckpt_dir / "model.safetensors"))
+    want = expected_native_keys(cfg)
+    assert set(want) == set(native) - set(_OPTIONAL_KEYS)
+    assert all(tuple(native[k].shape) == tuple(v) for k, v in want.items())
+    audit_checkpoint(native, cfg)
+
+    def write(sd, name):
+        d = tmp_path / name
+        d.mkdir()
+        for f in ("config.json", "generation_config.json"):
+            if (ckpt_dir / f).exists():
+                shutil.copy(ckpt_dir / f, d / f)
+        save_file({k: v.contiguous() for k, v in sd.items()}, str(d / "model.safetensors"))
+        return d
+    # a legacy-named checkpoint loads (renamed, audited) and yields the same tensors
+    w = FlorenceWeights(write(_native_to_legacy(native), "legacy"))
+    assert torch.equal(w.sd["model.vision_tower.convs.0.conv.weight"], native["model.vision_tower.convs.0.conv.weight"].float())
+    assert torch.equal(w.sd["model.multi_modal_projector.image_projection.weight"], native["model.multi_modal_projector.image_projection.weight"].float())
+    # missing / unexpected / mis-shaped
+    bad = dict(native); bad.pop("model.vision_tower.blocks.2.7.channel_block.ffn.fc2.bias")
+    with pytest.raises(ValueError, match=r"1 missing \[model\.vision_tower\.blocks\.2\.7\.channel_block\.ffn\.fc2\.bias\]"):
+        FlorenceWeights(write(bad, "missing"))
+    bad = dict(native); bad["model.vision_tower.blocks.0.0.spatial_block.window_attn.fn.qkv.weight"] = torch.zeros(3)
+    with pytest.raises(ValueError, match="1 unexpected"):
+        FlorenceWeights(write(bad, "unexpected"))
+    bad = dict(native); bad["model.language_model.decoder.layers.3.fc1.weight"] = torch.zeros(3072, 767)
+    with pytest.raises(ValueError, match=r"1 mis-shaped \[model\.language_model\.decoder\.layers\.3\.fc1\.weight: \(3072, 767\) != \(3072, 768\)\]"):
+        FlorenceWeights(write(bad, "shape"))
