@@ -1,0 +1,99 @@
+"""How many of the synthetic frames does the MI355X reproduce ELEMENT FOR ELEMENT against the oracle's own list — measured, not
+predicted from a-priori margins (tools/scan_parity_frames.py is the a-priori scan: 9 of 110 seeds have no NMS tie in the oracle)?
+
+  python tools/scan_gpu_vs_oracle.py oracle 0:110    (any box; CPU only: the oracle's final boxes / scores per seed, full-width stand-in,
+                                                      1920x1080 frames at 640x640 -> tools/_scan/oracle_finals.json; deterministic)
+  python tools/scan_gpu_vs_oracle.py device          (GPU box: the detector's final boxes for the same seeds, then per frame: same count,
+                                                      one-to-one pairing at IoU >= 0.999, same glue elements and crop rectangles)
+The oracle is test infrastructure: this tool is a measurement script, nothing in the product imports it."""
+import json
+import sys
+from pathlib import Path
+
+import torch
+from PIL import Image
+
+ROOT = Path(__file__).resolve().parents[1]
+sys.path.insert(0, str(ROOT))
+sys.path.insert(0, str(ROOT / "tests"))
+CACHE = ROOT / "tools" / "_scan" / "oracle_finals.json"
+IW, IH = 1920, 1080
+
+
+def bits(t):
+    return t.contiguous().view(torch.int32).flatten().tolist()
+
+
+def unbits(v, cols=None):
+    t = torch.tensor(v, dtype=torch.int32).view(torch.float32)
+    return t.view(-1, cols) if cols else t
+
+
+def run_oracle(lo, hi):
+    from oracle import detector_ref as D
+    from omniparser_amd.synth import synthetic_screenshot
+    from tools.make_weights import ensure_blob
+    m = torch.jit.load(str(ensure_blob(seed=0, nc=1, width=1.0)), map_location="cpu").eval()
+    out = json.loads(CACHE.read_text()) if CACHE.exists() else {}
+    for s in range(lo, hi):
+        if str(s) in out:
+            continue
+        rb, rs, rc, dbg = D.predict(m, Image.fromarray(synthetic_screenshot(s, IW, IH)), conf=0.05, imgsz=640, iou=0.1, max_det=300, return_debug=True)
+        out[str(s)] = {"boxes": bits(rb), "conf": bits(rs), "near_ties": int(dbg["near_ties"]), "score_ties": int(dbg["score_ties"]),
+                       "candidates": int(dbg["valid"].sum())}
+        print(s, len(rb), dbg["near_ties"], dbg["score_ties"], flush=True)
+    CACHE.parent.mkdir(exist_ok=True)
+    CACHE.write_text(json.dumps(out))
+
+
+def run_device():
+    from omniparser_amd.pipeline import ScreenParser
+    from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
+    from omniparser_amd.util.yolov9 import YOLOv9Detector
+    from tools.make_weights import ensure_blob
+    gold = json.loads(CACHE.read_text())
+    det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=1.0), device="cuda", precision="f32")
+    sp = ScreenParser(det, None, box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640)
+    rows, n_exact, n_boxes_exact, tie_free, tie_free_exact = [], 0, 0, 0, 0
+    for s in sorted(map(int, gold)):
+        g = gold[str(s)]
+        rb, rs = unbits(g["boxes"], 4), unbits(g["conf"])
+        img = Image.fromarray(synthetic_screenshot(s, IW, IH))
+        r = det.predict(img, conf=0.05, imgsz=640, iou=0.1)[0]
+        gb, gs = r.boxes.xyxy.cpu(), r.boxes.conf.cpu()
+        texts, obox = synthetic_ocr(s, IW, IH, 40)
+        el_r, cr_r = sp.glue(rb, IW, IH, obox, texts)
+        el_g, cr_g = sp.glue(gb, IW, IH, obox, texts)
+        same_n = len(gb) == len(rb)
+        boxes_ok = False
+        if same_n and len(rb):
+            # order-free one-to-one pairing at IoU >= 0.999 (two boxes whose scores agree to 1e-6 may exchange ranks)
+            x1 = torch.maximum(rb[:, None, 0], gb[None, :, 0]); y1 = torch.maximum(rb[:, None, 1], gb[None, :, 1])
+            x2 = torch.minimum(rb[:, None, 2], gb[None, :, 2]); y2 = torch.minimum(rb[:, None, 3], gb[None, :, 3])
+            inter = (x2 - x1).clamp(min=0) * (y2 - y1).clamp(min=0)
+            ar = (rb[:, 2] - rb[:, 0]) * (rb[:, 3] - rb[:, 1]); ag = (gb[:, 2] - gb[:, 0]) * (gb[:, 3] - gb[:, 1])
+            m = torch.nan_to_num(inter / (ar[:, None] + ag[None, :] - inter).clamp_min(1e-12), nan=1.0)
+            best, arg = m.max(1)
+            degenerate = (ar <= 0)                        # zero-area boxes have no IoU: matched by coordinates
+            close = (rb[:, None, :] - gb[None, :, :]).abs().amax(2).min(1).values < 1e-2
+            boxes_ok = bool(((best >= 0.999) | (degenerate & close)).all()) and len(set(arg[~degenerate].tolist())) == int((~degenerate).sum())
+        elems_ok = boxes_ok and len(el_r) == len(el_g) and [list(c) for c in cr_r] == [list(c) for c in cr_g] and all(
+            (a["type"], a["source"], a["interactivity"], a["content"]) == (b["type"], b["source"], b["interactivity"], b["content"]) and
+            max(abs(x - y) for x, y in zip(a["bbox"], b["bbox"])) < 1e-5 for a, b in zip(el_g, el_r))
+        tf = g["near_ties"] == 0 and g["score_ties"] == 0
+        n_boxes_exact += boxes_ok; n_exact += elems_ok; tie_free += tf; tie_free_exact += (tf and elems_ok)
+        rows.append({"seed": s, "boxes": [len(rb), len(gb)], "elements": [len(el_r), len(el_g)], "oracle_ties": [g["near_ties"], g["score_ties"]],
+                     "boxes_identical": bool(boxes_ok), "elements_identical": bool(elems_ok)})
+    print(json.dumps({"frames": len(rows), "final_boxes_identical": n_boxes_exact, "elements_and_crops_identical": n_exact,
+                      "oracle_tie_free_frames": tie_free, "tie_free_and_identical": tie_free_exact,
+                      "definition": "identical = same count, one-to-one pairing at IoU >= 0.999 (zero-area boxes by coordinates), then the same element "
+                                    "list (type / source / content / order, bbox within 1e-5 in ratio units) and the same integer crop rectangles",
+                      "frames_not_identical": [r for r in rows if not r["elements_identical"]]}))
+
+
+if __name__ == "__main__":
+    if sys.argv[1] == "oracle":
+        lo, hi = (int(v) for v in sys.argv[2].split(":"))
+        run_oracle(lo, hi)
+    else:
+        run_device()
