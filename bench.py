@@ -600,6 +600,18 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
         cap.generate(input_ids=ids, pixel_values=pix, max_new_tokens=20, num_beams=1, do_sample=False)
     t_crop = (time.perf_counter() - t0) / n
     per_shot = t_det + mean_crops * t_crop
+    c0 = ROOT / "profiles" / "r4_s4_configs0.json"
+    if c0.exists():
+        # BASELINE configs[0] measured WHOLE in a separate session (tools/configs0.py: the reference's demo_image.jpg, ONE full CPU pass of
+        # every crop at 768x768 vs Omniparser.parse on the MI355X) — quoted from the committed record, not measured by this run
+        try:
+            d0 = json.loads(c0.read_text())
+            res["configs0_measured_separately"] = {"cpu_seconds_per_image": d0["cpu_reference_equivalent"]["seconds_per_image"],
+                                                   "mi355x_seconds_per_image": d0["mi355x"]["seconds_per_image"], "image": d0["image"],
+                                                   "size": d0["size"], "captions_identical": d0["agreement"]["captions_identical"],
+                                                   "source": "profiles/r4_s4_configs0.json"}
+        except Exception:                                   # noqa: BLE001 — an optional citation
+            pass
     res.update(value=round(1.0 / per_shot, 5),
                sample=f"detector on 2 screenshots ({t_det:.2f} s each) + crop/resize/Florence-2 generate on one batch of {n} crops at "
                       f"{R}x{R} ({t_crop:.2f} s/crop), composed as t_det + {mean_crops} crops x t_crop (glue excluded)")
