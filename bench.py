@@ -155,7 +155,10 @@ def main():
         elems, ids = parser.parse_batch([frames[f] for f in idx], [ocr[f] for f in idx], return_ids=True)
         pack(step_id, li, elems, ids)
 
+    step_done = []                       # host clock when each step's results were in hand (diagnostic: a cold first process shows here)
+
     def pack(step_id, li, elems, ids):
+        step_done.append(time.perf_counter())
         crop_counts.append(sum(parser.stats["crops"]))
         if li is not None:
             pack_records(recs, B, dev, step_id, li, elems, ids)
@@ -181,6 +184,7 @@ def main():
             note(f"warm-up step {w} done")
     sync_all()
     crop_counts.clear()
+    step_done.clear()
     t0 = time.perf_counter()
     if args.pipeline and args.mode == "e2e":
         # the same K steps as a software pipeline over batches (ScreenParser.parse_stream): detector + hand-off of step i+1 overlap
@@ -236,6 +240,8 @@ def main():
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
+        # wall time between consecutive steps' results inside the timed region (pipelined: step i's results arrive while step i+1 runs)
+        out["config"]["step_wall_ms"] = [round(1000.0 * (b - a), 1) for a, b in zip([t0] + step_done[:-1], step_done)][:40]
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
         if args.pipeline:
             out["config"]["pipeline"] = ("parse_stream: detector + hand-off graph of step i+1 on the detector's stream, caption micro-batches alternating "
