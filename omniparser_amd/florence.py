@@ -294,7 +294,7 @@ class _StepPlans:
 
 class _DecodePlans(_StepPlans):
     """Decode for the crops of SEVERAL caption micro-batches at once.  The encode side of a batch of screenshots runs in micro-batches
-    of <= 128 crops (60 GB of activations each at 768x768); the decode side is 20 steps of ~110 small kernels whose cost hardly
+    of <= 128 crops (~25 GB of activations each at 768x768 with activation reuse, 60 GB without); the decode side is 20 steps of ~110 small kernels whose cost hardly
     depends on the row count (launch-bound GEMMs over 128 rows) — per micro-batch that was 29 ms, 80 ms of a 750 ms step.  Here the
     cross-attention K / V of every micro-batch are copied (6 x 460 MB per 128 crops, ~1 ms) into the row range of ONE decode plan over
     B rows, which then runs its 20 steps once.  Rows are independent: ids per crop are what the per-micro-batch decode produces
@@ -649,7 +649,7 @@ class Florence2Captioner:
     def bucket(n: int) -> int:
         """plan capacity for a micro-batch of n crops (rows beyond n are computed and ignored): powers of two plus 96 — the bench
         step's 349 crops are 128 + 128 + 93, and a 96-row plan for that tail computes 8 % fewer rows per step than a third 128-row
-        one.  Every capacity is one more resident plan (60 GB of activations at 128 rows, 768x768 crops; at most OMNI_CAPTION_PLAN_GB
+        one.  Every capacity is one more resident plan (~25 GB of activations at 128 rows, 768x768 crops — 60 GB without activation reuse; at most OMNI_CAPTION_PLAN_GB
         stay resident), which is why the ladder is not finer; OMNI_CAPTION_BUCKETS overrides it."""
         for b in _BUCKETS:
             if n <= b:
@@ -662,9 +662,9 @@ class Florence2Captioner:
         return max(128, (n + 127) // 128 * 128)
 
     # ---- resident plan sets: ONE cache for encode and decode plans, bounded by BYTES (and, secondarily, by count), LRU, never
-    # evicting what the batch being issued has already taken.  A 128-row plan set at 768x768 crops holds ~60 GB of activations, a
+    # evicting what the batch being issued has already taken.  A 128-row plan set at 768x768 crops holds ~25 GB of activations (60 GB without activation reuse), a
     # 384-row decode plan ~8 GB: a bound counted in plans either thrashes on a stream with varying crop counts (every eviction is a
-    # device-wide synchronise + a ~60 GB rebuild + a graph capture) or lets the resident set grow past the HBM.
+    # device-wide synchronise + a rebuild of tens of GB + a graph capture) or lets the resident set grow past the HBM.
     def begin_batch(self):
         """Called by the pipeline before it takes the plans of one caption batch: everything taken from here on is pinned until the
         next call (at most 2 lane plans + 1 remainder plan + 1 decode plan)."""
@@ -720,7 +720,7 @@ class Florence2Captioner:
     @torch.inference_mode()
     def plans(self, B, R, max_new, slot=0) -> _CaptionPlans:
         """slot 1 = a second, independent set of buffers of the same capacity: the pipelined stream (pipeline.py::parse_stream) keeps two
-        128-crop micro-batches in flight on two HIP streams (60 GB of activations each at 768x768)."""
+        128-crop micro-batches in flight on two HIP streams (~25 GB of activations each at 768x768 with activation reuse, 60 GB without)."""
         key = (B, R, max_new) if slot == 0 else (B, R, max_new, slot)
         return self._cached_plan(key, lambda: _CaptionPlans(self, B, R, max_new))
 
