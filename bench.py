@@ -1,8 +1,9 @@
 #!/usr/bin/env python
 """bench.py — screenshots/sec of the MI355X screen-parsing hot path (BASELINE.json metric).
 
-Contract: `python bench.py --gpus N --steps K --warmup W` (N>1 under torch.distributed.run, one rank
-per GPU).  A *step* is one pass of the hot path over one batch of synthetic 1920x1080 screenshots that
+Contract: `python bench.py --gpus N --steps K --warmup W` — for N>1 either under torch.distributed.run (one rank per
+GPU, the environment it sets is used as is) or plainly, in which case this script spawns its N ranks itself
+(`omniparser_amd.dist.self_launch`).  A *step* is one pass of the hot path over one batch of synthetic 1920x1080 screenshots that
 are already resident in HBM as RGB bytes:
 
   --mode e2e (default; BASELINE configs[2]): batch of 8 screenshots -> Pillow-exact Lanczos letterbox ->
@@ -81,6 +82,11 @@ def note(msg):
 
 def main():
     args = parse_args()
+    if args.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        # `python bench.py --gpus N` with no launcher: this process spawns the N ranks itself (one per GPU, RCCL rendezvous on 127.0.0.1) and
+        # relays rank 0's JSON line; under `python -m torch.distributed.run` the environment is already there and nothing is spawned
+        from omniparser_amd.dist import self_launch
+        sys.exit(self_launch(args.gpus))
     import faulthandler
     faulthandler.dump_traceback_later(int(os.environ.get("OMNI_BENCH_WATCHDOG", "240")), repeat=True, file=sys.stderr)   # where is it, if it stalls
     import torch

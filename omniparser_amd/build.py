@@ -47,11 +47,38 @@ def _stale(target: Path, deps) -> bool:
     return not target.exists() or not st.exists() or st.read_text().strip() != _digest(deps)
 
 
-def _mark(target: Path, deps) -> None:
-    _stamp(target).write_text(_digest(deps) + "\n")
+def _mark(target: Path, digest: str) -> None:
+    """`digest` is the one computed BEFORE the compile started: a source edited while hipcc runs leaves a stamp that does not match
+    it, so the next call rebuilds instead of trusting an object made from the older content."""
+    tmp = _stamp(target).with_name(_stamp(target).name + f".tmp{os.getpid()}")
+    tmp.write_text(digest + "\n")
+    os.replace(tmp, _stamp(target))
+
+
+class _BuildLock:
+    """One builder at a time per tree: N ranks of `bench.py --gpus N` (or pytest-xdist workers) all call `ensure_built()`; without
+    the lock they would compile and link the same `_obj/*.o`, `libomni_amd.so` and stamps concurrently.  flock on a file in `_obj/`;
+    the waiters find everything fresh when they get the lock."""
+
+    def __enter__(self):
+        import fcntl
+        OBJ.mkdir(exist_ok=True)
+        self.f = open(OBJ / ".build.lock", "w")
+        fcntl.flock(self.f, fcntl.LOCK_EX)
+        return self
+
+    def __exit__(self, *exc):
+        import fcntl
+        fcntl.flock(self.f, fcntl.LOCK_UN)
+        self.f.close()
 
 
 def build_lib(force: bool = False, verbose: bool = True) -> Path:
+    with _BuildLock():
+        return _build_lib_locked(force, verbose)
+
+
+def _build_lib_locked(force: bool, verbose: bool) -> Path:
     srcs = sources()
     hdrs = list(CSRC.glob("*.h")) + [PKG.parent / "include" / "omni_amd.h"]
     OBJ.mkdir(exist_ok=True)
@@ -59,15 +86,19 @@ def build_lib(force: bool = False, verbose: bool = True) -> Path:
     for src in srcs:
         obj = OBJ / (src.stem + ".o")
         if force or _stale(obj, [src] + hdrs):
-            jobs.append((src, obj))
+            jobs.append((src, obj, _digest([src] + hdrs)))
+    lib_digest = _digest(srcs + hdrs)
 
     def compile_one(job):
-        src, obj = job
-        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(obj)]
+        src, obj, digest = job
+        tmp = obj.with_name(obj.name + f".tmp{os.getpid()}")
+        cmd = [HIPCC, *FLAGS, "-c", str(src), "-o", str(tmp)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
             raise RuntimeError(f"hipcc failed for {src.name}:\n{r.stderr}")
-        _mark(obj, [src] + hdrs)
+        os.replace(tmp, obj)
+        _mark(obj, digest)
         return src.name
 
     if jobs:
@@ -77,11 +108,14 @@ def build_lib(force: bool = False, verbose: bool = True) -> Path:
                     print(f"[omniparser_amd.build] compiled {name}", file=sys.stderr)
     objs = [OBJ / (s.stem + ".o") for s in srcs]
     if force or jobs or _stale(LIB, srcs + hdrs):
-        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(LIB), *map(str, objs)]
+        tmp = LIB.with_name(LIB.name + f".tmp{os.getpid()}")
+        cmd = [HIPCC, "--offload-arch=gfx950", "-shared", "-fPIC", "-o", str(tmp), *map(str, objs)]
         r = subprocess.run(cmd, capture_output=True, text=True)
         if r.returncode != 0:
+            tmp.unlink(missing_ok=True)
             raise RuntimeError(f"link failed:\n{r.stderr}")
-        _mark(LIB, srcs + hdrs)
+        os.replace(tmp, LIB)                       # a process that already mapped the old file keeps its inode
+        _mark(LIB, lib_digest)
         if verbose:
             print(f"[omniparser_amd.build] linked {LIB}", file=sys.stderr)
     return LIB

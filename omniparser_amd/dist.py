@@ -34,6 +34,49 @@ def init_from_env(backend: str = None):
     return rank, world, local_rank
 
 
+def self_launch(n: int, argv=None, env_extra=None) -> int:
+    """`python bench.py --gpus N` without a launcher (WORLD_SIZE unset): the script owns its fan-out.  The reference has no launcher to
+    match (ref:util/omniparser.py:16-32 is one process on one device), so a plain invocation must work the way
+    `python -m torch.distributed.run --nproc-per-node N` does: N children of this very command line, one per GPU, with
+    RANK / LOCAL_RANK / WORLD_SIZE / MASTER_ADDR / MASTER_PORT set (127.0.0.1, a free port); stdout and stderr are inherited, so rank 0's
+    one JSON line is this process's stdout.  The parent touches no GPU.  Returns the largest child exit code; if a rank dies, the
+    others (exact PIDs, nothing by pattern) are terminated so a failed rendezvous cannot hang the job."""
+    import socket
+    import subprocess
+    import sys
+    import time
+    argv = list(sys.argv if argv is None else argv)
+    with socket.socket() as s:
+        s.bind(("127.0.0.1", 0))
+        port = s.getsockname()[1]
+    procs = []
+    for r in range(n):
+        env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
+                   MASTER_PORT=str(port), OMNI_SELF_LAUNCHED="1", **(env_extra or {}))
+        env.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")          # dmabuf IPC only on this driver (RCCL across processes)
+        procs.append(subprocess.Popen([sys.executable, *argv], env=env))
+    rc = 0
+    live = list(procs)
+    while live:
+        for p in list(live):
+            r = p.poll()
+            if r is None:
+                continue
+            live.remove(p)
+            if r != 0 and rc == 0:
+                rc = r if r > 0 else 128 - r
+                deadline = time.time() + 10.0
+                for q in live:                                      # one rank failed: the others would wait in a collective forever
+                    q.terminate()
+                for q in live:
+                    try:
+                        q.wait(max(0.1, deadline - time.time()))
+                    except subprocess.TimeoutExpired:
+                        q.kill()
+        time.sleep(0.05)
+    return rc
+
+
 def shard_indices(n_items: int, rank: int, world: int) -> List[int]:
     """round-robin: item i belongs to rank i % world."""
     return list(range(rank, n_items, world))

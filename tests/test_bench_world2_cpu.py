@@ -44,3 +44,48 @@ def test_bench_main_world2_gloo_on_the_emulation():
     assert "cpu_baseline" not in d or d["cpu_baseline"] is None or "skipped" in json.dumps(d["cpu_baseline"])
     # every screenshot of the job arrived in the gathered records: mean kept boxes over all 4 items is a real count
     assert d["config"]["mean_elements_per_screenshot"] > 5
+
+
+def _check_world2_line(d):
+    assert d["n_gpus"] == 2 and d["steps"] == 2 and d["scaling"] == "weak" and d["unit"] == "screenshots/s"
+    assert abs(d["value"] - 4 / (d["ms_per_step"] * 2 / 1000.0)) < 1e-3 * d["value"] + 1e-3
+    assert "replicas x2" in d["config"]["parallelism"]
+    assert d["config"]["mean_elements_per_screenshot"] > 5
+
+
+def test_bench_self_launch_world2_gloo_on_the_emulation():
+    """`python bench.py --gpus 2` with NO launcher environment (how a driver that does not use torchrun starts it): the script spawns its
+    two ranks itself (omniparser_amd.dist.self_launch), rank 0's JSON line is the parent's stdout, and the line equals in structure what
+    the torchrun-style invocation above prints."""
+    from tools.make_weights import ensure_blob
+    ensure_blob(seed=0, nc=1, width=0.25)
+    args = ["--gpus", "2", "--steps", "2", "--warmup", "1", "--mode", "detect", "--batch", "1", "--width", "0.25", "--frame", "640x480",
+            "--imgsz", "320", "--no-extra", "--no-cpu-baseline"]
+    env = dict(os.environ, OMNI_DIST_BACKEND="gloo", OMNI_VERIFY_IMPORT="0", OMNI_BENCH_WATCHDOG="900")
+    for k in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT", "OMNI_EMU"):
+        env.pop(k, None)
+    r = subprocess.run([sys.executable, str(ROOT / "tests" / "emu" / "bench_emulated.py"), *args], env=env, cwd=str(ROOT),
+                       capture_output=True, text=True, timeout=1500)
+    assert r.returncode == 0, r.stderr[-3000:]
+    lines = [l for l in r.stdout.strip().splitlines() if l.startswith("{")]
+    assert len(lines) == 1, r.stdout[-2000:]
+    _check_world2_line(json.loads(lines[0]))
+
+
+def test_self_launch_propagates_a_failing_rank(tmp_path):
+    """one rank exits non-zero while the other would wait forever: the launcher terminates the survivor (its exact PID) and returns the
+    failing status instead of hanging."""
+    script = tmp_path / "ranks.py"
+    script.write_text(
+        "import os, sys, time\n"
+        "assert os.environ['WORLD_SIZE'] == '2' and os.environ['MASTER_ADDR'] == '127.0.0.1' and int(os.environ['MASTER_PORT']) > 0\n"
+        "assert os.environ['LOCAL_RANK'] == os.environ['RANK']\n"
+        "if os.environ['RANK'] == '1':\n    sys.exit(7)\n"
+        "time.sleep(600)\n")
+    code = ("import sys, time; sys.path.insert(0, %r)\n"
+            "from omniparser_amd.dist import self_launch\n"
+            "t = time.time(); rc = self_launch(2, argv=[%r]); print(rc, time.time() - t < 60)\n") % (str(ROOT), str(script))
+    env = {k: v for k, v in os.environ.items() if k not in ("RANK", "LOCAL_RANK", "WORLD_SIZE", "MASTER_ADDR", "MASTER_PORT")}
+    r = subprocess.run([sys.executable, "-c", code], env=env, capture_output=True, text=True, timeout=120)
+    assert r.returncode == 0, r.stderr[-2000:]
+    assert r.stdout.split() == ["7", "True"], r.stdout

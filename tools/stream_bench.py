@@ -3,6 +3,7 @@
 
     python tools/stream_bench.py --items 64 --caption-res 64
     python -m torch.distributed.run --nnodes=1 --nproc-per-node 8 --master-addr 127.0.0.1 tools/stream_bench.py --items 1581
+    python tools/stream_bench.py --gpus 8 --items 1581          # the same job, self-launched (omniparser_amd.dist.self_launch)
 
 The dataset is absent (no network): frames are synthetic screenshots at the resolution mix of `stream.RESOLUTION_MIX`
 (documented as synthetic), a small pool per resolution kept resident in HBM, OCR boxes synthetic.  Prints one JSON
@@ -28,7 +29,11 @@ def main():
     ap.add_argument("--pool", type=int, default=2, help="distinct synthetic frames kept per resolution")
     ap.add_argument("--ocr", type=int, default=40)
     ap.add_argument("--seed", type=int, default=0)
+    ap.add_argument("--gpus", type=int, default=None, help="ranks; with no launcher environment (WORLD_SIZE unset) and N > 1 the script spawns them itself")
     a = ap.parse_args()
+    if a.gpus and a.gpus > 1 and "WORLD_SIZE" not in os.environ:
+        from omniparser_amd.dist import self_launch
+        sys.exit(self_launch(a.gpus))
     import torch
     import torch.distributed as dist
     from omniparser_amd import dist as OD
