@@ -28,7 +28,10 @@
 extern "C" {
 #endif
 
-#define OMNI_ABI_VERSION 1
+/* 2 (round 5): omni_stream_create / omni_stream_destroy / omni_plan_run_split and omni_debug_host_op are gone; OMNI_OP_ATTN_ROWS i17,
+ * OMNI_OP_CHAN_ATTN i7 and OMNI_OP_CONV p6 / i22 are ignored; OMNI_OP_NMS sorts candidates inside the op.  A host compiled against
+ * version 1 must be rebuilt: omni_abi_version() is what it checks at load time (omniparser_amd/_lib.py does). */
+#define OMNI_ABI_VERSION 2
 
 enum { OMNI_F32 = 0, OMNI_F16 = 1 };
 enum { OMNI_ACT_NONE = 0, OMNI_ACT_SILU = 1, OMNI_ACT_GELU = 2 };
@@ -253,11 +256,6 @@ int omni_plan_profile(omni_plan_t* plan, void* stream, float* h_ms);
  * weight_bytes < 0: use `xcd_n` (1, 2, 4 or 8, must divide ntiles). */
 int omni_debug_tile_map(int mtiles, int ntiles, int xcd_n, long long weight_bytes, int bid, int* mt, int* nt, int* grid,
                         int* xcd_n_used);
-
-/* Host emulation of one op on HOST pointers, running the same per-thread source the kernel runs (only kinds whose
- * bodies need no LDS / cross-lane ops: OMNI_OP_DWCONV3; variant 0 = point kernel, 1 = strip kernel).  Test
- * infrastructure for boxes without a GPU; never used by omni_op_launch or plans. */
-int omni_debug_host_op(const omni_op_t* op, int variant);
 
 /* ------------------------------------------------------------------------ *
  * Model-level entry points: the two models of the hot path for hosts

@@ -21,12 +21,13 @@ OP_DWCONV3, OP_LAYERNORM, OP_ATTN_ROWS, OP_CHAN_ATTN, OP_PROJ_PREP, OP_ASSEMBLE 
 OP_EMBED_STEP, OP_ATTN_DECODE, OP_GREEDY_STEP, OP_CROP_RESIZE, OP_DWCONV3_LN, OP_SPLIT_CONVERT, OP_GLUE = 14, 15, 16, 17, 18, 19, 20
 OP_OVERLAY, OP_PNG_PACK, OP_PNG_DEFLATE, OP_MLP_FUSED = 21, 22, 23, 24
 CAND_BYTES = 32
+ABI_VERSION = 2         # include/omni_amd.h::OMNI_ABI_VERSION — a library built from other headers is refused at load time
 
 EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
     "omni_plan_create", "omni_plan_run", "omni_plan_capture", "omni_plan_replay",
     "omni_plan_num_ops", "omni_plan_destroy", "omni_resample_coeffs", "omni_plan_time", "omni_debug_tile_map",
-    "omni_debug_host_op", "omni_plan_profile",
+    "omni_plan_profile",
     "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
     "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
 ]
@@ -94,8 +95,6 @@ def bind(path):
     L.omni_debug_tile_map.argtypes = [c_int, c_int, c_int, ctypes.c_longlong, c_int, POINTER(c_int), POINTER(c_int), POINTER(c_int),
                                       POINTER(c_int)]
     L.omni_debug_tile_map.restype = c_int
-    L.omni_debug_host_op.argtypes = [POINTER(OmniOp), c_int]
-    L.omni_debug_host_op.restype = c_int
     c_ll = ctypes.c_longlong
     for name in ("omni_model_load", "omni_detector_create", "omni_captioner_create"):
         fn = getattr(L, name)
@@ -113,8 +112,8 @@ def bind(path):
     L.omni_detector_infer.restype = c_int
     L.omni_captioner_caption.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_int, POINTER(c_int32)]
     L.omni_captioner_caption.restype = c_int
-    if L.omni_abi_version() != 1:
-        raise OmniError(f"ABI version mismatch: {L.omni_abi_version()}")
+    if L.omni_abi_version() != ABI_VERSION:
+        raise OmniError(f"ABI version mismatch: library {L.omni_abi_version()}, host code {ABI_VERSION} (rebuild: python -m omniparser_amd.build)")
     return L
 
 
@@ -270,11 +269,6 @@ def tile_map(mtiles: int, ntiles: int, bid: int, xcd_n: int = 1, weight_bytes: i
     check(lib().omni_debug_tile_map(mtiles, ntiles, xcd_n, weight_bytes, bid, ctypes.byref(mt), ctypes.byref(nt), ctypes.byref(grid),
                                     ctypes.byref(used)))
     return mt.value, nt.value, grid.value, used.value
-
-
-def host_op(op, variant: int = 1):
-    """Run the host emulation of `op` (host pointers!) — the same per-thread source the GPU kernel runs."""
-    check(lib().omni_debug_host_op(ctypes.byref(op), variant))
 
 
 class CModel:

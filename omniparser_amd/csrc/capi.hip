@@ -66,15 +66,13 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
 // runs off the segment is caught, a neighbour inside the same segment is not).  Ranges are computed for the op kinds that hold
 // almost all of a plan's launches (conv / GEMM family, pools, LayerNorm, depthwise conv, split-convert, fused FFN); for the
 // other kinds the first byte is checked.  On by default wherever a device is present — omni_op_launch (the single-op path is
-// never hot) and omni_plan_create (once per plan) — OMNI_CHECK_PTRS=0 turns it off, the host emulation has no device pointers.
-#ifndef OMNI_HOST_EMU
+// never hot) and omni_plan_create (once per plan) — OMNI_CHECK_PTRS=0 turns it off; without a device there is nothing to check against.
 static bool check_ptrs_enabled() {
   const char* e = getenv("OMNI_CHECK_PTRS");
   if (e && e[0] == '0') return false;
-  static int ndev = -1;
-  if (ndev < 0) { int n = 0; ndev = (hipGetDeviceCount(&n) == hipSuccess) ? n : 0; }
-  if (ndev <= 0) { (void)hipGetLastError(); return false; }
-  return true;
+  // initialised once, thread-safely (omni_op_launch is entered from web-server workers and pipeline helper threads)
+  static const int ndev = [] { int n = 0; const bool ok = hipGetDeviceCount(&n) == hipSuccess; if (!ok) (void)hipGetLastError(); return ok ? n : 0; }();
+  return ndev > 0;
 }
 
 static void op_extents(const omni_op_t* op, long long ext[8]) {
@@ -151,10 +149,6 @@ static int check_op_ptrs(const omni_op_t* op, int index) {
   }
   return OMNI_OK;
 }
-#else
-static bool check_ptrs_enabled() { return false; }
-static int check_op_ptrs(const omni_op_t*, int) { return OMNI_OK; }
-#endif
 
 extern "C" int omni_op_launch(const omni_op_t* op, void* stream) {
   if (!op) { omni_set_error("omni_op_launch: null op"); return OMNI_E_ARG; }

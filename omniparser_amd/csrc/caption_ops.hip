@@ -40,9 +40,8 @@ __device__ __forceinline__ float wave_max(float v) {
 // ------------------------------------------------------------------------------------ dwconv3
 struct DwArgs { const void* x; const void* w; const float* bias; void* y; int B, H, W, C; long long total; };
 
-// Per-output body of the original kernel (one 16-byte channel vector of one pixel); host-callable so the CPU
-// suite can run the very same code (omni_debug_host_op).  Kept as the fallback for channel counts whose vector
-// count per pixel is not a power of two, and as the bit-exact reference of the strip kernel below.
+// Per-output body of the original kernel (one 16-byte channel vector of one pixel).  Kept as the fallback for channel counts whose
+// vector count per pixel is not a power of two, and as the bit-exact reference of the strip kernel below.
 template <typename T>
 __host__ __device__ __forceinline__ void dwconv3_point_body(const DwArgs& a, long long idx) {
   constexpr int V = ElemTraits<T>::kVec;
@@ -2259,37 +2258,4 @@ int omni_launch_misc(const omni_op_t* op, hipStream_t s) {
     case OMNI_OP_PROJ_PREP: case OMNI_OP_ASSEMBLE: case OMNI_OP_EMBED_STEP: return launch_glue(op, s);
     default: omni_set_error("misc: bad kind %d", op->kind); return OMNI_E_ARG;
   }
-}
-
-// ---------------------------------------------------------------------------------------------------------
-// Host emulation of kernels whose per-thread bodies are plain __host__ __device__ code (no LDS, no cross-lane ops):
-// the CPU test-suite runs the SAME source the GPU runs, block by block, on host pointers.  Test infrastructure
-// only — never reached from omni_op_launch / plans.   variant: 0 = round-1 point kernel, 1 = strip kernel.
-extern "C" int omni_debug_host_op(const omni_op_t* op, int variant) {
-  if (!op) { omni_set_error("debug_host_op: null op"); return OMNI_E_ARG; }
-  if (op->kind != OMNI_OP_DWCONV3) { omni_set_error("debug_host_op: kind %d has no host emulation", op->kind); return OMNI_E_ARG; }
-  DwArgs a{};
-  a.x = op->p[0]; a.w = op->p[1]; a.bias = (const float*)op->p[2]; a.y = op->p[4];
-  a.B = op->i[0]; a.H = op->i[1]; a.W = op->i[2]; a.C = op->i[3];
-  OMNI_REQUIRE(a.x && a.w && a.bias && a.y && a.B > 0 && a.H > 0 && a.W > 0 && a.C > 0, "dwconv3: bad arguments");
-  OMNI_REQUIRE(op->dtype == OMNI_F32 || op->dtype == OMNI_F16, "dwconv3: bad dtype");
-  const int V = op->dtype == OMNI_F32 ? 4 : 8;
-  OMNI_REQUIRE(a.C % V == 0, "dwconv3: C must be a multiple of the 16-byte vector width");
-  a.total = (long long)a.B * a.H * a.W * a.C;
-  if (variant == 0) {
-    for (long long idx = 0; idx < a.total / V; ++idx) {
-      if (op->dtype == OMNI_F32) dwconv3_point_body<float>(a, idx); else dwconv3_point_body<half_t>(a, idx);
-    }
-    return OMNI_OK;
-  }
-  const DwStripGrid g = dwconv3_strip_grid(a, V);
-  OMNI_REQUIRE(g.ok, "dwconv3 strip kernel does not apply to C = %d", a.C);
-  for (unsigned bz = 0; bz < g.gz; ++bz)
-    for (unsigned by = 0; by < g.gy; ++by)
-      for (unsigned bx = 0; bx < g.gx; ++bx)
-        for (unsigned t = 0; t < 256; ++t) {
-          if (op->dtype == OMNI_F32) dwconv3_strip_body<float>(a, (int)bz, (int)by * DW_ROWS, bx * 256u + t, g.cv_log2);
-          else dwconv3_strip_body<half_t>(a, (int)bz, (int)by * DW_ROWS, bx * 256u + t, g.cv_log2);
-        }
-  return OMNI_OK;
 }

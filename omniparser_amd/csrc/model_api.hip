@@ -195,9 +195,6 @@ extern "C" int omni_model_load(const char* path, omni_model_t** out) {
   }
   const char* g = getenv("OMNI_HIPGRAPH");
   m->graphs = !(g && atoi(g) == 0);
-#ifdef OMNI_HOST_EMU
-  m->graphs = false;
-#endif
   if (m->graphs) {
     for (auto& kv : m->plans) {
       rc = omni_plan_run(kv.second, m->stream);                     // warm-up (module load) outside capture

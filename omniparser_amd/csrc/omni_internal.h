@@ -32,9 +32,7 @@ void omni_set_error(const char* fmt, ...);
 #endif
 
 // this wave's LDS reads have returned (placed in front of a barrier that releases the buffer they read to other waves' LDS-DMA)
-#ifdef OMNI_HOST_EMU
-#define OMNI_WAIT_LGKM0() ((void)0)
-#else
+#ifndef OMNI_WAIT_LGKM0
 #define OMNI_WAIT_LGKM0() asm volatile("s_waitcnt lgkmcnt(0)" ::: "memory")
 #endif
 
@@ -44,10 +42,8 @@ void omni_set_error(const char* fmt, ...);
 #endif
 
 // lanes of ONE wave exchange data through LDS (write, OMNI_WAVE_SYNC, read): the hardware executes a wave's LDS instructions in
-// order, so only the compiler must be kept from reordering; the host emulation (work-items are fibers) needs a real rendezvous
-#ifdef OMNI_HOST_EMU
-#define OMNI_WAVE_SYNC() ((void)__shfl(0, 0))
-#else
+// order, so only the compiler must be kept from reordering (a build that runs work-items as fibers defines its own rendezvous)
+#ifndef OMNI_WAVE_SYNC
 #define OMNI_WAVE_SYNC() __builtin_amdgcn_wave_barrier()
 #endif
 

@@ -617,7 +617,7 @@ class Florence2Captioner:
     reuse_activations = True  # scratch tensors of a DaViT stage are released at its end and back the tensors of the later stages
                               # (PlanBuilder.release): same kernels, same order, different addresses — a rank's plan sets hold 89 GB
                               # instead of 176 GB of HBM at the same speed (profiles/r4_s2_candidates_ab.txt).  With it `stage_out[:3]` are
-                              # no longer valid after the encode plan: the bisection taps (tools/r3_bisect.py) turn it off
+                              # no longer valid after the encode plan: the bisection taps (tools/archive/r3_bisect.py) turn it off
 
     def __init__(self, model_dir, device=None, precision: Optional[str] = None, resolution: Optional[int] = None):
         device = L.require_device(device, "Florence2Captioner")

@@ -30,7 +30,6 @@
 #include <type_traits>
 #include <vector>
 
-#define OMNI_HOST_EMU 1
 #define __HIP_DEVICE_COMPILE__ 1
 #define __global__
 #define __device__
@@ -284,6 +283,8 @@ void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
 #define OMNI_WAIT_VMCNT(n) emu::wait_vmcnt(n)
+#define OMNI_WAIT_LGKM0() ((void)0)                  // LDS reads are synchronous here
+#define OMNI_WAVE_SYNC() ((void)__shfl(0, 0))        // work-items are fibers: lanes of a wave need a real rendezvous
 #define OMNI_DYN_LDS(type, name) type* name = reinterpret_cast<type*>(emu::blk->dyn_lds)
 
 template <class A, class B> inline auto min(A a, B b) { using T = std::common_type_t<A, B>; return (T)a < (T)b ? (T)a : (T)b; }
@@ -431,7 +432,9 @@ enum { hipSuccess = 0, hipErrorNotSupported = 801 };
 enum { hipStreamCaptureModeThreadLocal = 1 };
 inline const char* hipGetErrorString(hipError_t e) { return e == hipSuccess ? "success" : "not supported by the host emulation"; }
 inline hipError_t hipGetLastError() { return hipSuccess; }
-inline hipError_t hipGetDeviceCount(int* n) { *n = 0; return hipSuccess; }
+inline hipError_t hipGetDeviceCount(int* n) { *n = 0; return hipSuccess; }       // no device: capi.hip's pointer check stays off
+typedef void* hipDeviceptr_t;
+inline hipError_t hipMemGetAddressRange(hipDeviceptr_t* base, size_t* size, hipDeviceptr_t) { *base = nullptr; *size = 0; return hipErrorNotSupported; }
 inline hipError_t hipStreamSynchronize(hipStream_t) { return hipSuccess; }
 inline hipError_t hipMemsetAsync(void* p, int v, size_t n, hipStream_t) { std::memset(p, v, n); return hipSuccess; }
 // model_api.hip: device memory is host memory here

@@ -143,3 +143,26 @@ def test_kernel_checks_also_pass_in_reverse_work_item_order():
                        env=env, capture_output=True, text=True, cwd=str(here.parent))
     assert r.returncode == 0, r.stdout[-3000:] + r.stderr[-1000:]
     assert " passed" in r.stdout and "failed" not in r.stdout
+
+
+def test_dwconv3_strip_and_point_kernels_equal_torch(emu):
+    """x + depthwise_conv3x3(x) + bias from the device sources: the strip kernel serves power-of-two vector counts per pixel (every
+    DaViT stage), the point kernel the rest; shapes cover H % 4 != 0, one-row / one-column images, rows shorter than a block, several
+    row chunks per row, f32 and f16.  (Until round 4 a debug entry point of the SHIPPING library ran these bodies on the host; the
+    emulation build runs the kernels themselves.)"""
+    import torch
+    import torch.nn.functional as Fn
+    g = torch.Generator().manual_seed(11)
+    for dtype, tdt, V, tol in ((L.F32, torch.float32, 4, 2e-5), (L.F16, torch.float16, 8, 1e-2)):
+        for (B, H, W, C) in [(2, 12, 12, 128), (1, 7, 5, 256), (3, 1, 9, 64), (1, 9, 1, 32), (2, 6, 50, 64), (1, 5, 3, 1024), (1, 4, 4, 96),
+                             (1, 13, 11, 8 * V // 4)]:
+            x = torch.randn(B, H, W, C, generator=g).to(tdt).contiguous()
+            w = (torch.randn(3, 3, C, generator=g) * 0.3).to(tdt).contiguous()
+            bias = torch.randn(C, generator=g).contiguous()
+            y = torch.full_like(x, float("nan"))
+            op = L.make_op(L.OP_DWCONV3, dtype, p=[x.data_ptr(), w.data_ptr(), bias.data_ptr(), None, y.data_ptr()], i={0: B, 1: H, 2: W, 3: C})
+            L.launch(op, 0)
+            assert not torch.isnan(y.float()).any(), (B, H, W, C)                   # every output written
+            ref = x.float() + Fn.conv2d(x.float().permute(0, 3, 1, 2), w.float().permute(2, 0, 1).unsqueeze(1), bias, padding=1,
+                                        groups=C).permute(0, 2, 3, 1)
+            assert (y.float() - ref).abs().max().item() <= tol * max(1.0, ref.abs().max().item()), (B, H, W, C, dtype)

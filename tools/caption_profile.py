@@ -12,34 +12,12 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
-def op_shape(op):
-    i, k = op.i, op.kind
-    if k in (1, 19):
-        return (i[0] * max(i[10], 1) * max(i[11], 1) if k == 1 else i[0] * max(i[1], 1), i[12] if k == 1 else i[3], i[6] * i[7] * i[3] if k == 1 else 0)
-    if k in (8, 18):
-        return (i[0] * i[1] * i[2], i[3], 0)
-    if k == 9:
-        return (i[0] * max(i[1], 1), i[3], i[6])
-    if k == 10:
-        return (i[11] * i[9], i[8] * i[15], i[12])
-    if k == 11:
-        return (i[0] * i[1], i[3], 0)
-    if k == 15:
-        return (i[10], i[9], i[7] if i[7] > 0 else i[8])
-    return (i[0], i[3], 0)
-
-
 def main():
     import torch
     from omniparser_amd import _lib as L
     from omniparser_amd.florence import Florence2Captioner
     from tools.make_weights import caption_dir, ensure_via_subprocess
-    split_env = os.environ.get("OMNI_CONV_SPLIT")
-    from tools.plan_table import NAMES, op_work          # (its import sets OMNI_CONV_SPLIT=0 for CPU-only plan tables: undo that)
-    if split_env is None:
-        os.environ.pop("OMNI_CONV_SPLIT", None)
-    else:
-        os.environ["OMNI_CONV_SPLIT"] = split_env
+    from omniparser_amd.opwork import op_kernel, op_shape, op_work
     B = int(sys.argv[1]) if len(sys.argv) > 1 else 128
     R = int(sys.argv[2]) if len(sys.argv) > 2 else 768
     rep = int(sys.argv[3]) if len(sys.argv) > 3 else 2
@@ -77,10 +55,7 @@ def main():
         agg = {}
         for op, t in zip(plan.ops, ms):
             f, b = op_work(op)
-            name = NAMES.get(op.kind, {19: "split_convert", 16: "greedy_step"}.get(op.kind, str(op.kind)))
-            if op.kind == 1:
-                name = "gemm_dma" if op.i[20] == 2 else ("conv_split" if op.i[20] else "conv_igemm")
-            key = (name, op_shape(op))
+            key = (op_kernel(op), op_shape(op))
             a = agg.setdefault(key, [0, 0.0, 0.0, 0.0])
             a[0] += 1; a[1] += t; a[2] += f; a[3] += b
         rows = [{"kernel": k[0], "shape": list(k[1]), "n": a[0], "ms": round(a[1], 3), "GBps": round(a[3] / max(a[1], 1e-9) / 1e6, 1),

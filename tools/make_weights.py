@@ -162,7 +162,7 @@ def build_random_captioner(seed=0, init_std=0.06, chan_qk_scale=CHAN_QK_SCALE):
 
 
 def ensure_caption_checkpoint(seed=0, standin=CAPTION_STANDIN):
-    """standin="v1": the round-1/2 stand-in (no channel-attention scale) — kept only so that tools/r3_bisect.py can show what
+    """standin="v1": the round-1/2 stand-in (no channel-attention scale) — kept only so that tools/archive/r3_bisect.py can show what
     it does to the f32 arithmetic on real crops."""
     import json
     from safetensors.torch import save_file
