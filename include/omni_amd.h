@@ -106,7 +106,10 @@ enum {
    * (ref:util/yolov9.py:131) + [:max_det] + clamp (:134-135).
    *  p0 cand p1 count p2 sorted cand scratch (cap) p3 mask scratch u64[cap*ceil(cap/64)]
    *  p4 out boxes f32[max_det,4] p5 out scores f32[max_det] p6 out cls i32[max_det] p7 out count i32[1]
-   *  i0 cap i1 max_det i2 img_w i3 img_h ; f0 iou */
+   *  i0 cap i1 max_det i2 img_w i3 img_h ; f0 iou
+   *  i4 frames (0 = 1): frame f reads cand + f*cap records, count[f], sorted + f*(cap+1) records, writes out_* + f*max_det, out_count[f]
+   *  (the mask scratch is shared: frames that need it run one after another); i5 = 1: force the tiled kernels (tests).
+   *  Frames with <= 2048 candidates are sorted and suppressed by one workgroup out of LDS; the result is the same list either way. */
   OMNI_OP_NMS = 7,
   /* x + depthwise3x3(x) + bias (DaViT conv1/conv2, hf:models/florence2/modeling_florence2.py:432-436).
    *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p4 y; i0 B i1 H i2 W i3 C */

@@ -12,11 +12,16 @@
 // blob (SURVEY App. B head); here it is fused into the decode so the 64-channel box logits are read
 // from HBM exactly once.
 //
-// wave64 notes: compaction uses one atomic per passing anchor (few % of anchors pass); ordering is
-// restored by an O(N^2) rank kernel keyed on (score desc, anchor asc) == torch's stable descending
-// sort; the IoU predicate is evaluated in 64x64 tiles into 64-bit masks (one u64 per lane = one row),
-// and the serial greedy pass resolves a 64-box block entirely in registers with v_readlane before
-// OR-ing the kept rows' masks into the LDS-resident suppression vector.
+// wave64 notes: compaction uses one atomic per passing anchor (few % of anchors pass).
+// NMS, up to 2048 candidates per frame (every 640x640 input: ~1 400): ONE 1024-thread workgroup per frame (round 5,
+// nms_block_kernel) — bitonic sort of 64-bit keys (score desc, anchor asc == torch's stable descending sort) in LDS, the
+// candidates' offset boxes in LDS, then per 64-box block: wave 0 builds the block's 64x64 IoU mask in registers, resolves it
+// greedily with v_readlane, and all 16 waves apply the block's kept boxes to every later candidate; it stops at max_det keeps.
+// No N x N mask in HBM, no O(N^2) rank pass, no serial chain of dependent global loads (the round-1 path cost 547 us per frame).
+// NMS, more candidates (1088x1920 inputs: ~9 000): the round-1 path — O(N^2) rank kernel, IoU predicate in 64x64 tiles into
+// 64-bit masks (one u64 per lane = one row), single-wave greedy pass that resolves a 64-box block in registers with
+// v_readlane and ORs the kept rows' masks into an LDS-resident suppression vector.  Both paths evaluate the SAME f32
+// expressions in the same operand order, so their keep lists are bit-identical (tests: known answers + random clouds on both).
 #include "omni_internal.h"
 
 #pragma clang fp contract(off)
@@ -106,7 +111,11 @@ struct NmsArgs {
   float* meta;   // [0] = max coordinate, [1] = use_trick flag (as float bits), lives after sorted[]
   int cap, max_det, img_w, img_h;
   float iou;
+  int frames;      // nms_block_kernel: one workgroup per frame; frame f's buffers = base + f * (cap | cap + 1 | max_det | 1) records
 };
+
+constexpr int NMS_FAST_N = 2048;          // candidates the single-workgroup path holds in LDS
+constexpr int NMS_FAST_ANCHOR_BITS = 21;  // key = ~score bits (32) | anchor (21) | slot (11)
 
 __device__ __forceinline__ int clamp_count(const int* count, int cap) {
   int n = *count;
@@ -114,10 +123,11 @@ __device__ __forceinline__ int clamp_count(const int* count, int cap) {
 }
 
 // rank sort: sorted[rank(i)] = cand[i], key = (score desc, anchor asc)
-__global__ __launch_bounds__(256) void rank_kernel(NmsArgs a) {
+__global__ __launch_bounds__(256) void rank_kernel(NmsArgs a, int fast) {
   __shared__ float s_score[256];
   __shared__ int s_anchor[256];
   const int n = clamp_count(a.count, a.cap);
+  if (fast && n <= NMS_FAST_N) return;          // nms_block_kernel took this frame
   for (int base = blockIdx.x * 256; base < n; base += gridDim.x * 256) {
     int i = base + threadIdx.x;
     Cand me;
@@ -140,9 +150,10 @@ __global__ __launch_bounds__(256) void rank_kernel(NmsArgs a) {
 }
 
 // max coordinate + dispatch flag of torchvision.ops.batched_nms (CPU thresholds)
-__global__ __launch_bounds__(256) void nms_prep_kernel(NmsArgs a) {
+__global__ __launch_bounds__(256) void nms_prep_kernel(NmsArgs a, int fast) {
   __shared__ float s_max[256];
   const int n = clamp_count(a.count, a.cap);
+  if (fast && n <= NMS_FAST_N) return;
   float m = -INFINITY;
   for (int i = threadIdx.x; i < n; i += 256) {
     Cand c = a.cand[i];
@@ -160,10 +171,11 @@ __global__ __launch_bounds__(256) void nms_prep_kernel(NmsArgs a) {
   }
 }
 
-__global__ __launch_bounds__(64) void mask_kernel(NmsArgs a) {
+__global__ __launch_bounds__(64) void mask_kernel(NmsArgs a, int fast) {
   __shared__ float sx1[64], sy1[64], sx2[64], sy2[64], sar[64];
   __shared__ int scl[64];
   const int n = clamp_count(a.count, a.cap);
+  if (fast && n <= NMS_FAST_N) return;
   const int nblk = (n + 63) >> 6;
   const bool trick = a.meta[1] != 0.0f;
   const float off1 = a.meta[0] + 1.0f;   // max_coordinate + 1
@@ -220,9 +232,10 @@ __device__ __forceinline__ unsigned long long readlane64(unsigned long long v, i
 }
 
 // single wave: greedy pass over score-ordered boxes
-__global__ __launch_bounds__(64) void reduce_kernel(NmsArgs a, int max_words) {
+__global__ __launch_bounds__(64) void reduce_kernel(NmsArgs a, int max_words, int fast) {
   OMNI_DYN_LDS(__attribute__((aligned(16))) unsigned long long, remv);
   const int n = clamp_count(a.count, a.cap);
+  if (fast && n <= NMS_FAST_N) return;
   const int nblk = (n + 63) >> 6;
   const int lane = threadIdx.x;
   for (int w = lane; w < nblk && w < max_words; w += 64) remv[w] = 0ull;
@@ -269,6 +282,164 @@ __global__ __launch_bounds__(64) void reduce_kernel(NmsArgs a, int max_words) {
   if (lane == 0) *a.out_count = kept_total < a.max_det ? kept_total : a.max_det;
 }
 
+// ---------------------------------------------------------------------------------------------
+// One workgroup per frame: sort + greedy NMS of up to NMS_FAST_N candidates without leaving the CU.
+__device__ __forceinline__ unsigned f32_bits(float v) { unsigned u; __builtin_memcpy(&u, &v, 4); return u; }
+
+__device__ __forceinline__ unsigned long long or_reduce_wave(unsigned long long v) {
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) {
+    unsigned lo = __shfl_xor((unsigned)(v & 0xffffffffull), o);
+    unsigned hi = __shfl_xor((unsigned)(v >> 32), o);
+    v |= ((unsigned long long)hi << 32) | lo;
+  }
+  return v;
+}
+
+__global__ __launch_bounds__(1024) void nms_block_kernel(NmsArgs a) {
+  __shared__ unsigned long long key[NMS_FAST_N];           // 16 KB   sort keys; afterwards: sorted position -> (score bits, slot)
+  __shared__ float bx1[NMS_FAST_N], by1[NMS_FAST_N], bx2[NMS_FAST_N], by2[NMS_FAST_N], bar[NMS_FAST_N];   // 40 KB offset boxes, areas
+  __shared__ short bcl[NMS_FAST_N];                        // 4 KB    class ids
+  __shared__ unsigned char dead[NMS_FAST_N];               // 2 KB    suppressed flags (one owner thread per candidate: plain stores)
+  __shared__ float red[16];
+  __shared__ unsigned long long s_kept;
+  __shared__ int s_total;
+  const int f = blockIdx.x;
+  const Cand* cand = a.cand + (long long)f * a.cap;
+  Cand* sorted = a.sorted + (long long)f * (a.cap + 1);
+  const int n = clamp_count(a.count + f, a.cap);
+  if (n > NMS_FAST_N) return;                               // the tiled path (rank / mask / reduce kernels) handles this frame
+  const int tid = threadIdx.x, lane = tid & 63, wave = tid >> 6;
+  float* out_boxes = a.out_boxes + (long long)f * a.max_det * 4;
+  float* out_scores = a.out_scores + (long long)f * a.max_det;
+  int* out_cls = a.out_cls + (long long)f * a.max_det;
+  if (n == 0) { if (tid == 0) a.out_count[f] = 0; return; }
+  // ---- keys + max coordinate (torchvision.ops.batched_nms: offsets = idxs * (boxes.max() + 1) when numel <= 4000)
+  int N = 64; while (N < n) N <<= 1;
+  float m = -INFINITY;
+  for (int i = tid; i < N; i += 1024) {
+    unsigned long long k = ~0ull;
+    if (i < n) {
+      Cand c = cand[i];
+      m = fmaxf(m, fmaxf(fmaxf(c.x1, c.y1), fmaxf(c.x2, c.y2)));
+      k = ((unsigned long long)(~f32_bits(c.score)) << 32) | ((unsigned long long)(unsigned)c.anchor << 11) | (unsigned)i;
+    }
+    key[i] = k;
+    dead[i] = 0;
+  }
+#pragma unroll
+  for (int o = 32; o > 0; o >>= 1) m = fmaxf(m, __shfl_xor(m, o));
+  if (lane == 0) red[wave] = m;
+  __syncthreads();
+  float mx = red[0];
+#pragma unroll
+  for (int w = 1; w < 16; ++w) mx = fmaxf(mx, red[w]);
+  const bool trick = 4ll * n <= 4000;
+  const float off1 = mx + 1.0f;
+  // ---- bitonic sort, ascending keys = score descending, then anchor ascending (scores are positive: their bit patterns order them)
+  for (int k2 = 2; k2 <= N; k2 <<= 1) {
+    for (int j = k2 >> 1; j > 0; j >>= 1) {
+      for (int t = tid; t < (N >> 1); t += 1024) {
+        int lo = ((t & ~(j - 1)) << 1) | (t & (j - 1));
+        int hi = lo | j;
+        unsigned long long x = key[lo], y = key[hi];
+        bool up = (lo & k2) == 0;
+        if ((x > y) == up) { key[lo] = y; key[hi] = x; }
+      }
+      __syncthreads();
+    }
+  }
+  // ---- sorted records -> LDS (offset boxes exactly as the tiled path computes them) and the sorted scratch
+  for (int i = tid; i < n; i += 1024) {
+    Cand c = cand[(int)(key[i] & 2047ull)];
+    float o = trick ? (float)c.cls * off1 : 0.0f;
+    float x1 = trick ? c.x1 + o : c.x1, y1 = trick ? c.y1 + o : c.y1;
+    float x2 = trick ? c.x2 + o : c.x2, y2 = trick ? c.y2 + o : c.y2;
+    bx1[i] = x1; by1[i] = y1; bx2[i] = x2; by2[i] = y2;
+    bar[i] = (x2 - x1) * (y2 - y1);
+    bcl[i] = (short)c.cls;
+    sorted[i] = c;
+  }
+  if (tid == 0) s_total = 0;
+  __syncthreads();
+  const int nblk = (n + 63) >> 6;
+  const float thr = a.iou;
+  for (int blk = 0; blk < nblk; ++blk) {
+    if (wave == 0) {
+      const int i = blk * 64 + lane;
+      const int valid = n - blk * 64 < 64 ? n - blk * 64 : 64;
+      // this block's 64x64 mask: lane = row (the earlier, possibly kept box), bit q = a later box of the block it would suppress
+      unsigned long long bits = 0ull;
+      if (i < n) {
+        const float ix1 = bx1[i], iy1 = by1[i], ix2 = bx2[i], iy2 = by2[i], iarea = bar[i];
+        const int icl = bcl[i];
+        for (int q = lane + 1; q < valid; ++q) {
+          const int j = blk * 64 + q;
+          if (!trick && bcl[j] != icl) continue;
+          float xx1 = fmaxf(ix1, bx1[j]);
+          float yy1 = fmaxf(iy1, by1[j]);
+          float xx2 = fminf(ix2, bx2[j]);
+          float yy2 = fminf(iy2, by2[j]);
+          float w = fmaxf(0.0f, xx2 - xx1);
+          float h = fmaxf(0.0f, yy2 - yy1);
+          float inter = w * h;
+          float ovr = inter / (iarea + bar[j] - inter);
+          if (ovr > thr) bits |= (1ull << q);
+        }
+      }
+      const int total = s_total;                              // read by every lane BEFORE the wave-collective steps below; lane 0 updates it after them
+      unsigned long long cur = or_reduce_wave((i < n && dead[i]) ? (1ull << lane) : 0ull);
+      unsigned long long keptbits = 0ull;
+      for (int t = 0; t < valid; ++t) {
+        unsigned long long row = readlane64(bits, t);
+        if (!((cur >> t) & 1ull)) { keptbits |= (1ull << t); cur |= row; }
+      }
+      const bool mine = (keptbits >> lane) & 1ull;
+      const int oidx = total + __popcll(keptbits & ((1ull << lane) - 1ull));
+      if (mine && oidx < a.max_det) {
+        Cand c = sorted[i];                                   // written by this workgroup above (same wave order: visible after the barrier)
+        float fw = (float)a.img_w, fh = (float)a.img_h;
+        out_boxes[oidx * 4 + 0] = fminf(fmaxf(c.x1, 0.0f), fw);
+        out_boxes[oidx * 4 + 1] = fminf(fmaxf(c.y1, 0.0f), fh);
+        out_boxes[oidx * 4 + 2] = fminf(fmaxf(c.x2, 0.0f), fw);
+        out_boxes[oidx * 4 + 3] = fminf(fmaxf(c.y2, 0.0f), fh);
+        out_scores[oidx] = c.score;
+        out_cls[oidx] = c.cls;
+      }
+      if (lane == 0) { s_kept = keptbits; s_total = total + __popcll(keptbits); }
+    }
+    __syncthreads();
+    if (s_total >= a.max_det) break;                          // the first max_det keeps are final: nothing later can change them
+    // every later candidate against this block's kept boxes (the kept box is the ROW operand, as in the mask above)
+    const unsigned long long kept = s_kept;
+    if (kept) {
+      for (int j = (blk + 1) * 64 + tid; j < n; j += 1024) {
+        if (dead[j]) continue;
+        const float jx1 = bx1[j], jy1 = by1[j], jx2 = bx2[j], jy2 = by2[j], jarea = bar[j];
+        const int jcl = bcl[j];
+        unsigned long long kb = kept;
+        while (kb) {
+          const int t = __ffsll((long long)kb) - 1;
+          kb &= kb - 1;
+          const int i = blk * 64 + t;
+          if (!trick && bcl[i] != jcl) continue;
+          float xx1 = fmaxf(bx1[i], jx1);
+          float yy1 = fmaxf(by1[i], jy1);
+          float xx2 = fminf(bx2[i], jx2);
+          float yy2 = fminf(by2[i], jy2);
+          float w = fmaxf(0.0f, xx2 - xx1);
+          float h = fmaxf(0.0f, yy2 - yy1);
+          float inter = w * h;
+          float ovr = inter / (bar[i] + jarea - inter);
+          if (ovr > thr) { dead[j] = 1; break; }
+        }
+      }
+    }
+    __syncthreads();
+  }
+  if (tid == 0) a.out_count[f] = s_total < a.max_det ? s_total : a.max_det;
+}
+
 __global__ void zero_count_kernel(int* count) { if (threadIdx.x == 0) *count = 0; }
 
 }  // namespace
@@ -313,20 +484,34 @@ int omni_launch_nms(const omni_op_t* op, hipStream_t s) {
   a.out_cls = (int*)op->p[6]; a.out_count = (int*)op->p[7];
   a.cap = op->i[0]; a.max_det = op->i[1]; a.img_w = op->i[2]; a.img_h = op->i[3];
   a.iou = op->f[0];
+  a.frames = op->i[4] > 0 ? op->i[4] : 1;
   OMNI_REQUIRE(a.cand && a.count && a.sorted && a.mask && a.out_boxes && a.out_scores && a.out_cls && a.out_count,
                "nms: null pointer");
   OMNI_REQUIRE(a.cap > 0 && a.max_det > 0, "nms: bad cap/max_det");
-  // sorted scratch holds cap records + 1 spare record used for {max_coord, trick flag}
-  a.meta = reinterpret_cast<float*>(a.sorted + a.cap);
   int max_words = (a.cap + 63) / 64;
   OMNI_REQUIRE((size_t)max_words * 8 <= 160 * 1024, "nms: cap too large for the LDS suppression vector");
-  int rank_blocks = (a.cap + 255) / 256; if (rank_blocks > 1024) rank_blocks = 1024;
-  hipLaunchKernelGGL(nms_prep_kernel, dim3(1), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(rank_kernel, dim3(rank_blocks), dim3(256), 0, s, a);
-  long long pairs = (long long)max_words * max_words;
-  int mask_blocks = pairs < 4096 ? (int)pairs : 4096;
-  hipLaunchKernelGGL(mask_kernel, dim3(mask_blocks), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), (size_t)max_words * 8, s, a, max_words);
+  // up to NMS_FAST_N candidates: one workgroup per frame does everything (sort, masks, greedy pass) out of LDS.  The candidate count is
+  // known on the device only, so the tiled kernels are launched as well and return at once for the frames the fast kernel took (and
+  // the fast kernel returns for the frames it cannot hold): an empty launch inside a graph costs ~2 us, a host round trip ~20.
+  const int fast = (a.cap < (1 << NMS_FAST_ANCHOR_BITS)) && op->i[5] != 1 ? 1 : 0;          // i5 = 1: force the tiled path (tests)
+  if (fast) hipLaunchKernelGGL(nms_block_kernel, dim3(a.frames), dim3(1024), 0, s, a);
+  if (a.cap > NMS_FAST_N || !fast) {
+    for (int f = 0; f < a.frames; ++f) {
+      NmsArgs b = a;
+      b.cand = a.cand + (long long)f * a.cap; b.count = a.count + f; b.sorted = a.sorted + (long long)f * (a.cap + 1);
+      b.out_boxes = a.out_boxes + (long long)f * a.max_det * 4; b.out_scores = a.out_scores + (long long)f * a.max_det;
+      b.out_cls = a.out_cls + (long long)f * a.max_det; b.out_count = a.out_count + f;
+      // sorted scratch holds cap records + 1 spare record used for {max_coord, trick flag}
+      b.meta = reinterpret_cast<float*>(b.sorted + b.cap);
+      int rank_blocks = (b.cap + 255) / 256; if (rank_blocks > 1024) rank_blocks = 1024;
+      hipLaunchKernelGGL(nms_prep_kernel, dim3(1), dim3(256), 0, s, b, fast);
+      hipLaunchKernelGGL(rank_kernel, dim3(rank_blocks), dim3(256), 0, s, b, fast);
+      long long pairs = (long long)max_words * max_words;
+      int mask_blocks = pairs < 4096 ? (int)pairs : 4096;
+      hipLaunchKernelGGL(mask_kernel, dim3(mask_blocks), dim3(64), 0, s, b, fast);
+      hipLaunchKernelGGL(reduce_kernel, dim3(1), dim3(64), (size_t)max_words * 8, s, b, max_words, fast);
+    }
+  }
   OMNI_HIP_CHECK(hipGetLastError());
   return OMNI_OK;
 }

@@ -115,12 +115,14 @@ class _DetectPlan:
                    10: pad_left, 11: pad_top, 12: 0, 13: coffc[0], 14: coffc[1], 15: coffc[2],
                    16: coffb[0], 17: coffb[1], 18: coffb[2], 19: bi},
                 f={0: conf, 1: scale}))
-            pb.add_op(L.make_op(
-                L.OP_NMS, det.dtype,
-                p=[self.cand[bi].data_ptr(), self.count[bi:].data_ptr(), self.sorted[bi].data_ptr(),
-                   self.mask.data_ptr(), self.out_boxes[bi].data_ptr(), self.out_scores[bi].data_ptr(),
-                   self.out_cls[bi].data_ptr(), self.out_count[bi:].data_ptr()],
-                i={0: A, 1: max_det, 2: iw, 3: ih}, f={0: iou}))
+        # ONE NMS op for the whole batch (frames are contiguous in every buffer): up to 2048 candidates per frame — every 640x640 input —
+        # one workgroup per frame sorts and suppresses out of LDS, all frames of the batch at once; frames with more candidates
+        # (1088x1920 inputs) fall to the tiled kernels inside the same op, one after another over the shared mask scratch
+        pb.add_op(L.make_op(
+            L.OP_NMS, det.dtype,
+            p=[self.cand.data_ptr(), self.count.data_ptr(), self.sorted.data_ptr(), self.mask.data_ptr(), self.out_boxes.data_ptr(),
+               self.out_scores.data_ptr(), self.out_cls.data_ptr(), self.out_count.data_ptr()],
+            i={0: A, 1: max_det, 2: iw, 3: ih, 4: batch}, f={0: iou}))
         self.plan = pb.build()
         self.n_ops = len(pb.ops)
         torch.cuda.synchronize(det.device)          # buffers were allocated / zero-filled on the current stream: order them before det.stream

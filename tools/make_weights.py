@@ -16,47 +16,29 @@ ROOT = Path(__file__).resolve().parents[1]
 sys.path.insert(0, str(ROOT))
 
 
-# Frames the GPU parity tests / smoke / bench run the detector on, per stand-in width: (image seed, iw, ih, imgsz, tiled).
-# build_random_detector centres the score threshold in a gap of THESE frames' anchor logits (oracle/yolov9e_ref.py).
-PARITY_FRAMES = {
-    1.0: [(0, 1920, 1080, (1080, 1920), False)],          # the eight 640x640 bench frames are the calibration batch itself
-    0.5: [(s, 1920, 1080, 640, False) for s in (0, 1, 2)] + [(4, 3840, 2160, 640, True), (2, 1280, 800, 640, False)],
-    0.25: [(0, 1920, 1080, (1080, 1920), False), (0, 640, 480, 320, False)],
-}
+# Stand-in detector version.  v5 (round 5): BatchNorm shifts centred at +1 and gains 0.15 (oracle/yolov9e_ref.py::build_random_detector) —
+# the stand-in's own f32-vs-f64 head difference is <= 2.6e-5 at 1088x1920 (v4: 1e-2 ... 8e-2) and <= 2e-5 at 640x640; and the score
+# threshold is placed on the CALIBRATION batch alone (seeds 0..7 at 640x640): rounds 2-4 centred it in a gap of the parity frames'
+# own logits (`PARITY_FRAMES`), i.e. tuned the stand-in to the frames it was tested on.  Every frame list below is now chosen by an
+# a-priori scan of the CPU oracle (tools/scan_parity_frames.py) over frames the calibration never saw (seeds >= 8, other sizes).
+DETECTOR_STANDIN = "v5"
 
-
-# Frames (synthetic_screenshot seed at 1920x1080 — 640x480 for the 320 entry — letterboxed to the given network size) on which the
-# CPU oracle takes no NMS decision on a tie, with margin: no IoU within 1e-5 of the threshold (listed frames: >= 5.6e-5), no suppression
-# by a box whose score is within 4e-6 of its victim's (listed frames: >= 1.0e-5); GPU-vs-oracle differences are ~1e-6 in the scores,
-# ~2e-4 px in the boxes, ~1e-5 in the logits (threshold margin of the listed frames >= 1.0e-4).  With the v4 stand-in EVERY 640x640 and
-# 320x320 frame is well conditioned (f32 vs f64 <= 1.3e-5), so the list only selects for ties.  On these frames the parity tests
-# demand the oracle's boxes one for one and fail if the oracle on the test box disagrees that they are tie-free.
-# Scan: tools/scan_parity_frames.py -> profiles/r2_parity_frame_scan.md.  Re-scan whenever build_random_detector or synth.py changes.
-EXACT_FRAMES = {(1.0, 640): (1,), (0.5, 640): (4, 2), (0.25, 640): (1, 3), (0.25, 320): (2, 0)}
-# frames the scan found well conditioned (ties or not): candidate sets must be identical there, final boxes up to one exchange per tie
+# Frames (synthetic_screenshot seed at 1920x1080 — 640x480 for the 320 entry — letterboxed to the given network size; "native" = the
+# scale_img=True path, 1088x1920 network input) on which the CPU oracle is tie-free WITH MARGIN: no NMS IoU within 3e-5 of the
+# threshold, no suppression by a box whose score is within 9e-6 of its victim's, no anchor logit within 1e-4 of logit(conf) — several
+# times the GPU-vs-oracle differences (scores ~1e-6, boxes ~2e-4 px, logits ~2e-5).  On these frames the parity tests demand the
+# oracle's boxes one for one and fail if the oracle on the test box disagrees that they are tie-free.
+# Scan: tools/scan_parity_frames.py -> profiles/r5_parity_frame_scan.md.  Re-scan whenever build_random_detector or synth.py changes.
+EXACT_FRAMES = {(1.0, 640): (), (0.5, 640): (), (0.25, 640): (), (0.25, 320): (), (1.0, "native"): (), (0.25, "native"): ()}
+# frames the scan found well conditioned (ties or not): candidate sets must be identical there, final boxes up to the tie rules
 WELL_FRAMES = {(1.0, 640): tuple(range(8)), (0.5, 640): tuple(range(8)), (0.25, 640): (0, 1, 2, 3), (0.25, 320): (0, 1, 2, 3)}
-
-
-def parity_inputs(width):
-    from oracle.yolov9e_ref import letterbox_tensor
-    from omniparser_amd.pipeline import ScreenParser
-    from omniparser_amd.synth import synthetic_screenshot
-    xs = []
-    for seed, iw, ih, imgsz, tiled in PARITY_FRAMES.get(float(width), []):
-        img = synthetic_screenshot(seed, iw, ih)
-        if tiled:
-            origins, tw, th = ScreenParser.tile_origins(iw, ih)
-            xs += [letterbox_tensor(img[y:y + th, x:x + tw], imgsz) for x, y in origins]
-        else:
-            xs.append(letterbox_tensor(img, imgsz))
-    return xs
 
 
 CALIB_DIR = ROOT / "tools" / "standin_calibration"
 
 
 def calibration_path(seed=0, nc=1, width=1.0):
-    return CALIB_DIR / f"v4_s{seed}_nc{nc}_w{width:g}.pt"
+    return CALIB_DIR / f"{DETECTOR_STANDIN}_s{seed}_nc{nc}_w{width:g}.pt"
 
 
 def make_blob(path, seed=0, nc=1, width=1.0):
@@ -69,7 +51,7 @@ def make_blob(path, seed=0, nc=1, width=1.0):
     if cpath.exists() and os.environ.get("OMNI_RECALIBRATE", "0") != "1":
         model = build_random_detector(seed=seed, nc=nc, width=width, calibration=torch.load(str(cpath), map_location="cpu"))
     else:
-        model = build_random_detector(seed=seed, nc=nc, width=width, margin_frames=parity_inputs(width))
+        model = build_random_detector(seed=seed, nc=nc, width=width)      # threshold placed on the calibration batch alone
         sd = model.state_dict()
         calib = {k: sd[k].clone() for k in calibrated_keys(sd)}
         calib["margin"] = torch.tensor(model.margin, dtype=torch.float64)
@@ -85,7 +67,7 @@ def make_blob(path, seed=0, nc=1, width=1.0):
 
 
 def default_path(seed=0, nc=1, width=1.0):
-    tag = f"v4_s{seed}_nc{nc}_w{width:g}"       # v4: calibration batch with noisy / random / native-scale frames (end of round 2)
+    tag = f"{DETECTOR_STANDIN}_s{seed}_nc{nc}_w{width:g}"
     return ROOT / "weights" / f"icon_detect_v3_{tag}" / "icon_detect_v3" / "model.pt"
 
 

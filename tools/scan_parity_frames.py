@@ -1,12 +1,19 @@
 """Scan synthetic frames for the properties the box-for-box parity tests need (CPU only, oracle only):
-  noise      max |f32 - f64| over the stand-in's head tensors (conditioning of the oracle on that frame)
+  noise      max |f32 - f64| over the stand-in's head tensors (conditioning of the oracle on that frame; --noise)
   thr_margin smallest distance of an anchor's best class logit from logit(conf) (a candidate cannot flip below GPU rounding noise)
   near_ties / score_ties / iou_margin / score_gap   NMS decisions of the oracle that sit on a tie (oracle/detector_ref.py::nms)
-Frames with noise <= 3.3e-5, no ties and comfortable margins go into tools/make_weights.py::EXACT_FRAMES.
-usage: python tools/scan_parity_frames.py [width ...]   -> markdown table on stdout (committed as profiles/r2_parity_frame_scan.md)"""
+  elements / crops   what the reference's hand-off (remove_overlap_new against the synthetic OCR fixture) leaves of the boxes
+Frames without ties and with comfortable margins go into tools/make_weights.py::EXACT_FRAMES / omniparser_amd/synth.py::BENCH_SEEDS
+(criteria: `passes()` below, fixed BEFORE looking at any device result).
+
+usage: python tools/scan_parity_frames.py --width 1.0 --imgsz 640 --seeds 0:110 [--noise] [--frame 1920x1080] [--json out.json]
+       (imgsz: an integer or `native`)   -> markdown table on stdout, rows appended to the JSON file (resumable)"""
+import argparse
+import json
 import math
 import os
 import sys
+from types import SimpleNamespace
 
 import torch
 from PIL import Image
@@ -14,44 +21,87 @@ from PIL import Image
 sys.path.insert(0, os.path.dirname(os.path.dirname(os.path.abspath(__file__))))
 from oracle import detector_ref as D                      # noqa: E402
 from oracle.yolov9e_ref import YOLOv9E                    # noqa: E402
-from omniparser_amd.synth import synthetic_screenshot     # noqa: E402
+from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot     # noqa: E402
 from tools.make_weights import ensure_blob                # noqa: E402
 
-CASES = {1.0: [(s, 640, 1920, 1080) for s in range(8)],
-         0.5: [(s, 640, 1920, 1080) for s in range(8)],
-         0.25: [(s, 640, 1920, 1080) for s in range(4)] + [(s, 320, 640, 480) for s in range(4)] + [(0, (1080, 1920), 1920, 1080)]}
+THR_MARGIN, IOU_MARGIN, SCORE_GAP = 1e-4, 3e-5, 9e-6      # several times the GPU-vs-oracle differences (logits 2e-5, boxes 2e-4 px, scores 1e-6)
+
+
+def passes(r):
+    return r["near_ties"] == 0 and r["score_ties"] == 0 and r["thr_margin"] >= THR_MARGIN and r["iou_margin"] >= IOU_MARGIN and r["score_gap"] >= SCORE_GAP
 
 
 def main():
-    # `--seeds A:B` scans full-HD frames A..B-1 at 640x640 for the widths given (choosing the bench's tie-free frames)
-    args = sys.argv[1:]
-    if "--seeds" in args:
-        k = args.index("--seeds")
-        lo, hi = (int(v) for v in args[k + 1].split(":"))
-        del args[k:k + 2]
-        for w in (float(a) for a in args) if args else (1.0,):
-            CASES[w] = [(s, 640, 1920, 1080) for s in range(lo, hi)]
-    widths = [float(a) for a in args] or [0.25, 0.5, 1.0]
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--width", type=float, default=1.0)
+    ap.add_argument("--nc", type=int, default=1)
+    ap.add_argument("--blob-seed", type=int, default=0)
+    ap.add_argument("--imgsz", default="640")
+    ap.add_argument("--seeds", default="0:8")
+    ap.add_argument("--frame", default="1920x1080")
+    ap.add_argument("--noise", action="store_true", help="also evaluate the stand-in in f64 (slow at full width / native size)")
+    ap.add_argument("--json", default=None)
+    ap.add_argument("--tiled", action="store_true", help="the configs[4] policy (oracle/tiling_ref.py: 2x2 overlapping tiles -> global NMS) on --frame")
+    a = ap.parse_args()
+    iw, ih = (int(v) for v in a.frame.split("x"))
+    imgsz = int(a.imgsz) if a.imgsz.isdigit() else (ih, iw)
+    lo, hi = (int(v) for v in a.seeds.split(":"))
     thr = math.log(0.05 / 0.95)
-    print("| width | seed | frame | net input | boxes | candidates | noise f32-f64 | thr margin | near ties | score ties | IoU margin | score gap |")
-    print("|---|---|---|---|---|---|---|---|---|---|---|---|")
-    for width in widths:
-        m = torch.jit.load(str(ensure_blob(seed=0, nc=1, width=width)), map_location="cpu").eval()
-        m64 = YOLOv9E(nc=1, width=width).double()
+    from omniparser_amd.pipeline import ScreenParser
+    m = torch.jit.load(str(ensure_blob(seed=a.blob_seed, nc=a.nc, width=a.width)), map_location="cpu").eval()
+    m64 = None
+    if a.noise:
+        m64 = YOLOv9E(nc=a.nc, width=a.width).double()
         m64.load_state_dict({k: v.double() for k, v in m.state_dict().items()}, strict=False)
         m64.eval()
-        for seed, imgsz, iw, ih in CASES[width]:
+    done = json.loads(open(a.json).read()) if a.json and os.path.exists(a.json) else {}
+    key = f"w{a.width:g}_nc{a.nc}_{a.imgsz}_{a.frame}" + ("_tiled" if a.tiled else "")
+    rows = done.setdefault(key, {})
+    print("| width | seed | frame | net input | boxes | candidates | elements | crops | noise f32-f64 | thr margin | near ties | score ties | IoU margin | score gap | passes |")
+    print("|---|---|---|---|---|---|---|---|---|---|---|---|---|---|---|")
+    for seed in range(lo, hi):
+        r = rows.get(str(seed))
+        if r is None and a.tiled:
+            from oracle import tiling_ref as TR
+            im = synthetic_screenshot(seed, iw, ih)
+            origins, tw, th = ScreenParser.tile_origins(iw, ih)
+            rb, rs, rc, st = TR.predict_tiled(m, im, origins, tw, th, return_stats=True)
+            texts, obox = synthetic_ocr(seed, iw, ih, 60)
+            el, cr = ScreenParser.glue(SimpleNamespace(iou_threshold=0.7), rb, iw, ih, obox, texts)
+            r = {"net_input": [640, 640], "boxes": len(rb), "candidates": 0, "elements": len(el), "crops": len(cr), "noise": None,
+                 "thr_margin": st["thr_margin"], "near_ties": st["near_ties"], "score_ties": st["score_ties"], "iou_margin": st["min_iou_margin"],
+                 "score_gap": st["min_score_gap"]}
+            rows[str(seed)] = r
+            if a.json:
+                with open(a.json + ".tmp", "w") as f:
+                    json.dump(done, f)
+                os.replace(a.json + ".tmp", a.json)
+        elif r is None or (a.noise and r.get("noise") is None):
             img = Image.fromarray(synthetic_screenshot(seed, iw, ih))
             rb, rs, rc, dbg = D.predict(m, img, conf=0.05, imgsz=imgsz, iou=0.1, return_debug=True)
             x = dbg["input"]
             with torch.inference_mode():
                 o32 = m(x)
-                o64 = m64(x.double())
-            noise = max((a.double() - b).abs().max().item() for a, b in zip(o32, o64))
+                noise = None
+                if m64 is not None:
+                    o64 = m64(x.double())
+                    noise = max((p.double() - q).abs().max().item() for p, q in zip(o32, o64))
             lg = torch.cat([o32[i].flatten(2) for i in (0, 2, 4)], 2).max(1).values.flatten()
-            print(f"| {width} | {seed} | {iw}x{ih} | {tuple(x.shape[2:])} | {len(rb)} | {int(dbg['valid'].sum())} | {noise:.2e} | "
-                  f"{(lg - thr).abs().min().item():.2e} | {dbg['near_ties']} | {dbg['score_ties']} | {dbg['min_iou_margin']:.2e} | "
-                  f"{dbg['min_score_gap']:.2e} |", flush=True)
+            texts, obox = synthetic_ocr(seed, iw, ih, 40)
+            el, cr = ScreenParser.glue(SimpleNamespace(iou_threshold=0.7), rb, iw, ih, obox, texts)
+            r = {"net_input": list(x.shape[2:]), "boxes": len(rb), "candidates": int(dbg["valid"].sum()), "elements": len(el), "crops": len(cr),
+                 "noise": noise, "thr_margin": (lg - thr).abs().min().item(), "near_ties": int(dbg["near_ties"]),
+                 "score_ties": int(dbg["score_ties"]), "iou_margin": float(dbg["min_iou_margin"]), "score_gap": float(dbg["min_score_gap"])}
+            rows[str(seed)] = r
+            if a.json:
+                with open(a.json + ".tmp", "w") as f:
+                    json.dump(done, f)
+                os.replace(a.json + ".tmp", a.json)
+        print(f"| {a.width} | {seed} | {iw}x{ih} | {tuple(r['net_input'])} | {r['boxes']} | {r['candidates']} | {r['elements']} | {r['crops']} | "
+              f"{'-' if r['noise'] is None else format(r['noise'], '.2e')} | {r['thr_margin']:.2e} | {r['near_ties']} | {r['score_ties']} | "
+              f"{r['iou_margin']:.2e} | {r['score_gap']:.2e} | {'yes' if passes(r) else ''} |", flush=True)
+    ok = [s for s in range(lo, hi) if passes(rows[str(s)])]
+    print(f"\npasses (no tie, thr margin >= {THR_MARGIN:g}, IoU margin >= {IOU_MARGIN:g}, score gap >= {SCORE_GAP:g}): {ok}")
 
 
 if __name__ == "__main__":
