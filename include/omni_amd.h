@@ -85,7 +85,10 @@ enum {
   OMNI_OP_MAXPOOL = 3,
   /* nearest-neighbour resize (F.interpolate mode='nearest') of a channel slice,
    * either overwriting or accumulating into y (Upsample, CBFuse).
-   *  p0 x p4 y; i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i10 Ho i11 Wo i13 ldo i14 out_coff i18 accumulate */
+   *  p0 x p4 y; i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i10 Ho i11 Wo i13 ldo i14 out_coff i18 accumulate
+   *  i17 = n > 1 (CBFuse in one launch): y = ((r(x0) + r(x1)) + ...) over n <= 5 sources of C channels in order, r = nearest resize to
+   *  Ho x Wo; source 0 as above, sources 1..4 = p1, p2, p3, p5 with (H, W, ld, coff) in i19-22, i23-26, i27-30, (i7, i12, i15, i16);
+   *  the same partial sums, rounded the same way, as n launches with i18 = 1 */
   OMNI_OP_RESIZE_NEAREST = 4,
   /* Pillow-exact separable resample (LANCZOS/BICUBIC, 8bpc fixed point) +
    * letterbox + /255 -> network input.  Replaces ref:util/yolov9.py:73-87.

@@ -106,6 +106,29 @@ static void op_extents(const omni_op_t* op, long long ext[8]) {
     case OMNI_OP_AVGPOOL2: case OMNI_OP_MAXPOOL: case OMNI_OP_RESIZE_NEAREST: {
       const long long B = i[0], Ho = op->kind == OMNI_OP_AVGPOOL2 ? i[1] - 1 : i[10], Wo = op->kind == OMNI_OP_AVGPOOL2 ? i[2] - 1 : i[11];
       ext[0] = span(B * i[1] * i[2], i[4], i[5], i[3]); ext[4] = span(B * Ho * Wo, i[13], i[14], i[3]);
+      if (op->kind == OMNI_OP_RESIZE_NEAREST && i[17] > 1) {                      // CBFuse: sources 1..4 = p1, p2, p3, p5
+        static const int pidx[4] = {1, 2, 3, 5};
+        static const int base[4][4] = {{19, 20, 21, 22}, {23, 24, 25, 26}, {27, 28, 29, 30}, {7, 12, 15, 16}};
+        for (int k = 0; k + 1 < i[17] && k < 4; ++k)
+          ext[pidx[k]] = span(B * i[base[k][0]] * i[base[k][1]], i[base[k][2]], i[base[k][3]], i[3]);
+      }
+      break;
+    }
+    case OMNI_OP_NMS: {
+      // p0 cand[frames][cap] p1 count[frames] p2 sorted[frames][cap + 1] p3 mask u64[cap * ceil(cap / 64)] p4..p7 outputs per frame
+      const long long cap = i[0], md = i[1], fr = i[4] > 0 ? i[4] : 1;
+      ext[0] = fr * cap * 32; ext[1] = fr * 4; ext[2] = fr * (cap + 1) * 32; ext[3] = cap * ((cap + 63) / 64) * 8;
+      ext[4] = fr * md * 16; ext[5] = fr * md * 4; ext[6] = fr * md * 4; ext[7] = fr * 4;
+      break;
+    }
+    case OMNI_OP_DETECT_DECODE: {
+      // p0..p2 class heads, p3..p5 box heads of strides 8 / 16 / 32 over a TH x TW input; p6 cand[cap] p7 count
+      for (int l = 0; l < 3; ++l) {
+        const long long hw = (long long)(i[1] / (8 << l)) * (i[2] / (8 << l));
+        ext[l] = span(hw, i[3 + l], i[13 + l], i[0]);
+        ext[3 + l] = span(hw, i[6 + l], i[16 + l], i[12] ? 4 : 64);
+      }
+      ext[6] = (long long)i[9] * 32; ext[7] = 4;
       break;
     }
     case OMNI_OP_LAYERNORM: {

@@ -13,6 +13,9 @@ struct PoolArgs {
   int B, H, W, C, ldi, in_coff, k, stride, pad, Ho, Wo, ldo, out_coff, accumulate;
   float hscale, wscale;
   long long total;  // B*Ho*Wo*(C/V)
+  // MODE 3 (CBFuse): up to 5 sources of one channel count, each with its own size / pitch / slice; source 0 = x, H, W, ldi, in_coff
+  int nsrc;
+  const void* xs[4]; int Hs[4], Ws[4], lds[4], coffs[4];
 };
 
 template <typename T> struct Vec16 {
@@ -30,7 +33,15 @@ __device__ __forceinline__ void stv(T* p, const Vec16<T>& v) {
   *reinterpret_cast<u32x4*>(p) = __builtin_bit_cast(u32x4, v);
 }
 
-template <typename T, int MODE>  // MODE 0 avgpool2 s1, 1 maxpool, 2 nearest resize
+// ATen nearest_idx: same size -> identity; exact 2x -> >>1; else min(floor(dst * scale), in - 1) with scale = in / out in f32
+__device__ __forceinline__ int nearest_idx(int o, int out, int in) {
+  if (out == in) return o;
+  if (out == 2 * in) return o >> 1;
+  int i = (int)floorf(o * ((float)in / (float)out));
+  return i < in - 1 ? i : in - 1;
+}
+
+template <typename T, int MODE>  // MODE 0 avgpool2 s1, 1 maxpool, 2 nearest resize, 3 sum of nearest-resized sources (CBFuse)
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
   constexpr int V = ElemTraits<T>::kVec;
   const int cv = a.C / V;
@@ -75,6 +86,19 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
 #pragma unroll
           for (int e = 0; e < V; ++e) acc[e] = fmaxf(acc[e], ElemTraits<T>::to_f32(v.v[e]));
         }
+      }
+    } else if (MODE == 3) {
+      // CBFuse (ref blob: torch.sum(torch.stack([F.interpolate(x_i, size, 'nearest') ...]), 0)): ((s0 + s1) + s2) + ... in source order,
+      // every partial sum rounded to T — bit for bit what the chain of accumulate-resize launches computed, in ONE pass over the output
+      Vec16<T> v = ldv<T>(xb + ((long long)nearest_idx(ho, a.Ho, a.H) * a.W + nearest_idx(wo, a.Wo, a.W)) * a.ldi);
+#pragma unroll
+      for (int e = 0; e < V; ++e) acc[e] = ElemTraits<T>::to_f32(v.v[e]);
+      for (int k = 0; k + 1 < a.nsrc; ++k) {
+        const T* xk = reinterpret_cast<const T*>(a.xs[k]) + (long long)b * a.Hs[k] * a.Ws[k] * a.lds[k] + a.coffs[k] + c;
+        Vec16<T> u = ldv<T>(xk + ((long long)nearest_idx(ho, a.Ho, a.Hs[k]) * a.Ws[k] + nearest_idx(wo, a.Wo, a.Ws[k])) * a.lds[k]);
+#pragma unroll
+        for (int e = 0; e < V; ++e)
+          acc[e] = ElemTraits<T>::to_f32(ElemTraits<T>::from_f32(acc[e])) + ElemTraits<T>::to_f32(u.v[e]);
       }
     } else {
       // ATen nearest_idx: same size -> identity; exact 2x -> >>1; else min(floor(dst*scale), in-1)
@@ -155,6 +179,19 @@ int omni_launch_resize_nearest(const omni_op_t* op, hipStream_t s) {
   int rc = fill_args(op, a, "resize_nearest");
   if (rc) return rc;
   OMNI_REQUIRE(a.Ho > 0 && a.Wo > 0, "resize_nearest: bad output size");
+  if (op->i[17] > 1) {                       // CBFuse: i17 sources summed in order (include/omni_amd.h)
+    a.nsrc = op->i[17];
+    OMNI_REQUIRE(a.nsrc <= 5 && !a.accumulate, "resize_nearest: at most 5 sources, and no accumulate with several");
+    static const int pidx[4] = {1, 2, 3, 5};
+    static const int base[4][4] = {{19, 20, 21, 22}, {23, 24, 25, 26}, {27, 28, 29, 30}, {7, 12, 15, 16}};
+    const int V = op->dtype == OMNI_F32 ? 4 : 8;
+    for (int k = 0; k + 1 < a.nsrc; ++k) {
+      a.xs[k] = op->p[pidx[k]];
+      a.Hs[k] = op->i[base[k][0]]; a.Ws[k] = op->i[base[k][1]]; a.lds[k] = op->i[base[k][2]]; a.coffs[k] = op->i[base[k][3]];
+      OMNI_REQUIRE(a.xs[k] && a.Hs[k] > 0 && a.Ws[k] > 0 && a.lds[k] % V == 0 && a.coffs[k] % V == 0, "resize_nearest: bad source %d", k + 1);
+    }
+    return launch<3>(op, a, s);
+  }
   a.hscale = (float)a.H / (float)a.Ho;
   a.wscale = (float)a.W / (float)a.Wo;
   return launch<2>(op, a, s);

@@ -57,6 +57,38 @@ def _legacy_to_native(sd: Dict[str, torch.Tensor]) -> Dict[str, torch.Tensor]:
     return out
 
 
+def normalise_config(cfg: dict) -> dict:
+    """config.json of the remote-code (`trust_remote_code`) Florence-2 — what the reference actually loads (ref:util/utils.py:63-68,
+    weights/icon_caption_florence/config.json) — in the vocabulary of the native transformers config this module reads: the DaViT
+    widths are `dim_embed` there (`embed_dim` natively), the learned 2-D position table and the temporal table carry their sizes in
+    nested dicts (`image_pos_embed.max_pos_embeddings`, `visual_temporal_embedding.max_temporal_embeddings`), and the generation
+    defaults (`no_repeat_ngram_size`, `forced_bos_token_id`, ...) sit in `text_config` or at the top level.  Returns a copy; a native
+    config passes through unchanged.  A config that names neither spelling raises a ValueError that says which key is missing —
+    never a bare KeyError from deep inside the loader."""
+    cfg = json.loads(json.dumps(cfg))
+    vc = cfg.get("vision_config")
+    tc = cfg.get("text_config")
+    if not isinstance(vc, dict) or not isinstance(tc, dict):
+        raise ValueError("Florence-2 config.json needs `vision_config` and `text_config` objects")
+    if "embed_dim" not in vc and "dim_embed" in vc:
+        vc["embed_dim"] = list(vc["dim_embed"])
+    pe = vc.get("image_pos_embed")
+    if isinstance(pe, dict) and "max_position_embeddings" not in vc and "max_pos_embeddings" in pe:
+        vc["max_position_embeddings"] = int(pe["max_pos_embeddings"])
+    te = vc.get("visual_temporal_embedding")
+    if isinstance(te, dict) and "max_temporal_embeddings" not in vc and "max_temporal_embeddings" in te:
+        vc["max_temporal_embeddings"] = int(te["max_temporal_embeddings"])
+    need_v = ("embed_dim", "depths", "num_heads", "num_groups", "patch_size", "patch_stride", "patch_padding", "patch_prenorm", "window_size",
+              "projection_dim")
+    need_t = ("d_model", "vocab_size", "encoder_layers", "decoder_layers", "encoder_attention_heads", "encoder_ffn_dim", "decoder_ffn_dim",
+              "max_position_embeddings")
+    missing = [f"vision_config.{k}" for k in need_v if k not in vc] + [f"text_config.{k}" for k in need_t if k not in tc]
+    if missing:
+        raise ValueError("Florence-2 config.json lacks " + ", ".join(missing) + " (native transformers names; the remote-code spellings "
+                         "dim_embed / image_pos_embed / visual_temporal_embedding are translated)")
+    return cfg
+
+
 def expected_native_keys(cfg: dict) -> Dict[str, tuple]:
     """Every tensor a Florence-2 checkpoint in the native transformers layout must hold, with its shape, derived from config.json alone
     (hf:models/florence2/modeling_florence2.py module tree).  `FlorenceWeights` audits a checkpoint against it at load:
@@ -146,7 +178,7 @@ class FlorenceWeights:
         from safetensors.torch import load_file
         d = Path(model_dir)
         self.dir = d
-        self.cfg = json.loads((d / "config.json").read_text())
+        self.cfg = normalise_config(json.loads((d / "config.json").read_text()))
         gpath = d / "generation_config.json"
         self.gen = json.loads(gpath.read_text()) if gpath.exists() else {}
         files = sorted(d.glob("*.safetensors"))
@@ -169,7 +201,9 @@ class FlorenceWeights:
         self.enc_layers, self.dec_layers = tc["encoder_layers"], tc["decoder_layers"]
         self.vocab = self.sd["lm_head.weight"].shape[0]
         self.embed_scale = math.sqrt(self.d_model) if tc.get("scale_embedding", False) else 1.0
-        g = lambda k, dflt: self.gen.get(k, tc.get(k, dflt))
+        # generation defaults: generation_config.json, else text_config, else the top level of config.json (where the remote-code config and
+        # `_from_model_config` exports keep them), else the transformers default (no n-gram ban, nothing forced)
+        g = lambda k, dflt: self.gen.get(k, tc.get(k, self.cfg.get(k, dflt)))
         self.pad, self.bos, self.eos = g("pad_token_id", 1), g("bos_token_id", 0), g("eos_token_id", 2)
         self.start = g("decoder_start_token_id", 2)
         self.ngram = g("no_repeat_ngram_size", 0) or 0
@@ -683,22 +717,30 @@ class Florence2Captioner:
         epoch = getattr(self, "_epoch", 0)
         if key in self._plans:
             self._plans[key] = self._plans.pop(key)            # most recently used last
-            meta[key][1] = epoch
+            meta.setdefault(key, [0, epoch])[1] = epoch        # (an entry placed in _plans from outside has no record: size unknown)
             return self._plans[key]
         max_bytes = int(float(os.environ.get("OMNI_CAPTION_PLAN_GB", "200")) * 2 ** 30)
         max_plans = int(os.environ.get("OMNI_MAX_CAPTION_PLANS", "16"))
         base = key[:4] if key[0] == "dec" else key[:3]         # the key without its slot: twins have the same size
         sizes = self.__dict__.setdefault("_plan_sizes", {})    # bytes of every plan set ever built (survives eviction): the estimate
-        est = sizes.get(base, 0)                               # for the one about to be built (0 = unknown: the count bound applies)
+        est = sizes.get(base, 0)                               # for the one about to be built
+        if not est and sizes:
+            # a shape never built before: scale the bytes-per-row of the known shape of the same kind and resolution (activations are
+            # linear in the row count) — so the byte bound also guards FIRST builds of non-default buckets / lanes / resolutions
+            same = [(b, v) for b, v in sizes.items() if (b[0] == "dec") == (base[0] == "dec") and b[-2] == base[-2] and v]
+            if same:
+                b0, v0 = max(same, key=lambda bv: bv[1])
+                rows0, rows = (b0[1] if b0[0] == "dec" else b0[0]), (base[1] if base[0] == "dec" else base[0])
+                est = int(v0 * rows / max(rows0, 1))
         def over():
             return len(self._plans) >= max_plans or (self._plans and self.plan_cache_bytes() + est > max_bytes)
         while over():
-            victim = next((k for k in self._plans if meta[k][1] != epoch), None)
+            victim = next((k for k in self._plans if meta.get(k, [0, None])[1] != epoch), None)
             if victim is None:
                 break                                          # everything resident belongs to the batch being issued
             torch.cuda.synchronize(self.device)                # work of any of the captioner's streams may still use the evicted plan's buffers
             self._plans.pop(victim)
-            meta.pop(victim)
+            meta.pop(victim, None)
             self.plan_evictions = getattr(self, "plan_evictions", 0) + 1
         on_gpu = self.device.type == "cuda" and torch.cuda.is_available()
         before = torch.cuda.memory_allocated(self.device) if on_gpu else 0

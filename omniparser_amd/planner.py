@@ -325,6 +325,25 @@ class PlanBuilder:
     def resize_nearest(self, x: View, out: View, accumulate=False):
         return self._pool(L.OP_RESIZE_NEAREST, x, out, accumulate=1 if accumulate else 0)
 
+    def resize_sum(self, srcs, out: View):
+        """out = ((resize(s0) + resize(s1)) + ...) — CBFuse as ONE launch (OMNI_OP_RESIZE_NEAREST with i17 sources, at most 5): the same
+        partial sums in the same order as a chain of accumulate-resize launches, one pass over the output instead of len(srcs)."""
+        assert 1 <= len(srcs) <= 5 and all(s.C == out.C and s.B == out.B for s in srcs)
+        if len(srcs) == 1:
+            return self.resize_nearest(srcs[0], out)
+        x = srcs[0]
+        slots = ((19, 20, 21, 22), (23, 24, 25, 26), (27, 28, 29, 30), (7, 12, 15, 16))
+        pidx = (1, 2, 3, 5)
+        p = [x.ptr, None, None, None, out.ptr, None]
+        i = {0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 10: out.H, 11: out.W, 13: out.ld, 14: out.coff, 17: len(srcs)}
+        for k, sv in enumerate(srcs[1:]):
+            p[pidx[k]] = sv.ptr
+            i.update({slots[k][0]: sv.H, slots[k][1]: sv.W, slots[k][2]: sv.ld, slots[k][3]: sv.coff})
+        self.ops.append(L.make_op(L.OP_RESIZE_NEAREST, self.dtype, p=p, i=i))
+        esz = 4 if self.dtype == L.F32 else 2
+        self.bytes += esz * (sum(s.B * s.H * s.W * s.C for s in srcs) + out.B * out.H * out.W * out.C)
+        return out
+
     def add_op(self, op):
         self.ops.append(op)
 

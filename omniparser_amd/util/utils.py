@@ -60,12 +60,21 @@ class FlorenceProcessor:
     not shipped with the reference; if `tokenizer.json` sits next to the checkpoint it is used for
     `batch_decode`, otherwise token ids are rendered as text."""
 
-    def __init__(self, model_dir=None, image_token_id=51289):
+    def __init__(self, model_dir=None, image_token_id=51289, special_ids=(0, 1, 2, 3)):
+        """special_ids: bos / pad / eos / unk of the checkpoint (Florence2Captioner passes what generation_config.json says) — used
+        only WITHOUT a tokenizer.json; with one, the special ids are the tokens that file flags `special` (what
+        `batch_decode(skip_special_tokens=True)` of the reference's AutoProcessor skips, ref:util/utils.py:128)."""
         self.image_token_id = image_token_id
         self.tok = None
+        self.special = set(int(i) for i in special_ids) | {int(image_token_id)}
         if model_dir is not None and (Path(model_dir) / "tokenizer.json").exists():
+            import json as _json
             from tokenizers import Tokenizer
-            self.tok = Tokenizer.from_file(str(Path(model_dir) / "tokenizer.json"))
+            path = Path(model_dir) / "tokenizer.json"
+            self.tok = Tokenizer.from_file(str(path))
+            added = _json.loads(path.read_text()).get("added_tokens", [])
+            self.special = {int(t["id"]) for t in added if t.get("special")} | {int(image_token_id)}
+            self.vocab_size = self.tok.get_vocab_size(with_added_tokens=True)
 
     def __call__(self, images=None, text=None, return_tensors="pt", do_resize=True, **kw):
         imgs = images if isinstance(images, (list, tuple)) else [images]
@@ -82,11 +91,12 @@ class FlorenceProcessor:
         return _Batch(input_ids=ids, pixel_values=pix, attention_mask=torch.ones_like(ids))
 
     def batch_decode(self, ids, skip_special_tokens=True):
-        special = {0, 1, 2, 3, self.image_token_id}
+        special = self.special
         out = []
         for row in ids.tolist():
             toks = [t for t in row if not (skip_special_tokens and t in special)]
             if self.tok is not None:
+                toks = [t for t in toks if 0 <= t < self.vocab_size]          # an id the tokenizer does not know (the image placeholder of another export)
                 out.append(self.tok.decode(toks, skip_special_tokens=skip_special_tokens))
             else:
                 out.append(" ".join(f"tok{t}" for t in toks))
@@ -100,7 +110,9 @@ def get_caption_model_processor(model_name, model_name_or_path="Salesforce/blip2
     if model_name != "florence2":
         raise NotImplementedError(f"caption model '{model_name}': only 'florence2' is implemented on MI355X")
     model = Florence2Captioner(model_name_or_path, device)
-    processor = FlorenceProcessor(model_name_or_path, image_token_id=model.w.cfg.get("image_token_id", 51289))
+    w = model.w
+    processor = FlorenceProcessor(model_name_or_path, image_token_id=w.cfg.get("image_token_id", 51289),
+                                  special_ids=(w.bos, w.pad, w.eos, w.cfg.get("text_config", {}).get("unk_token_id", 3)))
     return {"model": model, "processor": processor}
 
 

@@ -16,6 +16,7 @@ their roles from the blob's own graph (program order + hyper-parameters), not fr
 """
 from typing import Dict, List
 
+import os
 import torch
 
 from . import _lib as L
@@ -172,9 +173,11 @@ class YoloV9EGraph:
         """sum of nearest-resized routing tensors (the last CBFuse operand is added by the conv epilogue)."""
         pb = self.pb
         tmp = pb.alloc(srcs[0].B, H, W, srcs[0].C)
-        for i, sv in enumerate(srcs):
-            pb.resize_nearest(sv, tmp, accumulate=i > 0)
-        return tmp
+        if os.environ.get("OMNI_CBFUSE_CHAIN") == "1":          # the round-1 form: one accumulate-resize launch per source (A/B, bit-identical)
+            for i, sv in enumerate(srcs):
+                pb.resize_nearest(sv, tmp, accumulate=i > 0)
+            return tmp
+        return pb.resize_sum(srcs, tmp)
 
     # ------------------------------------------------------------ whole network
     def build(self, x: View):

@@ -369,9 +369,28 @@ def check_pools(dtype=L.F32, seed=0):
     pb.resize_nearest(xv, o5, accumulate=True)          # 4x: generic floor(dst*scale) path
     o6 = pb.alloc(2, 13, 18, 4 * V)
     pb.resize_nearest(xv, o6)                            # identity
+    # CBFuse in one launch: five sources of different sizes / pitches / slices (identity, exact 2x, 4x and two generic ratios) summed in
+    # order — bit-identical to the chain of accumulate-resize launches it replaces, and equal to torch.sum(torch.stack(...)) of the blob
+    srcs_t = [torch.randn(2, 2 * V, h, w, generator=g).to(tdt).float() for (h, w) in ((24, 40), (12, 20), (6, 10), (5, 7), (3, 3))]
+    srcs_v = [_nhwc(t, tdt, (2 + k % 2) * V, (k % 2) * V) for k, t in enumerate(srcs_t)]
+    o7 = pb.alloc(2, 24, 40, 2 * V)
+    pb.resize_sum(srcs_v, o7)
+    o8 = pb.alloc(2, 24, 40, 2 * V)
+    for k, sv in enumerate(srcs_v):
+        pb.resize_nearest(sv, o8, accumulate=k > 0)
+    o9 = pb.alloc(2, 24, 40, 3 * V, zero=True)
+    pb.resize_sum(srcs_v[:2], o9.slice(V, 2 * V))        # two sources into a channel slice
     for op in pb.ops:
         L.launch(op)
     _sync()
+    assert torch.equal(o7.t, o8.t), "fused CBFuse differs from the accumulate chain"
+    want = srcs_t[0]
+    for t in srcs_t[1:]:
+        want = (want.to(tdt) + F.interpolate(t, size=(24, 40), mode="nearest").to(tdt)).float()
+    res["cbfuse5"] = (o7.torch().cpu() - want).abs().max().item()
+    w2 = (srcs_t[0].to(tdt) + F.interpolate(srcs_t[1], size=(24, 40), mode="nearest").to(tdt)).float()
+    res["cbfuse2_slice"] = (o9.slice(V, 2 * V).torch().cpu() - w2).abs().max().item()
+    assert (o9.t[..., :V] == 0).all() and (o9.t[..., 3 * V:] == 0).all()
     tol = 1e-6 if dtype == L.F32 else 2e-3
     r1 = F.avg_pool2d(x[:, V:3 * V], 2, 1, 0, False, True)
     res["avgpool"] = (o1.torch().cpu() - r1).abs().max().item()
