@@ -4,12 +4,14 @@ scope)."""
 import numpy as np
 
 # Seeds of the 8 screenshots of the bench batch (bench.py, tests/gpu_checks.py::check_bench_path).  Chosen by tools/scan_parity_frames.py
-# (CPU oracle only, a-priori criteria, profiles/r3_bench_frame_scan.md) among seeds 0..109: frames on which the oracle's own NMS takes
-# NO decision on a tie (no IoU within 1e-5 of the threshold, no suppression by a box whose score is within 4e-6 of its victim's) and whose
-# margins (threshold >= 8e-5, IoU >= 3e-5, score gap >= 9e-6) are several times the GPU-vs-oracle differences (scores 1e-6, boxes 2e-4 px,
-# logits 1e-5) — so "box for box against the oracle's own list" is a well-posed statement on every frame of the benched batch, not on
-# 2 of 8 (seeds 0..7, rounds 1-2).  Of the nine seeds that pass, the eight with the most caption crops (345 per batch; rounds 1-2: 349).
-BENCH_SEEDS = (19, 57, 68, 97, 101, 102, 104, 107)
+# (CPU oracle only, criteria fixed beforehand, profiles/r5_parity_frame_scan.md) among seeds 8..109 — the stand-in's calibration batch holds
+# seeds 0..7, so every benched frame is HELD OUT — on which the oracle's own NMS takes NO decision on a tie (no IoU within 1e-5 of the
+# threshold, no suppression by a box whose score is within 4e-6 of its victim's) and whose margins (threshold >= 1e-4, IoU >= 3e-5, score
+# gap >= 9e-6) are several times the GPU-vs-oracle differences (scores 1e-6, boxes 2e-4 px, logits 2e-5): "box for box against the oracle's
+# own list" is a well-posed statement on every frame of the benched batch.  29 of the 110 scanned seeds pass (round 4's stand-in: 9); of
+# the 26 held-out ones, the 8 whose crop counts sum to 345 per batch — the crop count rounds 3-4 benched (128 + 128 + 96-row plans), so
+# screenshots/s stays comparable across rounds.
+BENCH_SEEDS = (14, 15, 18, 51, 87, 95, 102, 104)
 
 
 def synthetic_screenshot(seed: int = 0, w: int = 1920, h: int = 1080) -> np.ndarray:

@@ -723,50 +723,43 @@ def assert_detector_frame(rec, head_tol=HEAD_TOL, exact=False):
     """Per-frame parity of the whole detector stage with the CPU oracle (north_star: box for box, IoU >= 0.999, identical class ids).
 
       1. letterboxed input byte-exact;
-      2. head tensors of the full network within a FIXED epsilon (1e-4 absolute) — or, where the oracle's own f32-vs-f64 difference
-         was computed (`with_f64`) and is larger than that (frames on which the seeded stand-in amplifies rounding noise: outlier
-         activations, resolutions it was not calibrated on), within 8x that difference;
+      2. head tensors of the full network within a FIXED epsilon (1e-4 absolute) at EVERY input size — since the v5 stand-in (round 5)
+         the oracle's own f32-vs-f64 difference is <= 3e-5 at 1088x1920 as at 640x640, so there is no noise-relative escape any more;
       3. the device NMS equals the restated torchvision batched_nms + [:max_det] + clamp run on the device's OWN candidates, bit for bit;
-      4. on a frame that meets the fixed epsilon: the SAME anchors pass the score threshold, same class, scores within 1e-5, boxes
-         within 2e-3 px;
-      5. on such a frame whose oracle NMS takes no decision on a tie: the final boxes match the oracle's one to one (IoU >= 0.999,
-         same class, scores within 1e-5).  Greedy NMS is discontinuous: a suppression whose IoU lies within 1e-5 of the threshold
-         (`near_ties`), or that is taken by a box whose score is within 4e-6 of its victim's (`score_ties`), comes out the other way
-         under a 1e-6 change of the candidates in ANY implementation, and one such flip moves on to the neighbours (the oracle's own
-         final list changes by up to 10 boxes when its candidates are perturbed that much) — there 1-4 are the parity statement;
-         on a frame that does not meet the fixed epsilon only the box count is compared.
-    exact=True: the caller picked the frame from the tie-free, well-conditioned list (tools/make_weights.py::EXACT_FRAMES, scanned on
-    the CPU oracle), so 4 and 5 MUST apply — the test fails if they were skipped."""
+      4. the SAME anchors pass the score threshold, same class, scores within 1e-5, boxes within 2e-3 px — except that an anchor whose
+         ORACLE logit lies within `head_tol` of logit(conf) may fall on either side (the threshold is a discontinuity: with 8 400 ...
+         42 840 anchors the nearest one sits ~1e-4 ... 5e-5 away, the device's logit differs from the oracle's by ~2e-5).  Such anchors
+         are counted (`cand_borderline`); frames chosen for `exact=True` have none, or — 1088x1920 inputs, whose final list is full
+         (max_det boxes, all scoring far above conf) — none that could reach the final list (`borderline_below_final`);
+      5. on a frame whose oracle NMS takes no decision on a tie THAT CAN REACH THE FINAL LIST (oracle/detector_ref.py::postprocess): the
+         final boxes match the oracle's one to one (IoU >= 0.999, same class, scores within 1e-5).  Greedy NMS is discontinuous: a
+         suppression whose IoU lies within 1e-5 of the threshold (`near_ties`), or that is taken by a box whose score is within 4e-6 of
+         its victim's (`score_ties`), comes out the other way under a 1e-6 change of the candidates in ANY implementation, and one such
+         flip moves on to the neighbours — there 1-4 are the parity statement.
+    exact=True: the caller picked the frame from the scanned list (tools/make_weights.py::EXACT_FRAMES: tie-free with margins on the
+    CPU oracle), so 4 (without borderline anchors) and 5 MUST apply — the test fails if the oracle on this box disagrees."""
     assert rec["input_mismatch"] == 0, rec
-    noise = rec.get("oracle_noise(cls,dist,gpu_vs_f64)") or [(0.0, 0.0, 0.0)] * len(rec["head_err(cls,dist)"])
-    well = True
-    for (e_cls, e_dist), (n_cls, n_dist, _) in zip(rec["head_err(cls,dist)"], noise):
-        assert e_cls <= max(head_tol, 8 * n_cls) and e_dist <= max(head_tol, 8 * n_dist), rec
-        well = well and e_cls <= head_tol and e_dist <= head_tol
+    for (e_cls, e_dist) in rec["head_err(cls,dist)"]:
+        assert e_cls <= head_tol and e_dist <= head_tol, rec
     assert rec["nms_exact_on_gpu_candidates"], rec
     assert rec["n_ref"] > 0 and rec["n_gpu"] > 0, rec
     tie_free = rec["near_ties"] == 0 and rec["score_ties"] == 0
+    borderline = rec.get("cand_borderline", 0)
     if exact:
-        assert well and tie_free, rec
-    if well:
-        assert rec["cand_ref"] == rec["cand_gpu"] and rec["cand_same_anchors"] and rec["cand_same_classes"], rec
-        assert rec["cand_max_score_diff"] <= 1e-5 and rec["cand_max_box_diff_px"] <= 2e-3, rec
-    else:
-        assert abs(rec["cand_ref"] - rec["cand_gpu"]) <= max(3, 0.02 * rec["cand_ref"]), rec
-    if well and tie_free:
+        assert tie_free and (borderline == 0 or rec.get("borderline_below_final", False)), rec
+    assert rec["cand_same_anchors"] and rec["cand_same_classes"], rec          # (borderline anchors excluded by the comparison itself)
+    assert rec["cand_max_score_diff"] <= 1e-5 and rec["cand_max_box_diff_px"] <= 2e-3, rec
+    if tie_free and (borderline == 0 or rec.get("borderline_below_final", False)):
         assert rec["n_ref"] == rec["n_gpu"] and rec["unmatched_boxes"] == 0 and rec["matched_is_bijection"], rec
         assert rec["matched_min_iou"] >= 0.999 and rec["matched_cls_equal"] and rec["matched_max_score_diff"] <= 1e-5, rec
-    elif well:
+    else:
         # The oracle decides a tie by the last bit of a score / an IoU, and greedy NMS passes a flipped decision on: perturbing the
-        # oracle's OWN candidates by the GPU-vs-oracle differences (1e-6 in the scores, 2e-4 px) changes its own final boxes on the
-        # bench frames with one or two ties by 0 (55-100 % of the trials), 4 or 10 boxes (tools/scan_parity_frames.py,
-        # profiles/r2_parity_frame_scan.md).  What parity means here is therefore 3 + 4 — identical candidates, and the reference's
-        # NMS applied to them reproduced bit for bit — both asserted above; against the oracle's own final list only what a tie cannot
-        # change is asserted: the count within the ill-conditioned bound, matched boxes with equal classes and scores.
+        # oracle's OWN candidates by the GPU-vs-oracle differences changes its own final boxes on frames with one or two ties by 0, 4
+        # or 10 boxes (tools/tie_study.py).  What parity means here is 3 + 4 — identical candidates, and the reference's NMS applied
+        # to them reproduced bit for bit — both asserted above; against the oracle's own final list only what a tie cannot change
+        # is asserted: the count within a cascade-sized bound, matched boxes with equal classes and scores.
         assert abs(rec["n_ref"] - rec["n_gpu"]) <= max(3, 0.15 * rec["n_ref"]), rec
         assert rec["matched_cls_equal"] and rec["matched_max_score_diff"] <= 1e-5, rec
-    else:
-        assert abs(rec["n_ref"] - rec["n_gpu"]) <= max(3, 0.15 * rec["n_ref"]), rec
 
 
 def device_candidates(dp, bi):
@@ -833,11 +826,21 @@ def check_detector(width=1.0, nc=1, seed=0, image_seeds=(0, 1), imgsz=640, preci
         g_boxes, g_scores, g_cls, g_anchor = device_candidates(dp, 0)
         r_boxes, r_scores, r_cls = dbg["cand"]
         r_anchor = torch.nonzero(dbg["valid"]).flatten()
-        same = n_c == len(r_anchor) and torch.equal(g_anchor, r_anchor)
+        # anchors whose ORACLE logit lies within HEAD_TOL of logit(conf) may fall on either side of the threshold; all others must agree
+        lg = torch.cat([ref_out[2 * i].flatten(2) for i in range(3)], 2).max(1).values.flatten()
+        border = torch.nonzero((lg - math.log(conf / (1.0 - conf))).abs() <= HEAD_TOL).flatten()
+        gi, ri = ~torch.isin(g_anchor, border), ~torch.isin(r_anchor, border)
+        same = int(gi.sum()) == int(ri.sum()) and torch.equal(g_anchor[gi], r_anchor[ri])
+        differ = set(g_anchor[~gi].tolist()) ^ set(r_anchor[~ri].tolist())
+        rec["cand_borderline"] = len(differ)
         rec["cand_same_anchors"] = bool(same)
-        rec["cand_same_classes"] = bool(same and torch.equal(g_cls, r_cls))
-        rec["cand_max_score_diff"] = (g_scores - r_scores).abs().max().item() if same and n_c else (0.0 if same else float("inf"))
-        rec["cand_max_box_diff_px"] = (g_boxes - r_boxes).abs().max().item() if same and n_c else (0.0 if same else float("inf"))
+        rec["cand_same_classes"] = bool(same and torch.equal(g_cls[gi], r_cls[ri]))
+        n_cmp = int(gi.sum())
+        rec["cand_max_score_diff"] = (g_scores[gi] - r_scores[ri]).abs().max().item() if same and n_cmp else (0.0 if same else float("inf"))
+        rec["cand_max_box_diff_px"] = (g_boxes[gi] - r_boxes[ri]).abs().max().item() if same and n_cmp else (0.0 if same else float("inf"))
+        # a borderline anchor scores ~conf: with a FULL final list (max_det boxes, all scoring higher) it can neither enter the list nor
+        # suppress a member of it (greedy NMS runs in score order), so it cannot change the final boxes
+        rec["borderline_below_final"] = bool(len(rb) == 300 and len(differ) > 0 and float(rs.min()) > conf + 1e-3)
         # NMS exactness: restated torchvision batched_nms on the device's own candidates (anchor order = the reference's mask order)
         xb, xs, xc = _oracle_nms_clamp(g_boxes, g_scores, g_cls, iou, 300, iw, ih)
         rec["nms_exact_on_gpu_candidates"] = bool(len(xb) == len(gb) and torch.equal(xb, gb) and torch.equal(xs, gs) and torch.equal(xc, gc))

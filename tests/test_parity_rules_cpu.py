@@ -7,7 +7,10 @@ import pytest
 import torch
 
 
-def _oracle_frame(width=0.25, seed=3):
+SEED = 9          # a frame of tools/make_weights.py::EXACT_FRAMES[(0.25, 640)] (CPU scan: no tie, margins)
+
+
+def _oracle_frame(width=0.25, seed=SEED):
     from PIL import Image
     from oracle import detector_ref as D
     from omniparser_amd.synth import synthetic_screenshot
@@ -26,7 +29,7 @@ def frame():
 def _rec(dbg, rb, rs, rc, gb, gs, gc, head_err=2e-5, noise=None):
     import gpu_checks as G
     n = int(dbg["valid"].sum())
-    rec = {"seed": 3, "n_ref": len(rb), "n_gpu": len(gb), "input_mismatch": 0, "head_err(cls,dist)": [(head_err, head_err / 10)] * 3,
+    rec = {"seed": SEED, "n_ref": len(rb), "n_gpu": len(gb), "input_mismatch": 0, "head_err(cls,dist)": [(head_err, head_err / 10)] * 3,
            "oracle_noise(cls,dist,gpu_vs_f64)": noise or [], "cand_ref": n, "cand_gpu": n, "near_ties": int(dbg["near_ties"]),
            "score_ties": int(dbg["score_ties"]), "cand_same_anchors": True, "cand_same_classes": True, "cand_max_score_diff": 1e-6,
            "cand_max_box_diff_px": 2e-4, "nms_exact_on_gpu_candidates": True}
@@ -36,7 +39,7 @@ def _rec(dbg, rb, rs, rc, gb, gs, gc, head_err=2e-5, noise=None):
 def test_listed_frame_is_tie_free_and_rules_accept_rounding_noise(frame):
     import gpu_checks as G
     from tools.make_weights import EXACT_FRAMES
-    assert 3 in EXACT_FRAMES[(0.25, 640)]
+    assert SEED in EXACT_FRAMES[(0.25, 640)]
     img, rb, rs, rc, dbg = frame
     assert dbg["near_ties"] == 0 and dbg["score_ties"] == 0 and len(rb) > 50
     g = torch.Generator().manual_seed(0)
@@ -62,7 +65,7 @@ def test_rules_reject_real_defects(frame):
     gc = rc.clone(); gc[3] += 1
     with pytest.raises(AssertionError):
         G.assert_detector_frame(_rec(dbg, rb, rs, rc, rb, rs, gc), exact=True)
-    # head tensors beyond the fixed epsilon without an oracle noise figure that explains it
+    # head tensors beyond the fixed epsilon
     with pytest.raises(AssertionError):
         G.assert_detector_frame(_rec(dbg, rb, rs, rc, rb, rs, rc, head_err=5e-3))
     # NMS not exact on the device's own candidates
@@ -78,15 +81,23 @@ def test_rules_reject_real_defects(frame):
 def test_rules_on_ill_conditioned_or_tied_frames(frame):
     import gpu_checks as G
     img, rb, rs, rc, dbg = frame
-    # oracle noise 1e-3 (f32 vs f64), device error 3x that: accepted, but never as an `exact` frame; final boxes may be re-phased
+    # head tensors beyond the fixed epsilon are a failure at every input size: since the v5 stand-in the oracle's own f32-vs-f64
+    # difference is <= 3e-5 everywhere, and a figure for it no longer buys a looser bound
     noise = [(1e-3, 1e-4, 2e-3)] * 3
-    rec = _rec(dbg, rb, rs, rc, rb[: len(rb) - 3], rs[: len(rb) - 3], rc[: len(rb) - 3], head_err=3e-3, noise=noise)
+    with pytest.raises(AssertionError):
+        G.assert_detector_frame(_rec(dbg, rb, rs, rc, rb, rs, rc, head_err=3e-3, noise=noise))
+    # an anchor whose oracle logit sits within the head epsilon of the threshold fell on the other side: the frame cannot be `exact`,
+    # and against the oracle's final list only the count is bounded (the extra / missing candidate takes part in NMS) ...
+    rec = _rec(dbg, rb, rs, rc, rb[: len(rb) - 2], rs[: len(rb) - 2], rc[: len(rb) - 2]); rec["cand_borderline"] = 1
     G.assert_detector_frame(rec)
     with pytest.raises(AssertionError):
         G.assert_detector_frame(rec, exact=True)
-    # ...but 8x the noise is the limit
+    # ... unless the final list is full and the anchor scores far below it (1088x1920 inputs): then the final boxes must still be the oracle's
+    rec = _rec(dbg, rb, rs, rc, rb, rs, rc); rec.update(cand_borderline=2, borderline_below_final=True)
+    G.assert_detector_frame(rec, exact=True)
+    rec = _rec(dbg, rb, rs, rc, rb[1:], rs[1:], rc[1:]); rec.update(cand_borderline=2, borderline_below_final=True)
     with pytest.raises(AssertionError):
-        G.assert_detector_frame(_rec(dbg, rb, rs, rc, rb, rs, rc, head_err=9e-3, noise=noise))
+        G.assert_detector_frame(rec, exact=True)
     # a tie in the oracle's NMS: its own final list changes by up to 10 boxes under a 1e-6 perturbation of its candidates, so against
     # that list only the count is bounded — identical candidates and the bit-exact NMS on them remain mandatory
     tied = dict(dbg); tied["score_ties"] = 1
@@ -122,7 +133,7 @@ def test_bench_path_element_rules(frame):
     from omniparser_amd.synth import synthetic_ocr
     img, rb, rs, rc, dbg = frame
     sp = ScreenParser(None, None, processor=object())
-    texts, obox = synthetic_ocr(3, 1920, 1080, 40)
+    texts, obox = synthetic_ocr(SEED, 1920, 1080, 40)
     el_r, cr_r = sp.glue(rb, 1920, 1080, obox, texts)
     assert len(cr_r) > 20
 

@@ -29,7 +29,14 @@ DETECTOR_STANDIN = "v5"
 # times the GPU-vs-oracle differences (scores ~1e-6, boxes ~2e-4 px, logits ~2e-5).  On these frames the parity tests demand the
 # oracle's boxes one for one and fail if the oracle on the test box disagrees that they are tie-free.
 # Scan: tools/scan_parity_frames.py -> profiles/r5_parity_frame_scan.md.  Re-scan whenever build_random_detector or synth.py changes.
-EXACT_FRAMES = {(1.0, 640): (), (0.5, 640): (), (0.25, 640): (), (0.25, 320): (), (1.0, "native"): (), (0.25, "native"): ()}
+# Every listed seed is >= 8 (the calibration batch holds seeds 0..7 at 640x640) except where the frame SIZE differs from the calibration's.
+EXACT_FRAMES = {(1.0, 640): (14, 18), (0.5, 640): (14, 18), (0.25, 640): (9, 10), (0.25, 320): (8, 9), (1.0, "native"): (8, 12),
+                (0.25, "native"): (8, 9)}
+# configs[4]: the 3840x2160 frame on which the tiled policy (2x2 tiles -> global NMS) is tie-free in all four tiles and in the merge (half width)
+TILED_EXACT_SEED = 4
+# configs[3]: (w, h, seed) per resolution of stream.RESOLUTION_MIX, two frames at the most frequent size first (one device batch of two)
+STREAM_FRAMES = ((2560, 1440, 12), (2560, 1440, 14), (3840, 2160, 8), (1920, 1080, 14), (2880, 1800, 10), (3456, 2234, 13), (5120, 2880, 8),
+                 (2560, 1600, 20))
 # frames the scan found well conditioned (ties or not): candidate sets must be identical there, final boxes up to the tie rules
 WELL_FRAMES = {(1.0, 640): tuple(range(8)), (0.5, 640): tuple(range(8)), (0.25, 640): (0, 1, 2, 3), (0.25, 320): (0, 1, 2, 3)}
 

@@ -27,8 +27,11 @@ from tools.make_weights import ensure_blob                # noqa: E402
 THR_MARGIN, IOU_MARGIN, SCORE_GAP = 1e-4, 3e-5, 9e-6      # several times the GPU-vs-oracle differences (logits 2e-5, boxes 2e-4 px, scores 1e-6)
 
 
-def passes(r):
-    return r["near_ties"] == 0 and r["score_ties"] == 0 and r["thr_margin"] >= THR_MARGIN and r["iou_margin"] >= IOU_MARGIN and r["score_gap"] >= SCORE_GAP
+def passes(r, max_det=300):
+    """a full final list (max_det boxes: 1088x1920 inputs) makes the threshold margin irrelevant — an anchor scoring ~conf can neither enter
+    the list nor suppress a member of it (tests/gpu_checks.py::assert_detector_frame, `borderline_below_final`)"""
+    thr_ok = r["thr_margin"] >= THR_MARGIN or r["boxes"] >= max_det
+    return r["near_ties"] == 0 and r["score_ties"] == 0 and thr_ok and r["iou_margin"] >= IOU_MARGIN and r["score_gap"] >= SCORE_GAP
 
 
 def main():
