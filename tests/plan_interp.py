@@ -147,6 +147,12 @@ def run_op(op, m):
             y = F.max_pool2d(x, kk, s, pad)
         else:
             y = F.interpolate(x, size=(Ho, Wo), mode="nearest")
+            if i[17] > 1:                       # CBFuse in one op: ((r(x0) + r(x1)) + ...) with every partial sum rounded to the plan's dtype
+                slots = ((19, 20, 21, 22), (23, 24, 25, 26), (27, 28, 29, 30), (7, 12, 15, 16))
+                for kx in range(i[17] - 1):
+                    Hk, Wk, ldk, cok = (i[j] for j in slots[kx])
+                    xk = m.at(p[(1, 2, 3, 5)[kx]], dt)[: B * Hk * Wk * ldk].view(B, Hk, Wk, ldk)[..., cok:cok + C].permute(0, 3, 1, 2).float()
+                    y = y.to(dt).float() + F.interpolate(xk, size=(Ho, Wo), mode="nearest")
         out = m.at(p[4], dt)[: B * Ho * Wo * ldo].view(B, Ho, Wo, ldo)
         y = y.permute(0, 2, 3, 1)
         if acc:

@@ -91,7 +91,7 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
     cap = Florence2Captioner(small_vocab_caption_checkpoint(0), "cuda", precision="f32", resolution=64)
     frames = [torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in (0, 2)]
     ocr = [synthetic_ocr(0, 640, 480, 12), ([], [])]                                  # second frame without OCR
-    kw = dict(box_threshold=0.9, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)
+    kw = dict(box_threshold=0.85, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)     # (v5 stand-in: 0.85 leaves a handful of crops)
     monkeypatch.setenv("OMNI_DEVICE_GLUE", "1")
     sp = ScreenParser(det, cap, **kw)
     sp.max_new_tokens = 1                                          # the decode loop is covered by the captioner test
@@ -117,7 +117,7 @@ def test_parse_batch_device_handoff_equals_host_handoff(emu, monkeypatch):
                 assert a["content"] == b["content"]
         assert k == len(cr)
         n_crops += k
-    assert n_crops >= 6          # one packed micro-batch spanning both frames (the seams between micro-batches: tests/test_gpu_d_pipeline.py)
+    assert 4 <= n_crops <= 40    # one packed micro-batch (or a few) spanning both frames (the seams between micro-batches: tests/test_gpu_d_pipeline.py)
 
 
 def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):

@@ -45,7 +45,7 @@ def main():
         a["n"] += 1; a["us"] += r["us"]; a["gflop"] += r["gflop"]
     print("   M      N     K  k s   n   total_us  TF/s")
     for key, a in sorted(agg.items(), key=lambda kv: -kv[1]["us"])[:40]:
-        print("%6d %5d %5d %2d %d %3d %9.1f %6.1f" % (*key, a["n"], a["us"], a["gflop"] / a["us"] * 1e-3 * 1e6 / 1e3))
+        print("%6d %5d %5d %2d %d %3d %9.1f %6.1f" % (*key, a["n"], a["us"], a["gflop"] / a["us"] * 1e3))
     for r in rows:
         if r["kind"] != "conv":
             pass
