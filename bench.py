@@ -640,7 +640,11 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
     res0 = D.predict(model, Image.fromarray(img), conf=CONF, imgsz=imgsz, iou=NMS_IOU, max_det=MAX_DET)
     t_det1 = time.perf_counter() - t0
     bx = np.asarray(res0[0], dtype=np.float64).reshape(-1, 4)
-    boxes = [(int(b[0]), int(b[1]), max(int(b[2]), int(b[0]) + 2), max(int(b[3]), int(b[1]) + 2)) for b in bx[:n]]
+    boxes = []
+    for b in bx:                                             # integer rectangles inside the frame with a positive area (the hand-off drops the rest)
+        x0, y0, x1, y1 = max(int(b[0]), 0), max(int(b[1]), 0), min(int(b[2]), IW), min(int(b[3]), IH)
+        if x1 - x0 >= 2 and y1 - y0 >= 2 and len(boxes) < n:
+            boxes.append((x0, y0, x1, y1))
     rng = np.random.default_rng(0)
     while len(boxes) < n:                                    # a frame with fewer detections than the mean: fill with icon-sized rectangles
         x, y = int(rng.integers(0, IW - 64)), int(rng.integers(0, IH - 64))

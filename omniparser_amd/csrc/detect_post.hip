@@ -15,8 +15,8 @@
 // wave64 notes: compaction uses one atomic per passing anchor (few % of anchors pass).
 // NMS, up to 2048 candidates per frame (every 640x640 input: ~1 400): ONE 1024-thread workgroup per frame (round 5,
 // nms_block_kernel) — bitonic sort of 64-bit keys (score desc, anchor asc == torch's stable descending sort) in LDS, the
-// candidates' offset boxes in LDS, then per 64-box block: wave 0 builds the block's 64x64 IoU mask in registers, resolves it
-// greedily with v_readlane, and all 16 waves apply the block's kept boxes to every later candidate; it stops at max_det keeps.
+// candidates' offset boxes in LDS, every 64-box block's own 64x64 IoU mask built by the 16 waves in parallel, then per block: wave 0
+// resolves the block greedily with v_readlane, and all 16 waves apply its kept boxes to every later candidate; it stops at max_det keeps.
 // No N x N mask in HBM, no O(N^2) rank pass, no serial chain of dependent global loads (the round-1 path cost 547 us per frame).
 // NMS, more candidates (1088x1920 inputs: ~9 000): the round-1 path — O(N^2) rank kernel, IoU predicate in 64x64 tiles into
 // 64-bit masks (one u64 per lane = one row), single-wave greedy pass that resolves a 64-box block in registers with
@@ -364,29 +364,37 @@ __global__ __launch_bounds__(1024) void nms_block_kernel(NmsArgs a) {
   __syncthreads();
   const int nblk = (n + 63) >> 6;
   const float thr = a.iou;
+  // ---- every block's own 64x64 mask, all 16 waves at once (wave w: blocks w, w + 16, ...): lane = row (the earlier, possibly kept box),
+  //      bit q = a later box of the same block it would suppress.  The key array is free now (the gather above was its last reader).
+  unsigned long long* diag = key;
+  for (int blk = wave; blk < nblk; blk += 16) {
+    const int i = blk * 64 + lane;
+    const int valid = n - blk * 64 < 64 ? n - blk * 64 : 64;
+    unsigned long long bits = 0ull;
+    const int ii = i < n ? i : n - 1;
+    const float ix1 = bx1[ii], iy1 = by1[ii], ix2 = bx2[ii], iy2 = by2[ii], iarea = bar[ii];
+    const int icl = bcl[ii];
+#pragma unroll 4
+    for (int q = 1; q < valid; ++q) {                         // uniform trip count: every lane reads the SAME column q (LDS broadcast)
+      const int j = blk * 64 + q;
+      float xx1 = fmaxf(ix1, bx1[j]);
+      float yy1 = fmaxf(iy1, by1[j]);
+      float xx2 = fminf(ix2, bx2[j]);
+      float yy2 = fminf(iy2, by2[j]);
+      float w = fmaxf(0.0f, xx2 - xx1);
+      float h = fmaxf(0.0f, yy2 - yy1);
+      float inter = w * h;
+      float ovr = inter / (iarea + bar[j] - inter);
+      if (q > lane && ovr > thr && (trick || bcl[j] == icl)) bits |= (1ull << q);
+    }
+    if (i < n) diag[i] = bits;
+  }
+  __syncthreads();
   for (int blk = 0; blk < nblk; ++blk) {
     if (wave == 0) {
       const int i = blk * 64 + lane;
       const int valid = n - blk * 64 < 64 ? n - blk * 64 : 64;
-      // this block's 64x64 mask: lane = row (the earlier, possibly kept box), bit q = a later box of the block it would suppress
-      unsigned long long bits = 0ull;
-      if (i < n) {
-        const float ix1 = bx1[i], iy1 = by1[i], ix2 = bx2[i], iy2 = by2[i], iarea = bar[i];
-        const int icl = bcl[i];
-        for (int q = lane + 1; q < valid; ++q) {
-          const int j = blk * 64 + q;
-          if (!trick && bcl[j] != icl) continue;
-          float xx1 = fmaxf(ix1, bx1[j]);
-          float yy1 = fmaxf(iy1, by1[j]);
-          float xx2 = fminf(ix2, bx2[j]);
-          float yy2 = fminf(iy2, by2[j]);
-          float w = fmaxf(0.0f, xx2 - xx1);
-          float h = fmaxf(0.0f, yy2 - yy1);
-          float inter = w * h;
-          float ovr = inter / (iarea + bar[j] - inter);
-          if (ovr > thr) bits |= (1ull << q);
-        }
-      }
+      const unsigned long long bits = i < n ? diag[i] : 0ull;
       const int total = s_total;                              // read by every lane BEFORE the wave-collective steps below; lane 0 updates it after them
       unsigned long long cur = or_reduce_wave((i < n && dead[i]) ? (1ull << lane) : 0ull);
       unsigned long long keptbits = 0ull;

@@ -153,8 +153,11 @@ class YoloV9EGraph:
         c3 = self.cout(prefix + ".cv1")
         cat = pb.alloc(x.B, x.H, x.W, 4 * c3)
         self.conv_bn(prefix + ".cv1", x, cat.slice(0, c3), 1)
-        for i in range(3):
-            pb.maxpool(cat.slice(i * c3, c3), cat.slice((i + 1) * c3, c3), 5, 1, 2)
+        if os.environ.get("OMNI_SPP_CHAIN") == "1":              # the round-1 form: three cascaded 5x5 pool launches (A/B, bit-identical)
+            for i in range(3):
+                pb.maxpool(cat.slice(i * c3, c3), cat.slice((i + 1) * c3, c3), 5, 1, 2)
+        else:
+            pb.maxpool_cascade3(cat.slice(0, c3), cat.slice(c3, 3 * c3), 5)
         return self.conv_bn(prefix + ".cv5", cat, out, 1)
 
     def cblinear(self, prefix, x: View, splits: List[int]) -> List[View]:
