@@ -81,9 +81,7 @@ enum {
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */
   OMNI_OP_AVGPOOL2 = 2,
   /* max_pool2d(k,s,p) with -inf padding (ADown k3s2p1, SPP k5s1p2).
-   *  p0 x p4 y; i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i6 k i8 stride i9 pad i10 Ho i11 Wo i13 ldo i14 out_coff
-   *  i17 = 3 (SPP in one launch; stride 1, odd k, pad k/2): y = [pool(x) | pool(pool(x)) | pool(pool(pool(x)))] in the channel slices
-   *  out_coff, out_coff + C, out_coff + 2C of p4 — windows of k, 2k - 1 and 3k - 2 taps, exact for max */
+   *  p0 x p4 y; i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i6 k i8 stride i9 pad i10 Ho i11 Wo i13 ldo i14 out_coff */
   OMNI_OP_MAXPOOL = 3,
   /* nearest-neighbour resize (F.interpolate mode='nearest') of a channel slice,
    * either overwriting or accumulating into y (Upsample, CBFuse).

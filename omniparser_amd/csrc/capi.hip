@@ -105,8 +105,7 @@ static void op_extents(const omni_op_t* op, long long ext[8]) {
     }
     case OMNI_OP_AVGPOOL2: case OMNI_OP_MAXPOOL: case OMNI_OP_RESIZE_NEAREST: {
       const long long B = i[0], Ho = op->kind == OMNI_OP_AVGPOOL2 ? i[1] - 1 : i[10], Wo = op->kind == OMNI_OP_AVGPOOL2 ? i[2] - 1 : i[11];
-      ext[0] = span(B * i[1] * i[2], i[4], i[5], i[3]);
-      ext[4] = span(B * Ho * Wo, i[13], i[14], (op->kind == OMNI_OP_MAXPOOL && i[17] == 3) ? 3ll * i[3] : i[3]);
+      ext[0] = span(B * i[1] * i[2], i[4], i[5], i[3]); ext[4] = span(B * Ho * Wo, i[13], i[14], i[3]);
       if (op->kind == OMNI_OP_RESIZE_NEAREST && i[17] > 1) {                      // CBFuse: sources 1..4 = p1, p2, p3, p5
         static const int pidx[4] = {1, 2, 3, 5};
         static const int base[4][4] = {{19, 20, 21, 22}, {23, 24, 25, 26}, {27, 28, 29, 30}, {7, 12, 15, 16}};

@@ -41,7 +41,7 @@ __device__ __forceinline__ int nearest_idx(int o, int out, int in) {
   return i < in - 1 ? i : in - 1;
 }
 
-template <typename T, int MODE>  // MODE 0 avgpool2 s1, 1 maxpool, 2 nearest resize, 3 sum of nearest-resized sources (CBFuse), 4 SPP cascade
+template <typename T, int MODE>  // MODE 0 avgpool2 s1, 1 maxpool, 2 nearest resize, 3 sum of nearest-resized sources (CBFuse)
 __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
   constexpr int V = ElemTraits<T>::kVec;
   const int cv = a.C / V;
@@ -87,36 +87,6 @@ __global__ __launch_bounds__(256) void pool_kernel(PoolArgs a) {
           for (int e = 0; e < V; ++e) acc[e] = fmaxf(acc[e], ElemTraits<T>::to_f32(v.v[e]));
         }
       }
-    } else if (MODE == 4) {
-      // SPP (SPPELAN of the blob: y1 = maxpool_k(x), y2 = maxpool_k(y1), y3 = maxpool_k(y2), stride 1, pad k/2, -inf padding) in ONE pass:
-      // max is exact and associative, so the cascade equals windows of k, 2k - 1 and 3k - 2 taps around the same centre; one walk over
-      // the widest window, each tap folded into the outputs whose window holds it; y_j goes to the channel slice out_coff + j * C
-      float a2[V], a3[V];
-#pragma unroll
-      for (int e = 0; e < V; ++e) { acc[e] = -INFINITY; a2[e] = -INFINITY; a3[e] = -INFINITY; }
-      const int r1 = a.k / 2, r3 = 3 * r1;
-      for (int dr = -r3; dr <= r3; ++dr) {
-        const int hi = ho + dr;
-        if (hi < 0 || hi >= a.H) continue;
-        for (int ds = -r3; ds <= r3; ++ds) {
-          const int wi = wo + ds;
-          if (wi < 0 || wi >= a.W) continue;
-          const int d = max(dr < 0 ? -dr : dr, ds < 0 ? -ds : ds);
-          Vec16<T> v = ldv<T>(xb + ((long long)hi * a.W + wi) * a.ldi);
-#pragma unroll
-          for (int e = 0; e < V; ++e) {
-            const float f = ElemTraits<T>::to_f32(v.v[e]);
-            a3[e] = fmaxf(a3[e], f);
-            if (d <= 2 * r1) a2[e] = fmaxf(a2[e], f);
-            if (d <= r1) acc[e] = fmaxf(acc[e], f);
-          }
-        }
-      }
-      Vec16<T> o2, o3;
-#pragma unroll
-      for (int e = 0; e < V; ++e) { o2.v[e] = ElemTraits<T>::from_f32(a2[e]); o3.v[e] = ElemTraits<T>::from_f32(a3[e]); }
-      stv<T>(yp + a.C, o2);
-      stv<T>(yp + 2 * a.C, o3);
     } else if (MODE == 3) {
       // CBFuse (ref blob: torch.sum(torch.stack([F.interpolate(x_i, size, 'nearest') ...]), 0)): ((s0 + s1) + s2) + ... in source order,
       // every partial sum rounded to T — bit for bit what the chain of accumulate-resize launches computed, in ONE pass over the output
@@ -201,10 +171,6 @@ int omni_launch_maxpool(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.k > 0 && a.stride > 0 && a.pad >= 0 && a.pad * 2 <= a.k, "maxpool: bad window");
   OMNI_REQUIRE(a.Ho == (a.H + 2 * a.pad - a.k) / a.stride + 1 && a.Wo == (a.W + 2 * a.pad - a.k) / a.stride + 1,
                "maxpool: Ho/Wo mismatch");
-  if (op->i[17] == 3) {                      // SPP cascade: three outputs in consecutive channel slices (include/omni_amd.h)
-    OMNI_REQUIRE(a.stride == 1 && (a.k & 1) && a.pad == a.k / 2 && a.out_coff + 3 * a.C <= a.ldo, "maxpool cascade: needs stride 1, odd k, pad k/2, 3 slices");
-    return launch<4>(op, a, s);
-  }
   return launch<1>(op, a, s);
 }
 

@@ -325,18 +325,6 @@ class PlanBuilder:
     def resize_nearest(self, x: View, out: View, accumulate=False):
         return self._pool(L.OP_RESIZE_NEAREST, x, out, accumulate=1 if accumulate else 0)
 
-    def maxpool_cascade3(self, x: View, out3: View, k):
-        """SPP in one launch: out3 (3 * x.C channels) = [maxpool_k(x) | maxpool_k^2(x) | maxpool_k^3(x)], stride 1, pad k // 2 — the three
-        cascaded pools of SPPELAN computed as windows of k, 2k - 1 and 3k - 2 taps (exact for max)."""
-        assert out3.C == 3 * x.C and (out3.B, out3.H, out3.W) == (x.B, x.H, x.W) and k % 2 == 1
-        op = L.make_op(L.OP_MAXPOOL, self.dtype, p=[x.ptr, None, None, None, out3.ptr],
-                       i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 8: 1, 9: k // 2, 10: x.H, 11: x.W,
-                          13: out3.ld, 14: out3.coff, 17: 3})
-        self.ops.append(op)
-        esz = 4 if self.dtype == L.F32 else 2
-        self.bytes += esz * 4 * x.B * x.H * x.W * x.C
-        return out3
-
     def resize_sum(self, srcs, out: View):
         """out = ((resize(s0) + resize(s1)) + ...) — CBFuse as ONE launch (OMNI_OP_RESIZE_NEAREST with i17 sources, at most 5): the same
         partial sums in the same order as a chain of accumulate-resize launches, one pass over the output instead of len(srcs)."""

@@ -16,7 +16,6 @@ their roles from the blob's own graph (program order + hyper-parameters), not fr
 """
 from typing import Dict, List
 
-import os
 import torch
 
 from . import _lib as L
@@ -153,11 +152,11 @@ class YoloV9EGraph:
         c3 = self.cout(prefix + ".cv1")
         cat = pb.alloc(x.B, x.H, x.W, 4 * c3)
         self.conv_bn(prefix + ".cv1", x, cat.slice(0, c3), 1)
-        if os.environ.get("OMNI_SPP_CHAIN") == "1":              # the round-1 form: three cascaded 5x5 pool launches (A/B, bit-identical)
-            for i in range(3):
-                pb.maxpool(cat.slice(i * c3, c3), cat.slice((i + 1) * c3, c3), 5, 1, 2)
-        else:
-            pb.maxpool_cascade3(cat.slice(0, c3), cat.slice(c3, 3 * c3), 5)
+        # three cascaded 5x5 pools.  One launch computing all three as 5 / 9 / 13-tap windows (exact for max) was built and measured in
+        # round 5: 169 taps per output instead of 75 cost more than the two launches it saved (pools of a batch-1 plan 78.8 vs 59.1 us,
+        # batch 8 190.7 vs 159.0, profiles/r5_s2_detector_per_op_*.txt) — removed
+        for i in range(3):
+            pb.maxpool(cat.slice(i * c3, c3), cat.slice((i + 1) * c3, c3), 5, 1, 2)
         return self.conv_bn(prefix + ".cv5", cat, out, 1)
 
     def cblinear(self, prefix, x: View, splits: List[int]) -> List[View]:
@@ -176,10 +175,8 @@ class YoloV9EGraph:
         """sum of nearest-resized routing tensors (the last CBFuse operand is added by the conv epilogue)."""
         pb = self.pb
         tmp = pb.alloc(srcs[0].B, H, W, srcs[0].C)
-        if os.environ.get("OMNI_CBFUSE_CHAIN") == "1":          # the round-1 form: one accumulate-resize launch per source (A/B, bit-identical)
-            for i, sv in enumerate(srcs):
-                pb.resize_nearest(sv, tmp, accumulate=i > 0)
-            return tmp
+        # one launch (round 5; the accumulate-resize chain it replaces — bit-identical, tests/gpu_checks.py::check_pools — cost 17 launches
+        # / 128.6 us per batch-1 detector pass against 7 / 48.0 us now, profiles/r5_s1_detector_per_op_b1_640.txt)
         return pb.resize_sum(srcs, tmp)
 
     # ------------------------------------------------------------ whole network

@@ -143,12 +143,6 @@ def run_op(op, m):
         x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi)[..., icoff:icoff + C].permute(0, 3, 1, 2).float()
         if k == L.OP_AVGPOOL2:
             y = F.avg_pool2d(x, 2, 1, 0, False, True); Ho, Wo = H - 1, W - 1
-        elif k == L.OP_MAXPOOL and i[17] == 3:            # SPP cascade: three outputs in consecutive channel slices
-            y1 = F.max_pool2d(x, kk, 1, kk // 2); y2 = F.max_pool2d(y1, kk, 1, kk // 2); y3 = F.max_pool2d(y2, kk, 1, kk // 2)
-            out = m.at(p[4], dt)[: B * H * W * ldo].view(B, H, W, ldo)
-            for j, yy in enumerate((y1, y2, y3)):
-                out[..., ocoff + j * C:ocoff + (j + 1) * C] = yy.permute(0, 2, 3, 1).to(dt)
-            return
         elif k == L.OP_MAXPOOL:
             y = F.max_pool2d(x, kk, s, pad)
         else:

@@ -16,6 +16,9 @@ def test_first_launch_canary():
 def test_bad_pointers_are_errors_not_faults():
     import gpu_checks as G
     seen = G.check_bad_pointers_are_errors()
+    if "skipped" in seen:
+        import pytest
+        pytest.skip(seen["skipped"])
     assert len(seen) == 8, seen
     assert "not inside any device allocation" in seen["wild/launch"] and "runs past its allocation" in seen["past_end/plan"], seen
 
