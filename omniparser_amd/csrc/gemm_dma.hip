@@ -137,11 +137,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
 // slice: +2-5 % on the K >= 512 shapes (profiles/r3_s3_gemm_bench.txt).  Measured and NOT kept (within +-5 % of this kernel, removed
 // from the library after commit f6047af; profiles/r3_s7_gemm_bench_sched2_w4.txt, r3_s8_gemm_bench_k16.txt): the barrier in front of
 // the last unit of a slice, a 4-wave 256x256 tile, a 4-wave 256x128 tile with 16-wide K slices and two blocks per CU.
-// PROD (round-5 ablation, measured and NOT adopted — DESIGN section 3d): which of the three products of a MAC are issued.  7 = all
-// (w_hi x_hi + w_lo x_hi + w_hi x_lo: f32-class accuracy); 5 = without w_lo x_hi (weights at f16 precision); 3 = without w_hi x_lo
-// (activations at f16 precision).  Only 7 is ever launched by the product; 5 / 3 exist on the 256x256 tile behind OMNI_GEMM_PRODUCTS
-// for tools/gemm_products_ablation.py.
-template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0, int PROD = 7>
+template <int BM, int BN, int WM, int WN, int NSTAGE, int ACT, bool OSPLIT, bool RES, int SCHED = 0>
 __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #if defined(__HIP_DEVICE_COMPILE__)   // the buffer-resource type / LDS-DMA builtins do not exist in the host pass (it only needs the stub)
   constexpr int NW = WM * WN;
@@ -151,9 +147,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   constexpr int STAGE = (BM + BN) * 128;
   constexpr int NP = TM / 2;                                   // token-tile pairs per wave
   constexpr int NU = 2 * NP;                                   // MFMA units per K slice: (16-wide K group, tile pair)
-  constexpr int NPROD = (PROD & 1) + ((PROD >> 1) & 1) + ((PROD >> 2) & 1);
-  static_assert((PROD & 1) && NPROD >= 2, "the hi x hi product is always issued");
-  constexpr int NM = 2 * NPROD * TN;                           // MFMAs per unit: 2 token tiles x TN channel tiles x 3 products
+  constexpr int NM = 6 * TN;                                   // MFMAs per unit: 2 token tiles x TN channel tiles x 3 products
   static_assert(TM % 2 == 0 && TN >= 1 && A_DMA >= 1 && B_DMA >= 1 && NSTAGE >= 2 && NSTAGE <= 4, "tile / wave grid mismatch");
   static_assert(BM * 128 + (TN - 1) * 4096 < 65536 && (TM - 1) * 4096 < 65536, "ds_read immediate offsets");
   __shared__ __attribute__((aligned(16))) unsigned char lds[NSTAGE * STAGE];
@@ -239,27 +233,28 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.0f;
 
-  // three products per accumulator, issued product-major so that the same accumulator recurs every 2*TN MFMAs
+  // three products per accumulator, issued product-major so that the same accumulator recurs every 2*TN MFMAs.
+  // What the third product buys (round-5 ablation on the MI355X, tools/archive/r5_gemm_products_ablation.{patch,py},
+  // profiles/r5_s2_products_ablation.jsonl): with w_lo*x_hi or w_hi*x_lo dropped on every 256x256-tile layer the GEMM family of a
+  // 128-crop encode costs 142.8 / 144.5 instead of 160.6 ms (-11 %: the kernel is power / bandwidth bound, a third fewer MFMAs is
+  // not a third less time) and the greedy caption ids change on 53 / 61 of 735 crops; restricted to the K = 2048 layers: -2 %, 32 / 24
+  // crops.  Token-exactness against the f32 CPU path needs all three; the knob was removed after the measurement.
   auto mma = [&](const AF& af, const WF& wf, int ip) {
 #pragma unroll
     for (int t = 0; t < 2; ++t)
 #pragma unroll
       for (int j = 0; j < TN; ++j)
         acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
-    if constexpr (PROD & 2) {
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.l[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
-    }
-    if constexpr (PROD & 4) {
+      for (int j = 0; j < TN; ++j)
+        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.l[j], af.h[t], acc[ip * 2 + t][j], 0, 0, 0);
 #pragma unroll
-      for (int t = 0; t < 2; ++t)
+    for (int t = 0; t < 2; ++t)
 #pragma unroll
-        for (int j = 0; j < TN; ++j)
-          acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.l[t], acc[ip * 2 + t][j], 0, 0, 0);
-    }
+      for (int j = 0; j < TN; ++j)
+        acc[ip * 2 + t][j] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wf.h[j], af.l[t], acc[ip * 2 + t][j], 0, 0, 0);
   };
 
   const int nk = a.nk;
@@ -507,7 +502,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs a) {
 #endif
 }
 
-template <int BM, int BN, int WM, int WN, int NSTAGE, int PROD = 7>
+template <int BM, int BN, int WM, int WN, int NSTAGE>
 int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.mtiles = (a.M + BM - 1) / BM;
   a.ntiles = a.N / BN;
@@ -516,7 +511,7 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
   constexpr int SCHED = (BM == 256 && BN == 256) ? 1 : 0;      // front-loaded DMA issue on the 256x256 tile (see gemm_dma_kernel)
-#define OMNI_GD(ACT_, OS_, RES_) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED, PROD>), grid, block, 0, s, a)
+#define OMNI_GD(ACT_, OS_, RES_) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED>), grid, block, 0, s, a)
   if (act == OMNI_ACT_NONE && !osplit && !res) OMNI_GD(OMNI_ACT_NONE, false, false);
   else if (act == OMNI_ACT_NONE && !osplit && res) OMNI_GD(OMNI_ACT_NONE, false, true);
   else if (act == OMNI_ACT_NONE && osplit && !res) OMNI_GD(OMNI_ACT_NONE, true, false);
@@ -573,19 +568,7 @@ int omni_launch_gemm_dma(const omni_op_t* op, hipStream_t s) {
     else if (!strcmp(e, "256x256") && a.N % 256 == 0) tile = 0;
   }
   int rc;
-  // ablation knob (tools/gemm_products_ablation.py; never set by the product): OMNI_GEMM_PRODUCTS = 5 | 3 drops one of the three products
-  // on the 256x256 tile for layers with K >= OMNI_GEMM_PRODUCTS_MINK (default 0)
-  int prod = 7;
-  if (tile == 0) {
-    if (const char* e = getenv("OMNI_GEMM_PRODUCTS")) {
-      const char* mk = getenv("OMNI_GEMM_PRODUCTS_MINK");
-      const int p = atoi(e);
-      if ((p == 5 || p == 3) && a.K >= (mk ? atoi(mk) : 0)) prod = p;
-    }
-  }
-  if (tile == 0 && prod == 5) rc = launch_tile<256, 256, 2, 4, 2, 5>(a, act, osplit, s);
-  else if (tile == 0 && prod == 3) rc = launch_tile<256, 256, 2, 4, 2, 3>(a, act, osplit, s);
-  else if (tile == 0) rc = launch_tile<256, 256, 2, 4, 2>(a, act, osplit, s);
+  if (tile == 0) rc = launch_tile<256, 256, 2, 4, 2>(a, act, osplit, s);
   else if (tile == 1) rc = launch_tile<256, 128, 4, 2, 3>(a, act, osplit, s);
   else rc = launch_tile<128, 128, 2, 2, 2>(a, act, osplit, s);
   if (rc) return rc;

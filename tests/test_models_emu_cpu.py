@@ -141,7 +141,9 @@ def test_parse_stream_pipeline_equals_parse_batch(emu, monkeypatch):
         key = (x.sum((1, 2, 3)) * 977.0 + x[:, ::7, ::5].sum((1, 2, 3)) * 131.0).abs()
         return torch.stack([torch.full((n,), 0, dtype=torch.long), 100 + (key.long() % 40000), torch.full((n,), 2, dtype=torch.long)], 1).int()
     monkeypatch.setattr(cap, "_run", fingerprint)
-    sp = ScreenParser(det, cap, box_threshold=0.5, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=8)
+    # one micro-batch per batch (batch_size 32 >= the crops of two frames): more would take the MERGED decode — real decoder kernels on
+    # the emulation, minutes — which test_merged_decode_equals_per_micro_batch_decode covers on its own
+    sp = ScreenParser(det, cap, box_threshold=0.5, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=320, batch_size=32)
     batches = [([torch.from_numpy(synthetic_screenshot(s, 640, 480)) for s in seeds], [synthetic_ocr(s, 640, 480, 10) for s in seeds])
                for seeds in ((0, 1), (2,), (3, 0))]
     want, crops_want = [], []
