@@ -121,7 +121,7 @@ def test_detector_full_width_boxes_native():
     from tools.make_weights import EXACT_FRAMES
     exact = EXACT_FRAMES[(1.0, "native")]
     assert len(exact) >= 1
-    out, det = G.check_detector(width=1.0, image_seeds=exact[:2] + (0,), imgsz=(1080, 1920))
+    out, det = G.check_detector(width=1.0, image_seeds=exact[:1] + (0,), imgsz=(1080, 1920))      # (each frame costs ~12 s of CPU oracle)
     for rec in out["images"]:
         G.assert_detector_frame(rec, exact=rec["seed"] in exact)
     print(out)
