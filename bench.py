@@ -671,7 +671,7 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
         cap.generate(input_ids=ids, pixel_values=pix, max_new_tokens=20, num_beams=1, do_sample=False)
     t_cap = time.perf_counter() - t1
     whole = t_det1 + t_cap
-    c0 = ROOT / "profiles" / "r4_s4_configs0.json"
+    c0 = next((f for f in (ROOT / "profiles" / "r5_s3_configs0.json", ROOT / "profiles" / "r4_s4_configs0.json") if f.exists()), ROOT / "profiles" / "r5_s3_configs0.json")
     if c0.exists():
         # BASELINE configs[0] measured WHOLE in a separate session (tools/configs0.py: the reference's demo_image.jpg, ONE full CPU pass of
         # every crop at 768x768 vs Omniparser.parse on the MI355X) — quoted from the committed record, not measured by this run
@@ -680,7 +680,7 @@ def cpu_baseline(args, blob, imgsz, mean_crops):
             res["configs0_measured_separately"] = {"cpu_seconds_per_image": d0["cpu_reference_equivalent"]["seconds_per_image"],
                                                    "mi355x_seconds_per_image": d0["mi355x"]["seconds_per_image"], "image": d0["image"],
                                                    "size": d0["size"], "captions_identical": d0["agreement"]["captions_identical"],
-                                                   "source": "profiles/r4_s4_configs0.json"}
+                                                   "source": "profiles/" + c0.name}
         except Exception:                                   # noqa: BLE001 — an optional citation
             pass
     res.update(value=round(1.0 / whole, 5), seconds_per_screenshot=round(whole, 2),

@@ -409,6 +409,16 @@ def check_pools(dtype=L.F32, seed=0):
     w2 = (srcs_t[0].to(tdt) + F.interpolate(srcs_t[1], size=(24, 40), mode="nearest").to(tdt)).float()
     res["cbfuse2_slice"] = (o9.slice(V, 2 * V).torch().cpu() - w2).abs().max().item()
     assert (o9.t[..., :V] == 0).all() and (o9.t[..., 3 * V:] == 0).all()
+    tol = 1e-6 if dtype == L.F32 else 2e-3
+    r1 = F.avg_pool2d(x[:, V:3 * V], 2, 1, 0, False, True)
+    res["avgpool"] = (o1.torch().cpu() - r1).abs().max().item()
+    r2 = F.max_pool2d(x[:, :2 * V], 3, 2, 1)
+    res["maxpool3"] = (o2.slice(V, 2 * V).torch().cpu() - r2).abs().max().item()
+    assert (o2.t[..., :V] == 0).all()
+    res["maxpool5"] = (o3.torch().cpu() - F.max_pool2d(x, 5, 1, 2)).abs().max().item()
+    res["up2"] = (o4.torch().cpu() - F.interpolate(x, size=(26, 36), mode="nearest")).abs().max().item()
+    res["up4acc"] = (o5.torch().cpu() - (1.0 + F.interpolate(x, size=(52, 72), mode="nearest"))).abs().max().item()
+    res["ident"] = (o6.torch().cpu() - x).abs().max().item()
     for k, v in res.items():
         assert v <= tol, f"pool op {k}: err {v}"
     return res

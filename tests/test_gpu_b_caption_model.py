@@ -99,4 +99,4 @@ def test_captioner_f16_token_match_rate_r64():
     out, _ = G.check_captioner(R=64, n=16, precision="f16")
     print({k: out[k] for k in ("tokens_match", "feat_rel_err", "enc_rel_err", "ids_equal")})
     assert out["enc_rel_err"] < 5e-2, out
-    assert out["tokens_match"] >= 0.3, out
+    assert out["tokens_match"] >= 0.8, out          # measured 0.985 on the MI355X (profiles/r5_s3_f16_rate.txt); a broken f16 path scores < 0.2
