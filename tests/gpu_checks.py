@@ -1324,8 +1324,9 @@ class _OracleCaptioner:
 
     UNCHECKED = [2, 0, 2]          # ids of a crop beyond `max_crops` (decodes to the empty caption; real captions of the stand-in never do)
 
-    def __init__(self, model, R, max_crops=None):
-        self.model, self.R, self.max_crops = model, R, max_crops
+    def __init__(self, model, R, max_crops=None, use_cache=True):
+        """use_cache=False: every row is computed live and nothing is recorded — for tools that TIME the CPU pipeline (tools/configs0.py)."""
+        self.model, self.R, self.max_crops, self.use_cache = model, R, max_crops, use_cache
         self.cache = None
         self.device = torch.device("cpu")
         self.config = type("C", (), {"name_or_path": "florence-oracle", "model_type": "florence2"})()
@@ -1349,7 +1350,7 @@ class _OracleCaptioner:
             pv = PR.caption_pixel_values(img, b, self.R, CLIP_MEAN, CLIP_STD)
             key = OC.row_key(pv, self.R, max_new_tokens)
             keys.append(key)
-            hit = self.cache.get(key)
+            hit = self.cache.get(key) if self.use_cache else None
             if hit is not None:
                 rows[k] = (hit["ids"], float("inf") if hit["margin"] is None else hit["margin"])
             else:
@@ -1375,8 +1376,10 @@ class _OracleCaptioner:
                 row = seq[b].tolist()
                 eos = next((t for t in range(1, len(row)) if row[t] == 2), len(row) - 1)      # position 0 is the decoder start token (2)
                 rows[k] = (row[:eos + 1], m)
-                self.cache.put(keys[k], rows[k][0], m)
-        self.cache.flush()
+                if self.use_cache:
+                    self.cache.put(keys[k], rows[k][0], m)
+        if self.use_cache:
+            self.cache.flush()
         self.margins = [m for _, m in rows]
         T = max([len(r) for r, _ in rows] + [len(self.UNCHECKED)])
         res = torch.full((n_all, T), 1, dtype=torch.long)

@@ -64,7 +64,7 @@ def main():
     import gpu_checks as G
     from oracle import detector_ref as D
     cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
-    ocap = G._OracleCaptioner(build_random_captioner(0), 768)
+    ocap = G._OracleCaptioner(build_random_captioner(0), 768, use_cache=False)      # a timed CPU pass: never served from the oracle cache
     proc = U.FlorenceProcessor(cdir)
 
     class _Det:
