@@ -29,7 +29,7 @@ extern "C" {
 #endif
 
 /* 2 (round 5): omni_stream_create / omni_stream_destroy / omni_plan_run_split and omni_debug_host_op are gone; OMNI_OP_ATTN_ROWS i17,
- * OMNI_OP_CHAN_ATTN i7 and OMNI_OP_CONV p6 / i22 are ignored; OMNI_OP_NMS sorts candidates inside the op.  A host compiled against
+ * OMNI_OP_CHAN_ATTN i7 and OMNI_OP_CONV p6 are ignored (i22 / i23 = tile / split-K override); OMNI_OP_NMS sorts candidates inside the op.  A host compiled against
  * version 1 must be rebuilt: omni_abi_version() is what it checks at load time (omniparser_amd/_lib.py does). */
 #define OMNI_ABI_VERSION 2
 
@@ -75,7 +75,9 @@ enum {
    *           BOTH operands are "format B" f16 pairs — a 16-channel group is 64 bytes, 16 hi halves then 16 lo halves,
    *           value = hi + lo (4 bytes per element, same strides as f32) — x written that way by its producer
    *           (OMNI_OP_LAYERNORM i6, this op's i21, OMNI_OP_SPLIT_CONVERT), w = split(W * 2^k) with f1 = 2^-k;
-   *           i21 = 1: write y in format B as well (bias + activation applied first; no residual) */
+   *           i21 = 1: write y in format B as well (bias + activation applied first; no residual)
+   *  i22 / i23 (i20 = 1 only; 0 = the launcher's heuristic): output tile (1 = 64x64, 2 = 128x64, 3 = 128x128) and split-K count
+   *           (1 = no split, no reduce launch) — the per-shape choices of a tuning table; the sums differ only in the order of the K partials */
   OMNI_OP_CONV = 1,
   /* avg_pool2d(k=2,s=1,p=0) (ADown, ref blob T1).  p0 x, p4 y.
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */

@@ -563,7 +563,12 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
   }
 }
 
-void launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s) {
+// force_tile / force_splits (OMNI_OP_CONV i22 / i23, 0 = the heuristic below): the per-shape choices of the committed tuning table
+// (omniparser_amd/conv_tuning_gfx950.json, measured by tools/conv_autotune.py as serialized graph replays on the MI355X).  The heuristic
+// aims at >= 512-768 workgroups; for the latency-bound layers of a batch-1 detector pass (M = 400 ... 6 400: a kernel costs 5-13 us
+// whatever it computes, and every split-K conv is followed by a ~5.5 us reduce launch — 24 % of the pass in round 5's kernel trace)
+// fewer, longer blocks without the reduce are often faster.  Any choice gives the same sums up to the order of the K partials.
+int launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s, int force_tile, int force_splits) {
   a.cin_tiles = a.Cin / 32;
   a.ktiles = a.K / 32;
   // 128x128 at 2 waves/SIMD is the fastest split tile (measured 171-207 TF/s vs 128-165 for 128x64); the
@@ -572,13 +577,22 @@ void launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s) {
   auto blocks = [&](int m, int n) { return (long long)((a.M + m - 1) / m) * ((a.Cout + n - 1) / n); };
   if (blocks(bm, bn) < 512 && bn == 128) bn = 64;
   if (blocks(bm, bn) < 512) bm = 64;
+  if (force_tile) {
+    OMNI_REQUIRE(force_tile >= 1 && force_tile <= 3, "conv: bad tile code %d (1 = 64x64, 2 = 128x64, 3 = 128x128)", force_tile);
+    bm = force_tile == 1 ? 64 : 128;
+    bn = force_tile == 3 ? 128 : 64;
+  }
   long long nb = blocks(bm, bn);
   a.splits = 1;
-  if (nb < 512 && a.ws) {
+  const long long cap = a.ws ? ws_bytes / ((long long)a.M * a.Cout * 4) : 1;
+  if (force_splits) {
+    OMNI_REQUIRE(force_splits >= 1 && force_splits <= 64, "conv: bad split count %d", force_splits);
+    a.splits = force_splits > a.ktiles ? a.ktiles : force_splits;
+    if (a.splits > cap) a.splits = (int)(cap < 1 ? 1 : cap);
+  } else if (nb < 512 && a.ws) {
     int want = (int)((768 + nb - 1) / nb);
     int maxs = a.ktiles / 4;
     if (maxs > 32) maxs = 32;
-    long long cap = ws_bytes / ((long long)a.M * a.Cout * 4);
     if (maxs > cap) maxs = (int)cap;
     a.splits = want < maxs ? want : maxs;
     if (a.splits < 2) a.splits = 1;
@@ -588,6 +602,7 @@ void launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s) {
   if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
   else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);
   else launch_split_cfg<64, 64>(a, s);
+  return OMNI_OK;
 }
 
 template <typename T, int BM, int BN, int RB>
@@ -698,7 +713,8 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   a.K = a.KH * a.KW * a.Cin;
   if (op->i[20]) {        // split-f16 weights ([Cout][K/16][16 hi | 16 lo]) + f32 activations
     OMNI_REQUIRE(op->dtype == OMNI_F32 && a.Cin % 32 == 0, "conv: split-f16 mode needs f32 activations and Cin %% 32 == 0");
-    launch_split(a, ws_bytes, s);
+    int rc = launch_split(a, ws_bytes, s, op->i[22], op->i[23]);
+    if (rc) return rc;
   } else if (op->dtype == OMNI_F32) launch_typed<float>(a, ws_bytes, s);
   else launch_typed<half_t>(a, ws_bytes, s);
   OMNI_HIP_CHECK(hipGetLastError());

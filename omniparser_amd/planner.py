@@ -87,6 +87,11 @@ def live_tensors():
     return sorted(out, key=lambda r: r[0])
 
 
+def conv_key(M, N, K, k, s) -> str:
+    """key of a conv shape in a tuning table: rows x output channels x reduction length, kernel size, stride"""
+    return f"{M}x{N}x{K}k{k}s{s}"
+
+
 class PlanBuilder:
     workspace_on_host = False    # plans on CPU tensors get no split-K workspace (the plan interpreter needs none); the host emulation
                                  # of the kernels (tests/emu) sets it so that split-K launches are what the MI355X runs
@@ -102,6 +107,7 @@ class PlanBuilder:
         self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
+        self.conv_tuning = None  # {conv_key: (tile code, split-K count)} for the split-f16 conv kernel, or None = the launcher's heuristic
         self.reuse = False       # lifetime reuse of released scratch tensors (see `release`)
         self._free, self._released, self._pins = [], set(), []
         self.reused_bytes = 0    # bytes handed out from released tensors instead of fresh allocations
@@ -257,6 +263,10 @@ class PlanBuilder:
             assert b.numel() == cout
         if self.ws is None and (self.device.type == "cuda" or self.workspace_on_host):
             self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
+        # tile / split-K override of the split-f16 conv kernel from the plan's tuning table (None: the launcher's heuristic)
+        tune = (0, 0)
+        if wfmt == 1 and self.conv_tuning:
+            tune = tuple(self.conv_tuning.get(conv_key(x.B * Ho * Wo, cout, k * k * x.C, k, s), (0, 0)))
         op = L.make_op(
             L.OP_CONV, self.dtype,
             p=[x.ptr, w_packed.data_ptr(), b.data_ptr() if b is not None else None,
@@ -264,7 +274,8 @@ class PlanBuilder:
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
-               19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0},
+               19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0,
+               22: tune[0], 23: tune[1]},
             f={0: scale, 1: getattr(w_packed, "omni_oscale", 0.0) if wfmt == 2 else 0.0})
         self.ops.append(op)
         self.keep.append(w_packed)

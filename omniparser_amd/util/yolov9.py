@@ -46,6 +46,24 @@ def _precision_from_env(precision):
     return L.F32 if precision == "f32" else L.F16
 
 
+_CONV_TUNING = "unset"
+
+
+def conv_tuning():
+    """The committed tuning table of the detector's split-f16 convolutions (`omniparser_amd/conv_tuning_gfx950.json`, written by
+    tools/conv_autotune.py from serialized graph replays on the MI355X): {shape key: [tile code, split-K count]}.  OMNI_CONV_TUNING=0
+    turns it off (A/B), a missing file means the launcher's heuristic everywhere.  Tuning changes which K partials are summed in which
+    order, nothing else; it is applied to the detector only (the captioner's plans of different capacities stay bit-identical)."""
+    global _CONV_TUNING
+    if _CONV_TUNING == "unset":
+        import json
+        path = Path(__file__).resolve().parents[1] / "conv_tuning_gfx950.json"
+        _CONV_TUNING = None
+        if os.environ.get("OMNI_CONV_TUNING", "1") != "0" and path.exists():
+            _CONV_TUNING = {k: tuple(v) for k, v in json.loads(path.read_text())["choices"].items()}
+    return _CONV_TUNING
+
+
 class _DetectPlan:
     """Everything one (image size, network size, thresholds) configuration needs."""
 
@@ -56,6 +74,7 @@ class _DetectPlan:
         pad_left, pad_top = (tw - rw) // 2, (th - rh) // 2
         self.geom = (tw, th, scale, rw, rh, pad_left, pad_top)
         pb = PlanBuilder(det.device, det.dtype)
+        pb.conv_tuning = conv_tuning()               # per-shape tile / split-K choices measured on the MI355X (None: the launcher's heuristic)
         self.pb = pb
         self.batch = batch
         V = pb.V

@@ -52,6 +52,11 @@ CONV_CASES = [
 ]
 
 
+def mask_of(ld, off, c):
+    m = torch.ones(ld, dtype=torch.bool); m[off:off + c] = False
+    return m
+
+
 def check_conv(dtype=L.F32, seed=0, cases=None):
     g = torch.Generator().manual_seed(seed)
     tdt = torch.float32 if dtype == L.F32 else torch.float16
@@ -87,6 +92,18 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
         _sync()
         got = ov.torch().cpu().double()
         e = rel_err(got, ref)
+        if pb.ops[0].i[20] == 1:
+            # tile / split-K overrides of the tuning table (OMNI_OP_CONV i22 / i23): every combination computes the same sums up to the
+            # order of the K partials — same tolerance against the f64 reference, and splits = 1 equals the heuristic's no-split result
+            for tile, splits in ((1, 1), (2, 3), (3, 2), (1, 8), (3, 1), (2, 64)):
+                op = pb.ops[0]
+                op.i[22], op.i[23] = tile, splits
+                ov.t.fill_(7.0)
+                L.launch(op); _sync()
+                e2 = rel_err(ov.torch().cpu().double(), ref)
+                assert e2 < (2e-5 if dtype == L.F32 else 4e-3), f"conv case {case} with tile {tile} / splits {splits}: rel err {e2:.3e}"
+                assert (ov.t.float().cpu()[..., mask_of(old, ooff, Cout)] == 7.0).all(), f"override {tile}/{splits} wrote outside its slice: {case}"
+            op.i[22], op.i[23] = 0, 0
         # untouched channels of the output buffer must keep their fill value
         full = ov.t.float().cpu()
         mask = torch.ones(old, dtype=torch.bool); mask[ooff:ooff + Cout] = False
