@@ -429,3 +429,37 @@ def test_build_staleness_is_decided_by_content_not_mtime(tmp_path):
     # the shipped library carries a stamp that matches the tree it was built from
     hdrs = list(B.CSRC.glob("*.h")) + [B.PKG.parent / "include" / "omni_amd.h"]
     assert B.LIB.exists() and not B._stale(B.LIB, B.sources() + hdrs)
+
+
+def test_conv_tuning_table_is_well_formed_and_reaches_the_op_descriptors(monkeypatch):
+    """omniparser_amd/conv_tuning_gfx950.json (tools/conv_autotune.py): every entry is a shape key `MxNxKk<k>s<s>` with a tile code 1..3
+    and a split-K count 1..64; a PlanBuilder that carries the table writes the choice into OMNI_OP_CONV i22 / i23 of a matching
+    split-f16 conv and leaves every other conv on the launcher's heuristic (0, 0)."""
+    import json
+    import re
+    import torch
+    from omniparser_amd.planner import PlanBuilder, View, conv_key
+    from omniparser_amd.util import yolov9 as Y
+    table = json.loads((ROOT / "omniparser_amd" / "conv_tuning_gfx950.json").read_text())["choices"]
+    assert len(table) >= 20
+    for k, (tile, splits) in table.items():
+        assert re.fullmatch(r"\d+x\d+x\d+k[13]s[12]", k), k
+        assert tile in (1, 2, 3) and 1 <= splits <= 64, (k, tile, splits)
+    monkeypatch.setattr(Y, "_CONV_TUNING", "unset")
+    assert Y.conv_tuning() == {k: tuple(v) for k, v in table.items()}
+    monkeypatch.setenv("OMNI_CONV_TUNING", "0")
+    monkeypatch.setattr(Y, "_CONV_TUNING", "unset")
+    assert Y.conv_tuning() is None
+    monkeypatch.setattr(Y, "_CONV_TUNING", "unset")
+    # a 1x1 conv of 20 x 20 pixels, 128 -> 128 channels: key 400x128x128k1s1
+    pb = PlanBuilder("cpu", L.F32)
+    pb.split = True
+    pb.conv_tuning = {conv_key(400, 128, 128, 1, 1): (3, 2)}
+    x = View(torch.zeros(1, 20, 20, 128), 0, 128)
+    o1, o2 = pb.alloc(1, 20, 20, 128), pb.alloc(1, 10, 10, 128)
+    w = pb.pack_weight(torch.randn(128, 128, 1, 1))
+    pb.conv(x, w, None, o1, 1)
+    w3 = pb.pack_weight(torch.randn(128, 128, 3, 3))
+    pb.conv(x, w3, None, o2, 3, 2)
+    assert pb.ops[0].i[20] == 1 and (pb.ops[0].i[22], pb.ops[0].i[23]) == (3, 2)
+    assert (pb.ops[1].i[22], pb.ops[1].i[23]) == (0, 0)
