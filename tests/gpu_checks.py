@@ -1158,7 +1158,7 @@ def check_captioner(R=64, n=5, seed=0, precision="f32", max_new=20):
     """Florence2Captioner.generate (HIP path) vs transformers-native Florence-2 on CPU: token-exact ids."""
     import caption_checks as CC
     from omniparser_amd.florence import Florence2Captioner
-    from tools.make_weights import ensure_caption_checkpoint, build_random_captioner
+    from tools.make_weights import ensure_caption_checkpoint, shared_random_captioner as build_random_captioner
     d = ensure_caption_checkpoint(seed)
     model = build_random_captioner(seed)
     g = torch.Generator().manual_seed(11 + R)
@@ -1296,7 +1296,7 @@ def check_captioner_real_crops(R=768, n=4, seed=0, max_new=20, capacity=None, st
     from oracle import preprocess_ref as PR
     from omniparser_amd.florence import CLIP_MEAN, CLIP_STD, PROMPT_IDS, Florence2Captioner
     from omniparser_amd.synth import synthetic_screenshot
-    from tools.make_weights import CAPTION_STANDIN, build_random_captioner, ensure_caption_checkpoint, standin_scale
+    from tools.make_weights import CAPTION_STANDIN, shared_random_captioner as build_random_captioner, ensure_caption_checkpoint, standin_scale
     import caption_checks as CC
     d = ensure_caption_checkpoint(0, standin or CAPTION_STANDIN)
     img = synthetic_screenshot(seed, 1920, 1080)
@@ -1413,7 +1413,7 @@ def oracle_end_to_end(img, blob, proc, R, max_crops, kw):
     import types
     from oracle import detector_ref as D
     from omniparser_amd.util import utils as U
-    from tools.make_weights import build_random_captioner
+    from tools.make_weights import shared_random_captioner as build_random_captioner
     cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
     rb, rs, rc = D.predict(cpu_model, img, conf=0.05, imgsz=640, iou=0.1)
 
@@ -1437,7 +1437,7 @@ def check_end_to_end(width=0.5, R=64, image_seed=1, max_crops_checked=None, iw=1
     from omniparser_amd.florence import Florence2Captioner
     from omniparser_amd.util import utils as U
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import build_random_captioner, ensure_blob, ensure_caption_checkpoint
+    from tools.make_weights import shared_random_captioner as build_random_captioner, ensure_blob, ensure_caption_checkpoint
     blob = ensure_blob(seed=0, nc=1, width=width)
     cdir = ensure_caption_checkpoint(0)
     det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")
@@ -1494,7 +1494,7 @@ def check_tiled_captions(width=0.5, R=64, image_seed=4, iw=3840, ih=2160, micro_
     from omniparser_amd.pipeline import ScreenParser
     from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import build_random_captioner, ensure_blob, ensure_caption_checkpoint
+    from tools.make_weights import shared_random_captioner as build_random_captioner, ensure_blob, ensure_caption_checkpoint
     det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=width), device="cuda", precision="f32")
     cap = Florence2Captioner(ensure_caption_checkpoint(0), "cuda", precision="f32", resolution=R)
     img = synthetic_screenshot(image_seed, iw, ih)
@@ -1607,7 +1607,7 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     from omniparser_amd.pipeline import ScreenParser
     from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import build_random_captioner, ensure_blob, ensure_caption_checkpoint
+    from tools.make_weights import shared_random_captioner as build_random_captioner, ensure_blob, ensure_caption_checkpoint
     IW, IH = 1920, 1080
     blob = ensure_blob(seed=0, nc=1, width=width)
     cdir = ensure_caption_checkpoint(0)
@@ -1862,7 +1862,7 @@ def check_stream_parity(R=64, batch=2, chunk=4, min_margin=1e-3, n_frames=None):
     from omniparser_amd.pipeline import ScreenParser
     from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util.yolov9 import YOLOv9Detector
-    from tools.make_weights import build_random_captioner, ensure_blob, ensure_caption_checkpoint
+    from tools.make_weights import shared_random_captioner as build_random_captioner, ensure_blob, ensure_caption_checkpoint
     os.environ.setdefault("OMNI_MAX_DETECT_PLANS", "16")
     blob = ensure_blob(seed=0, nc=1, width=1.0)
     det = YOLOv9Detector(model_path=blob, device="cuda", precision="f32")

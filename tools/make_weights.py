@@ -150,6 +150,18 @@ def build_random_captioner(seed=0, init_std=0.06, chan_qk_scale=CHAN_QK_SCALE):
     return model.eval()
 
 
+_CAPTIONERS = {}
+
+
+def shared_random_captioner(seed=0, init_std=0.06, chan_qk_scale=CHAN_QK_SCALE):
+    """One instance per (seed, init_std, scale) and process: building the 230 M-parameter stand-in costs 10-20 s of CPU, and a test
+    process asks for the same read-only oracle model a dozen times (tests/gpu_checks.py).  Callers must not modify it."""
+    key = (seed, init_std, chan_qk_scale)
+    if key not in _CAPTIONERS:
+        _CAPTIONERS[key] = build_random_captioner(seed, init_std, chan_qk_scale)
+    return _CAPTIONERS[key]
+
+
 def ensure_caption_checkpoint(seed=0, standin=CAPTION_STANDIN):
     """standin="v1": the round-1/2 stand-in (no channel-attention scale) — kept only so that tools/archive/r3_bisect.py can show what
     it does to the f32 arithmetic on real crops."""
