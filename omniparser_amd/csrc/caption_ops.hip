@@ -409,6 +409,9 @@ __global__ __launch_bounds__(256) void dwconv3_ln_kernel(DwLnArgs a) {
 // Blocks are numbered so that horizontally adjacent blocks of a strip run on the SAME XCD (bid & 7 = XCD): their shared halo
 // columns then hit that XCD's L2.  Per-element arithmetic (tap order, (acc + bias) + centre, two-pass statistics) is the unfused
 // kernels': y1 is bit-identical to dwconv3_kernel, h equals layernorm_f32v4_kernel up to the summation order of the statistics.
+// Measured and not kept (round 5, two one-minute A/B sessions on the MI355X, per-op profile of a 128-crop plan): a second row of loads in
+// flight ahead of the arithmetic (244 instead of 214 registers at C = 512, same 2 waves per SIMD) — 15.6 vs 15.1 ms per 36 launches, no
+// gain: the kernel is not bound by load latency; non-temporal stores for both outputs — 14.98 vs 14.90 ms, within the run-to-run noise.
 template <int NV, int LPP, bool OSPLIT>
 __global__ __launch_bounds__(256) void dwln_strip_kernel(DwLnArgs a, int SR, int pxb, int strips, unsigned nblocks) {
   constexpr int PPB = 256 / LPP;                                  // pixels (columns) per block
