@@ -112,6 +112,8 @@ def main():
         rb, rs, rc = TR.predict_tiled(cpu_model, img, origins, tw, th)
         crops = ScreenParser.glue(glue, rb, 3840, 2160, obox, texts)[1]
         G._OracleCaptioner(model, 64).caption_crops(img, crops, max_new_tokens=20, batch_size=64)
+        # ... and at the crop size BASELINE configs[4] names (768x768, 64-crop micro-batches): test_tiled_4k_end_to_end_captions_token_exact_r768
+        G._OracleCaptioner(model, 768).caption_crops(img, crops, max_new_tokens=20, batch_size=16)
         return {"blob_sha16": sha16(blob), "boxes": int(rb.shape[0]), "crops": len(crops)}
 
     def stream():

@@ -21,3 +21,13 @@ def test_tiled_4k_end_to_end_captions_token_exact():
     out = G.check_tiled_captions(width=0.5, R=64)
     assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] >= 0.95 * out["crops"], out
     print(out)
+
+
+def test_tiled_4k_end_to_end_captions_token_exact_r768():
+    """BASELINE configs[4] at the crop size it names: the same 3840x2160 frame, tiled detection, 64-crop caption micro-batches at
+    768x768 (the reference's CPU-path crop size) — caption ids of every crop = the CPU oracle's (oracle rows from the committed cache,
+    generated in the CPU container: tests/golden/gen_oracle_cache.py `tiled`)."""
+    import gpu_checks as G
+    out = G.check_tiled_captions(width=0.5, R=768)
+    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] >= 0.95 * out["crops"], out
+    print(out)
