@@ -1,9 +1,9 @@
 #!/usr/bin/env bash
-# round-5 closing session at the candidate commit: the driver's two commands (suite, smoke), the driver's bench command, the default bench line
+# round-5 closing session (second, at the final commit): the driver's two commands (suite, smoke), the driver's bench command, the default bench line
 set -u
 cd "${GRAFT_REPO_ROOT:-/root/repo}"
 export TMPDIR=/tmp
-OUT=gpurun_out/r5_s7
+OUT=gpurun_out/r5_s10
 mkdir -p "$OUT"
 t0=$(date +%s)
 ( timeout 1400 python3 -m pytest tests/ -x -q -m gpu -p no:cacheprovider --durations=10 > "$OUT/pytest.log" 2>&1; echo "exit $?" >> "$OUT/pytest.log" )
