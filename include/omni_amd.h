@@ -226,9 +226,10 @@ typedef struct omni_cand {
 /* Launch ONE op on `stream` (unit tests, eager mode).
  * Pointer check (here and in omni_plan_create, wherever a device is present; OMNI_CHECK_PTRS=0 turns it off): every non-NULL p[k]
  * must lie in a device allocation known to the HIP runtime, and the byte range the op touches from it (computed for the conv /
- * GEMM family, pools, LayerNorm, depthwise conv, split-convert and the fused FFN; the first byte for the other kinds) must end
- * inside that allocation — otherwise OMNI_E_ARG with the op index, slot and address in omni_last_error(), never a GPU
- * memory-access fault (which would abort the process). */
+ * GEMM family, pools / resizes incl. the extra CBFuse sources, LayerNorm, depthwise conv, split-convert, the fused FFN, detect-decode
+ * and NMS; the FIRST BYTE only for the attention, decode-step, crop, hand-off and PNG kinds) must end inside that allocation —
+ * otherwise OMNI_E_ARG with the op index, slot and address in omni_last_error() instead of a GPU memory-access fault (which would
+ * abort the process).  What it cannot see: an overrun that stays inside one allocation (with a caching allocator: one segment). */
 int omni_op_launch(const omni_op_t* op, void* stream);
 
 /* Plan: an immutable list of ops replayed per inference; optionally captured

@@ -64,8 +64,8 @@ static int dispatch(const omni_op_t* op, hipStream_t s) {
 // known to the HIP runtime, and the byte range the op will touch from it must end inside that allocation
 // (hipMemGetAddressRange; with a caching allocator the allocation is the allocator's segment — a wild pointer or a range that
 // runs off the segment is caught, a neighbour inside the same segment is not).  Ranges are computed for the op kinds that hold
-// almost all of a plan's launches (conv / GEMM family, pools, LayerNorm, depthwise conv, split-convert, fused FFN); for the
-// other kinds the first byte is checked.  On by default wherever a device is present — omni_op_launch (the single-op path is
+// almost all of a plan's launches (conv / GEMM family, pools / resizes, LayerNorm, depthwise conv, split-convert, fused FFN,
+// detect-decode, NMS); for the other kinds (attention, decode step, crop, hand-off, PNG) the first byte is checked.  On by default wherever a device is present — omni_op_launch (the single-op path is
 // never hot) and omni_plan_create (once per plan) — OMNI_CHECK_PTRS=0 turns it off; without a device there is nothing to check against.
 static bool check_ptrs_enabled() {
   const char* e = getenv("OMNI_CHECK_PTRS");

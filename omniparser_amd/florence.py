@@ -704,6 +704,15 @@ class Florence2Captioner:
         next call (at most 2 lane plans + 1 remainder plan + 1 decode plan)."""
         self._epoch = getattr(self, "_epoch", 0) + 1
 
+    def _wcache_bytes(self) -> int:
+        """device bytes of the packed weights shared by all plans of this model (tensors, or tuples of tensors / None)"""
+        n = 0
+        for v in self.__dict__.get("_wcache", {}).values():
+            for t in (v if isinstance(v, (tuple, list)) else (v,)):
+                if isinstance(t, torch.Tensor):
+                    n += t.numel() * t.element_size()
+        return n
+
     def plan_cache_bytes(self) -> int:
         return sum(m[0] for k, m in self.__dict__.get("_plan_meta", {}).items() if k in self._plans)
 
@@ -744,11 +753,15 @@ class Florence2Captioner:
             self.plan_evictions = getattr(self, "plan_evictions", 0) + 1
         on_gpu = self.device.type == "cuda" and torch.cuda.is_available()
         before = torch.cuda.memory_allocated(self.device) if on_gpu else 0
+        w_before = self._wcache_bytes()
         import contextlib
         with (torch.cuda.device(self.device) if self.device.type == "cuda" else contextlib.nullcontext()):
             obj = build()
         self._plans[key] = obj
-        meta[key] = [max(0, (torch.cuda.memory_allocated(self.device) if on_gpu else 0) - before), epoch]
+        # the plan's OWN bytes: the first build of a model also uploads the shared weights (the weight cache outlives every plan and
+        # is not freed by an eviction), which must not be booked on whichever plan happened to come first
+        grown = (torch.cuda.memory_allocated(self.device) if on_gpu else 0) - before - (self._wcache_bytes() - w_before)
+        meta[key] = [max(0, grown), epoch]
         sizes[base] = meta[key][0]
         return obj
 
