@@ -463,3 +463,28 @@ def test_conv_tuning_table_is_well_formed_and_reaches_the_op_descriptors(monkeyp
     pb.conv(x, w3, None, o2, 3, 2)
     assert pb.ops[0].i[20] == 1 and (pb.ops[0].i[22], pb.ops[0].i[23]) == (3, 2)
     assert (pb.ops[1].i[22], pb.ops[1].i[23]) == (0, 0)
+
+
+def test_tie_statistics_count_only_decisions_that_can_reach_the_final_list():
+    """oracle/detector_ref.py::postprocess counts NMS ties (diagnostics the parity tests select frames by) over the first max_det keeps
+    and over victims scoring above the last of them: a tie about a box that can never enter the final list is not a tie of the result.
+    Construction: 6 well-separated high-score boxes, then a low-score pair whose IoU sits exactly at the threshold.  With max_det = 4 the
+    pair is out of reach (no tie counted, final list = the 4 best); with max_det = 300 the same pair IS a counted near tie.  The kept
+    boxes are identical either way — the statistics pass never changes the result."""
+    from oracle import detector_ref as D
+    far = [[100.0 * k, 0.0, 100.0 * k + 50.0, 50.0] for k in range(6)]
+    # IoU([0,0,10,10], [0,0,10,5]) = 0.5 exactly, placed far away from the others
+    pair = [[2000.0, 0.0, 2010.0, 10.0], [2000.0, 0.0, 2010.0, 5.0]]
+    boxes = torch.tensor(far + pair)
+    scores = torch.tensor([0.9, 0.85, 0.8, 0.75, 0.7, 0.65, 0.2, 0.1])
+    cls = torch.zeros(8, dtype=torch.long)
+    full = D.batched_nms(boxes, scores, cls, 0.5)
+    for max_det, want_ties in ((4, 0), (300, 1)):
+        keep = full[:max_det]
+        stats = {"score_floor": float(scores[keep[-1]]) - 1e-4 if len(full) > max_det else -float("inf")}
+        again = D.batched_nms(boxes, scores, cls, 0.5, stats, max_keep=max_det)
+        assert again.tolist() == full[:max_det].tolist()                       # an abridged pass keeps the same first max_det boxes
+        assert stats.get("near_ties", 0) == want_ties, (max_det, stats)
+    # the unabridged call without a floor counts every decision, as rounds 2-4 did
+    stats = {}
+    assert D.batched_nms(boxes, scores, cls, 0.5, stats).tolist() == full.tolist() and stats["near_ties"] == 1
