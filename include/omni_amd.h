@@ -16,7 +16,10 @@
  *   - return 0 on success, negative OMNI_E_* on failure; omni_last_error()
  *     returns a thread-local message.
  *   - activations are NHWC (tokens x channels for the captioner), dtype
- *     OMNI_F32 (exact-f32 MFMA, parity mode) or OMNI_F16 (f16 MFMA, f32 accumulate).
+ *     OMNI_F32 (f32 storage, accumulation and statistics; GEMMs multiply on the f16
+ *     matrix cores with both operands split into two f16 halves and THREE products
+ *     per MAC — measured < 2e-6 relative to f64, the parity mode; short-K layers use
+ *     the exact f32 MFMA) or OMNI_F16 (f16 storage and MFMA, f32 accumulate).
  */
 #ifndef OMNI_AMD_H
 #define OMNI_AMD_H
@@ -31,7 +34,8 @@ extern "C" {
 /* 2 (round 5): omni_stream_create / omni_stream_destroy / omni_plan_run_split and omni_debug_host_op are gone; OMNI_OP_ATTN_ROWS i17,
  * OMNI_OP_CHAN_ATTN i7 and OMNI_OP_CONV p6 are ignored (i22 / i23 = tile / split-K override); OMNI_OP_NMS sorts candidates inside the op.  A host compiled against
  * version 1 must be rebuilt: omni_abi_version() is what it checks at load time (omniparser_amd/_lib.py does). */
-#define OMNI_ABI_VERSION 2
+/* 3 (round 6): + omni_overflow_count; plan bundles carry the ABI version they were written under (omni_model_load rejects others). */
+#define OMNI_ABI_VERSION 3
 
 enum { OMNI_F32 = 0, OMNI_F16 = 1 };
 enum { OMNI_ACT_NONE = 0, OMNI_ACT_SILU = 1, OMNI_ACT_GELU = 2 };
@@ -46,6 +50,13 @@ const char* omni_last_error(void);
 int omni_abi_version(void);
 /* number of visible HIP devices, <0 on error. */
 int omni_device_count(void);
+/* Range guard of the split-f16 formats (ABI 3).  OMNI_F32 plans keep the hi half of every GEMM operand in f16, so an activation
+ * with |x| > 65504 cannot be represented (format B clamps it, format A loses it); the fp32 reference has no such limit
+ * (ref:util/utils.py:66 loads the captioner in float32 on the CPU).  Every kernel that produces such an operand counts the
+ * threads that saw a value beyond the range; *count = that number since the last reset (0 on every tensor of a healthy model).
+ * Synchronous (a device-to-host copy of a few words): call it where the host already waits for results.  reset != 0 zeroes the
+ * counters. */
+int omni_overflow_count(int reset, unsigned long long* count);
 
 /* ------------------------------------------------------------------------ *
  * Generic op descriptor: the plan executor and the single-op entry point

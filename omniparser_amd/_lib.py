@@ -21,7 +21,7 @@ OP_DWCONV3, OP_LAYERNORM, OP_ATTN_ROWS, OP_CHAN_ATTN, OP_PROJ_PREP, OP_ASSEMBLE 
 OP_EMBED_STEP, OP_ATTN_DECODE, OP_GREEDY_STEP, OP_CROP_RESIZE, OP_DWCONV3_LN, OP_SPLIT_CONVERT, OP_GLUE = 14, 15, 16, 17, 18, 19, 20
 OP_OVERLAY, OP_PNG_PACK, OP_PNG_DEFLATE, OP_MLP_FUSED = 21, 22, 23, 24
 CAND_BYTES = 32
-ABI_VERSION = 2         # include/omni_amd.h::OMNI_ABI_VERSION — a library built from other headers is refused at load time
+ABI_VERSION = 3         # include/omni_amd.h::OMNI_ABI_VERSION — a library built from other headers is refused at load time
 
 EXPORTS = [
     "omni_last_error", "omni_abi_version", "omni_device_count", "omni_op_launch",
@@ -30,6 +30,7 @@ EXPORTS = [
     "omni_plan_profile",
     "omni_model_load", "omni_model_destroy", "omni_model_int", "omni_model_tensor", "omni_model_run",
     "omni_detector_create", "omni_detector_infer", "omni_captioner_create", "omni_captioner_caption",
+    "omni_overflow_count",
 ]
 
 
@@ -112,9 +113,21 @@ def bind(path):
     L.omni_detector_infer.restype = c_int
     L.omni_captioner_caption.argtypes = [c_void_p, c_void_p, c_int, c_int, c_int, POINTER(c_int32), c_int, POINTER(c_int32)]
     L.omni_captioner_caption.restype = c_int
+    L.omni_overflow_count.argtypes = [c_int, POINTER(ctypes.c_ulonglong)]
+    L.omni_overflow_count.restype = c_int
     if L.omni_abi_version() != ABI_VERSION:
         raise OmniError(f"ABI version mismatch: library {L.omni_abi_version()}, host code {ABI_VERSION} (rebuild: python -m omniparser_amd.build)")
     return L
+
+
+def overflow_count(reset=True) -> int:
+    """Range guard of the split-f16 formats (include/omni_amd.h::omni_overflow_count): threads that produced a GEMM operand beyond
+    the f16 range since the last reset.  Synchronous — call it where the host already waits for results."""
+    n = ctypes.c_ulonglong(0)
+    rc = lib().omni_overflow_count(1 if reset else 0, ctypes.byref(n))
+    if rc:
+        raise OmniError(lib().omni_last_error().decode())
+    return int(n.value)
 
 
 def require_device(device, what):

@@ -6,7 +6,7 @@ The reference builds its models inside Python (ref:util/utils.py:63-77 get_yolo_
 and a TorchScript blob underneath); here the Python graph builders (yolo_import / yolo_graph / florence) stay the only place that
 knows the architectures, and what they produce — an immutable op list over a fixed set of device buffers — is what travels:
 
-  header   "OMNIPLN1", counts
+  header   "OMNIPLN<abi>", counts
   tensors  size, role (scratch / zero-initialised / constant), file offset of the constant data
   plans    name + ops; every device pointer of an op as (tensor index, byte offset)
   named    I/O and state tensors by name (tensor index, byte offset, size)
@@ -27,7 +27,7 @@ import torch
 from . import _lib as L
 from . import planner
 
-MAGIC = b"OMNIPLN1"
+MAGIC = b"OMNIPLN%d" % L.ABI_VERSION      # the last character is the ABI the ops were written under: omni_model_load rejects any other
 ROLE = {"scratch": 0, "zero": 1, "const": 2}
 
 

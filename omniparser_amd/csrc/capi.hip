@@ -21,6 +21,27 @@ void omni_set_error(const char* fmt, ...) {
 extern "C" const char* omni_last_error(void) { return g_err; }
 extern "C" int omni_abi_version(void) { return OMNI_ABI_VERSION; }
 
+// ---- range guard of the split formats (omni_internal.h): one device counter per translation unit, read through registered readers
+static omni_ovf_reader_t g_ovf_readers[8];
+static int g_ovf_n = 0;
+void omni_register_overflow_reader(omni_ovf_reader_t fn) {
+  if (g_ovf_n < 8) g_ovf_readers[g_ovf_n++] = fn;
+}
+extern "C" int omni_overflow_count(int reset, unsigned long long* count) {
+  OMNI_REQUIRE(count != nullptr, "omni_overflow_count: null result pointer");
+  unsigned long long total = 0;
+  for (int k = 0; k < g_ovf_n; ++k) {
+    unsigned int v = 0;
+    if (g_ovf_readers[k](&v, reset)) {
+      omni_set_error("omni_overflow_count: reading the device counter failed");
+      return OMNI_E_HIP;
+    }
+    total += v;
+  }
+  *count = total;
+  return OMNI_OK;
+}
+
 extern "C" int omni_device_count(void) {
   int n = 0;
   hipError_t e = hipGetDeviceCount(&n);
@@ -88,8 +109,7 @@ static void op_extents(const omni_op_t* op, long long ext[8]) {
       ext[2] = Cout * 4;
       ext[3] = span(M, i[16], i[17], Cout);
       ext[4] = span(M, i[13], i[14], Cout);
-      ext[5] = i[19] > 0 ? (long long)i[19] * 1024 : 1;
-      ext[6] = i[22] > 0 ? (long long)i[22] * 4 : 1;
+      ext[5] = i[19] > 0 ? (long long)i[19] * 1024 : 1;      // p6 is ignored since ABI 2 (i22 = tile code, not a size): nothing to check
       break;
     }
     case OMNI_OP_MLP_FUSED: {

@@ -21,6 +21,8 @@
 
 #pragma clang fp contract(off)
 
+OMNI_RANGE_GUARD_TU()
+
 namespace {
 
 template <typename T> __device__ __forceinline__ float ldf(const T* p) { return ElemTraits<T>::to_f32(*p); }

@@ -30,6 +30,8 @@
 #include <string.h>
 #include <type_traits>
 
+OMNI_RANGE_GUARD_TU()
+
 namespace {
 
 struct ConvArgs {
@@ -60,6 +62,7 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, int mb, int n, 
     r[e] = (Rb && mb + dm < a.M) ? ElemTraits<T>::to_f32(Rb[dm * a.ldr]) : 0.0f;
   }
   const float scale = a.scale;
+  float amax = 0.0f;             // range guard (omni_internal.h): an f32 output beyond the f16 range cannot be split by the next conv's loader
 #pragma unroll
   for (int e = 0; e < 16; ++e) {
     const int dm = (e & 3) + 8 * (e >> 2);
@@ -68,8 +71,12 @@ __device__ __forceinline__ void epilogue_tile(const ConvArgs& a, int mb, int n, 
     if constexpr (ACT == OMNI_ACT_SILU) v = v / (1.0f + expf(-v));                                   // torch CPU: x / (1 + exp(-x))
     else if constexpr (ACT == OMNI_ACT_GELU) v = omni_gelu(v);                                     // exact erf GELU
     v += r[e];
-    if (mb + dm < a.M) Yb[dm * a.ldo] = ElemTraits<T>::from_f32(v);
+    if (mb + dm < a.M) {
+      Yb[dm * a.ldo] = ElemTraits<T>::from_f32(v);
+      amax = __builtin_fmaxf(__builtin_fabsf(v), amax);
+    }
   }
+  if constexpr (sizeof(T) == 4) omni_report_range(amax);
 }
 
 template <typename T, int BM, int BN, int RB, bool ALIGNED, bool PW>
@@ -322,6 +329,7 @@ __global__ __launch_bounds__(256) void splitk_reduce_kernel(ConvArgs a) {
   if (a.scale != 0.0f) v *= a.scale;
   v = act_apply(v, a.act);
   if (a.res) v += ElemTraits<T>::to_f32(reinterpret_cast<const T*>(a.res)[m * a.ldr + a.res_coff + n]);
+  if constexpr (sizeof(T) == 4) omni_report_range(__builtin_fabsf(v));
   reinterpret_cast<T*>(a.y)[m * a.ldo + a.out_coff + n] = ElemTraits<T>::from_f32(v);
 }
 

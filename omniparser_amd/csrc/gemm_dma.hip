@@ -26,6 +26,8 @@
 #include <string.h>
 #include <type_traits>
 
+OMNI_RANGE_GUARD_TU()
+
 namespace {
 
 typedef __attribute__((address_space(3))) void lds_void;
@@ -57,6 +59,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
   __syncthreads();                                           // every wave is done reading the last K slice
   unsigned char* stg = lds + wave * (32 * EP);
   const float osc = a.oscale;
+  float amax = 0.0f;                                         // range guard of the split output (omni_internal.h)
   const int rrow = lane >> 4, chunk = lane & 15;             // read phase: 16 lanes per row, 16 bytes per lane
   static_assert(!(RES && OSPLIT), "residual + format-B output is not a layer of this model");
 #pragma unroll
@@ -103,7 +106,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
           const int cl = j * 32 + q * 8 + 4 * hsel;          // channel within the pass's 64
           if constexpr (OSPLIT) {
             uint2 hi, lo;
-            omni_split4(v, hi, lo);
+            omni_split4(v, hi, lo, amax);
             *reinterpret_cast<uint2*>(wr + omni_split_off(cl)) = hi;
             *reinterpret_cast<uint2*>(wr + omni_split_off(cl) + 32) = lo;
           } else {
@@ -127,6 +130,7 @@ __device__ __forceinline__ void gemm_epilogue(f32x16 (&acc)[TM][TN], const GemmA
       OMNI_WAVE_SYNC();                                      // the next token tile overwrites the staging rows
     }
   }
+  if constexpr (OSPLIT) omni_report_range(amax);
 }
 
 // K-loop schedule: the DMA pieces of the slice NSTAGE-1 ahead are spread over the units, ds_reads / DMA pieces interleaved one per
@@ -436,6 +440,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs a) {
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc2[0][j][e] = 0.0f;
   const float osc1 = a.osc1;
+  float amax = 0.0f;                                     // range guard of the hidden activations' split (omni_internal.h)
   __syncthreads();                                       // fc1 bias visible
 
   for (int c = 0; c < NCH; ++c) {
@@ -476,7 +481,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs a) {
                                      f32x2{bq[r], bq[r + 1]});
           v[r] = t[0]; v[r + 1] = t[1];
         }
-        omni_split4(v, hq[qq], lq[qq]);
+        omni_split4(v, hq[qq], lq[qq], amax);
       }
       gh[kg] = __builtin_bit_cast(f16x8, u32x4{hq[0].x, hq[0].y, hq[1].x, hq[1].y});
       gl[kg] = __builtin_bit_cast(f16x8, u32x4{lq[0].x, lq[0].y, lq[1].x, lq[1].y});
@@ -497,6 +502,7 @@ __global__ __launch_bounds__(256, 2) void mlp_fused_kernel(MlpArgs a) {
         acc2[0][j + 1] = __builtin_amdgcn_mfma_f32_32x32x16_f16(wh1, gl[kg], acc2[0][j + 1], 0, 0, 0);
       }
   }
+  omni_report_range(amax);
   // ---- epilogue: 2^-k2, fc2 bias, residual, coalesced f32 rows (gemm_epilogue: four waves x 32 tokens x 128 channels)
   gemm_epilogue<NW * 32, C, NW, 1, 1, OB, 2 * STAGE, OMNI_ACT_NONE, false, true>(acc2, a.ep, lds, m0, 0, wave, lane);
 #endif

@@ -99,7 +99,14 @@ extern "C" int omni_model_load(const char* path, omni_model_t** out) {
   if (!f) { omni_set_error("omni_model_load: cannot open %s", path); return OMNI_E_ARG; }
   Reader r{f};
   char magic[8];
-  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, "OMNIPLN1", 8) != 0) { fclose(f); omni_set_error("omni_model_load: %s is not a plan bundle", path); return OMNI_E_ARG; }
+  static_assert(OMNI_ABI_VERSION >= 0 && OMNI_ABI_VERSION <= 9, "one digit of the magic holds the ABI version");
+  const char want[9] = {'O', 'M', 'N', 'I', 'P', 'L', 'N', (char)('0' + OMNI_ABI_VERSION), 0};
+  if (fread(magic, 1, 8, f) != 8 || memcmp(magic, want, 7) != 0) { fclose(f); omni_set_error("omni_model_load: %s is not a plan bundle", path); return OMNI_E_ARG; }
+  if (magic[7] != want[7]) {   // op slot meanings change with the ABI (ABI 2 redefined OMNI_OP_CONV i22): a bundle is only valid under the ABI that wrote it
+    fclose(f);
+    omni_set_error("omni_model_load: %s was exported under ABI %c, this library is ABI %d (re-export the bundle)", path, magic[7], OMNI_ABI_VERSION);
+    return OMNI_E_ARG;
+  }
   const uint32_t nt = r.get<uint32_t>(), np = r.get<uint32_t>(), nn = r.get<uint32_t>(), ni = r.get<uint32_t>();
   if (!r.ok || nt > (1u << 20) || np > 1024u || nn > 4096u || ni > 4096u) {
     fclose(f);

@@ -377,6 +377,18 @@ class ScreenParser:
             self._ev["capE"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
         return (list(frames), flat, ids_all, ids_stream)
 
+    def _check_range(self):
+        """Range guard of the split-f16 GEMM operands (include/omni_amd.h::omni_overflow_count), read where the host has just waited for
+        a batch's ids anyway: a value beyond the f16 range was clamped (format B) or lost (format A) somewhere in the last batch(es) —
+        the fp32 reference has no such limit, so the result may differ from it.  Accumulated in `range_overflow_total`, the last
+        reading in `stats["split_overflow"]` (filled by the callers), fatal with OMNI_STRICT_RANGE=1 (what the parity tests run with)."""
+        n = L.overflow_count(reset=True)
+        self.range_overflow_last = n
+        self.range_overflow_total = getattr(self, "range_overflow_total", 0) + n
+        if n and os.environ.get("OMNI_STRICT_RANGE", "0") == "1":
+            raise L.OmniError(f"split-f16 range guard: {n} threads produced a GEMM operand beyond +-65504 in this batch "
+                              "(the fp32 reference has no such limit; results may differ from it)")
+
     @torch.inference_mode()
     def caption_finish(self, handle):
         frames, flat, ids_all, ids_stream = handle
@@ -386,6 +398,7 @@ class ScreenParser:
         with torch.cuda.stream(ids_stream):
             ids_all = [t.cpu() for t in ids_all]
         ids_all = [cap._finish_ids(t.long()) for t in ids_all]
+        self._check_range()
         out = [[] for _ in frames]
         k = 0
         for ids in ids_all:
@@ -431,7 +444,7 @@ class ScreenParser:
             with torch.inference_mode(), self.cap._lock:
                 caps = self.caption_finish(handle)
             ids_out = self._fill_captions(elems_all, caps)
-            self.stats = {"crops": [len(c) for c in crops_all], "boxes": nbox}
+            self.stats = {"crops": [len(c) for c in crops_all], "boxes": nbox, "split_overflow": getattr(self, "range_overflow_last", 0)}
             self.last_crops = crops_all
             return (elems_all, ids_out) if return_ids else elems_all
 
@@ -465,7 +478,7 @@ class ScreenParser:
                 caps = self.caption_finish(handle)
                 elems_all = self.assemble(snap, snap, ocr_els, counts, iw, ih, n_frames)
             ids_out = self._fill_captions(elems_all, caps)
-            self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()]}
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in snap.out_count[:n_frames].tolist()], "split_overflow": getattr(self, "range_overflow_last", 0)}
             self.last_crops = [snap.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
 
@@ -534,7 +547,8 @@ class ScreenParser:
             caps = self.caption(frames, n_crops, crops_dev=gs.crops)
             elems_all = self.assemble(dp, gs, ocr_els, counts, iw, ih, len(frames))
             ids_out = self._fill_captions(elems_all, caps)
-            self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()], "stage_ms": self.stage_ms()}
+            self.stats = {"crops": n_crops, "boxes": [int(v) for v in dp.out_count[: len(frames)].tolist()], "stage_ms": self.stage_ms(),
+                          "split_overflow": getattr(self, "range_overflow_last", 0)}
             self.last_crops = [gs.crops[f, :n].tolist() for f, n in enumerate(n_crops)]
             return (elems_all, ids_out) if return_ids else elems_all
         if tiled:
@@ -548,6 +562,6 @@ class ScreenParser:
             elems_all.append(el); crops_all.append(cr)
         caps = self.caption(frames, crops_all)
         ids_out = self._fill_captions(elems_all, caps)
-        self.stats = {"crops": [len(c) for c in crops_all], "boxes": [len(b) for b in det_boxes]}
+        self.stats = {"crops": [len(c) for c in crops_all], "boxes": [len(b) for b in det_boxes], "split_overflow": getattr(self, "range_overflow_last", 0)}
         self.last_crops = crops_all            # integer crop boxes per frame, in caption order (parity tests read them)
         return (elems_all, ids_out) if return_ids else elems_all

@@ -12,6 +12,9 @@ for p in (ROOT, os.path.join(ROOT, "tests"), os.path.join(ROOT, "tests", "emu"))
 # runs on the host emulation of its own kernels (tests/emu).  Sizes are the GPU's, so this takes minutes to hours; it is a
 # developer tool, never what the driver runs (OMNI_EMU is unset there and on the GPU box).
 REHEARSE = os.environ.get("OMNI_EMU", "0") == "1"
+# parity mode: a GEMM operand beyond the f16 range of the split formats is FATAL in every test that runs the pipeline (the product
+# only counts it into stats["split_overflow"]; omniparser_amd/pipeline.py::_check_range)
+os.environ.setdefault("OMNI_STRICT_RANGE", "1")
 
 
 def pytest_configure(config):

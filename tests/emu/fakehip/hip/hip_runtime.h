@@ -445,6 +445,14 @@ inline hipError_t hipFree(void* p) { std::free(p); return hipSuccess; }
 inline hipError_t hipMemset(void* p, int v, size_t n) { std::memset(p, v, n); return hipSuccess; }
 inline hipError_t hipMemcpy(void* d, const void* s_, size_t n, hipMemcpyKind) { std::memcpy(d, s_, n); return hipSuccess; }
 inline hipError_t hipMemcpyAsync(void* d, const void* s_, size_t n, hipMemcpyKind, hipStream_t) { std::memcpy(d, s_, n); return hipSuccess; }
+// device globals are plain statics here (the range-guard counter of omni_internal.h)
+#define HIP_SYMBOL(X) X
+template <typename T> inline hipError_t hipMemcpyFromSymbol(void* d, const T& sym, size_t n, size_t off, hipMemcpyKind) {
+  std::memcpy(d, reinterpret_cast<const char*>(&sym) + off, n); return hipSuccess;
+}
+template <typename T> inline hipError_t hipMemcpyToSymbol(T& sym, const void* s_, size_t n, size_t off, hipMemcpyKind) {
+  std::memcpy(reinterpret_cast<char*>(&sym) + off, s_, n); return hipSuccess;
+}
 inline hipError_t hipStreamCreateWithFlags(hipStream_t* s_, unsigned) { *s_ = nullptr; return hipSuccess; }
 inline hipError_t hipExtStreamCreateWithCUMask(hipStream_t* s_, uint32_t, const uint32_t*) { *s_ = nullptr; return hipSuccess; }
 inline hipError_t hipStreamDestroy(hipStream_t) { return hipSuccess; }

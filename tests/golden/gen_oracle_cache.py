@@ -1,7 +1,7 @@
 """Fill tests/golden/oracle_cache/ in the CPU container: the CAPTION-ORACLE halves of the `-m gpu` end-to-end tests (transformers
 Florence-2 fp32 on the oracle's own crop tensors — 3-4 s of 128 threads per 768x768 crop on the GPU box, which the lease should not pay).
 
-  python tests/golden/gen_oracle_cache.py [bench] [refimgs] [e2e] [tiled] [stream]        (default: all; resumable: rows already cached are hits)
+  python tests/golden/gen_oracle_cache.py [bench] [refimgs] [e2e] [tiled] [stream] [verify]        (default: all; resumable: rows already cached are hits)
 
 Each section computes, with the ORACLE only (no device), the crop rectangles the corresponding GPU test will send to
 `gpu_checks._OracleCaptioner.caption_crops` and calls it with OMNI_ORACLE_CACHE_WRITE=1, so the rows land in the committed cache file
@@ -43,7 +43,7 @@ def main():
     from omniparser_amd.synth import BENCH_SEEDS, synthetic_ocr, synthetic_screenshot
     from omniparser_amd.util import utils as U
     from tools.make_weights import CAPTION_STANDIN, DETECTOR_STANDIN, build_random_captioner, ensure_blob, ensure_caption_checkpoint
-    want = set(sys.argv[1:]) or {"bench", "refimgs", "e2e", "tiled", "stream"}
+    want = set(sys.argv[1:]) or {"bench", "refimgs", "e2e", "tiled", "stream", "verify"}
     model = build_random_captioner(0)
     cdir = ensure_caption_checkpoint(0)
     proc = U.FlorenceProcessor(cdir)
@@ -75,12 +75,40 @@ def main():
             rb, rs, rc = D.predict(cpu_model, Image.fromarray(im), conf=0.05, imgsz=640, iou=0.1, max_det=300)
             texts, obox = synthetic_ocr(s, 1920, 1080, 40)
             crops.append(ScreenParser.glue(glue, rb, 1920, 1080, obox, texts)[1])
-        flat, chosen = G.bench_path_chosen([len(c) for c in crops], 128)
+        # round 6: EVERY crop of the benched batch (345 rows), not the seams only — check_bench_path compares them all
         ocap = G._OracleCaptioner(model, 768)
-        for f in sorted({c[0] for c in chosen}):
-            ks = [k for (ff, k) in chosen if ff == f]
-            ocap.caption_crops(imgs[f], [crops[f][k] for k in ks], max_new_tokens=20, batch_size=8)
-        return {"blob_sha16": sha16(blob), "seeds": list(BENCH_SEEDS), "crops_per_frame": [len(c) for c in crops], "rows": len(chosen)}
+        for f in range(len(imgs)):
+            ocap.caption_crops(imgs[f], crops[f], max_new_tokens=20, batch_size=8)
+        return {"blob_sha16": sha16(blob), "seeds": list(BENCH_SEEDS), "crops_per_frame": [len(c) for c in crops], "rows": sum(len(c) for c in crops)}
+
+    def verify():
+        # staleness audit: N rows of the committed file recomputed LIVE on the benched frames (use_cache=False) and compared with what the
+        # file holds for the same key — ids equal, margins within 1e-4 (thread count changes the last bits of a CPU matmul)
+        import numpy as np
+        from oracle import preprocess_ref as PR
+        from omniparser_amd.florence import CLIP_MEAN, CLIP_STD
+        blob = ensure_blob(0, 1, 1.0)
+        cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
+        cache = OC.CaptionCache(model)
+        n, bad, dm = 0, [], 0.0
+        for s in BENCH_SEEDS[:2]:
+            im = synthetic_screenshot(s, 1920, 1080)
+            rb, rs, rc = D.predict(cpu_model, Image.fromarray(im), conf=0.05, imgsz=640, iou=0.1, max_det=300)
+            texts, obox = synthetic_ocr(s, 1920, 1080, 40)
+            cr = ScreenParser.glue(glue, rb, 1920, 1080, obox, texts)[1]
+            pick = [k for k in range(len(cr)) if cache.rows.get(OC.row_key(PR.caption_pixel_values(im, cr[k], 768, CLIP_MEAN, CLIP_STD), 768, 20))][:6]
+            live = G._OracleCaptioner(model, 768, use_cache=False)
+            ref = live.caption_crops(im, [cr[k] for k in pick], max_new_tokens=20, batch_size=8)
+            for j, k in enumerate(pick):
+                rec = cache.rows[OC.row_key(PR.caption_pixel_values(im, cr[k], 768, CLIP_MEAN, CLIP_STD), 768, 20)]
+                ids = [int(v) for v in ref[j].tolist()][:len(rec["ids"])]
+                n += 1
+                if ids != rec["ids"] or any(int(v) != 1 for v in ref[j].tolist()[len(rec["ids"]):]):
+                    bad.append((s, k))
+                if rec["margin"] is not None:
+                    dm = max(dm, abs(rec["margin"] - live.margins[j]))
+        assert not bad and dm < 1e-4, (bad, dm)
+        return {"rows_recomputed_live": n, "ids_equal": n - len(bad), "max_margin_diff": dm}
 
     def refimgs():
         # tests/test_gpu_j_reference_images.py (check_end_to_end, width 1.0, R = 768, first 8 crops) on the reference's own two images
@@ -139,6 +167,7 @@ def main():
     section("stream", stream)
     section("bench", bench)
     section("refimgs", refimgs)
+    section("verify", verify)
 
 
 if __name__ == "__main__":

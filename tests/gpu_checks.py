@@ -206,6 +206,71 @@ def check_gemm_dma(seed=0, cases=None, tiles=(None, "256x128", "128x128")):
     return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), t, e) for c, t, e in details]}
 
 
+def check_range_guard(seed=0):
+    """The split-f16 range guard (csrc/omni_internal.h, include/omni_amd.h::omni_overflow_count): a GEMM operand beyond +-65504
+    cannot be held by the split formats — the fp32 reference has no such limit (ref:util/utils.py:66) — so the kernels that produce
+    one must COUNT it.  (a) healthy tensors: counter stays 0 through split_convert, the pre-split GEMM with a split (GELU) output, a
+    LayerNorm with split output and a format-A convolution; (b) one 7e4 activation in front of split_convert; (c) a GEMM whose OUTPUT
+    reaches 7e4 and is written in format B; (d) a format-A convolution (conv_split / conv_igemm epilogue) whose f32 output reaches 7e4."""
+    g = torch.Generator().manual_seed(seed)
+    L.overflow_count(reset=True)
+    M, K, N = 300, 128, 256
+    out = {}
+
+    def gemm(x, w, b, osplit, act=L.ACT_NONE):
+        pb = PlanBuilder(DEV, L.F32)
+        xv = View(x.clone().view(1, M, 1, K).to(DEV), 0, K)
+        pb.split_convert(xv)
+        ov = View(torch.zeros(1, M, 1, N, device=DEV), 0, N)
+        pb.conv(xv, pb.pack_weight_dma(w), b, ov, 1, act=act, out_split=osplit)
+        for op in pb.ops:
+            L.launch(op)
+        _sync()
+        return ov.t.view(M, N).cpu()
+
+    x = torch.randn(M, K, generator=g)
+    w = torch.randn(N, K, generator=g) / math.sqrt(K)
+    b = torch.randn(N, generator=g)
+    gemm(x, w, b, True, L.ACT_GELU)
+    xl = torch.randn(200, 256, generator=g).to(DEV); yl = torch.zeros(200, 256, device=DEV); y2 = torch.zeros(200, 256, device=DEV)
+    gm, bt = torch.randn(256, generator=g).to(DEV), torch.randn(256, generator=g).to(DEV)
+    L.launch(L.make_op(L.OP_LAYERNORM, L.F32, p=[xl.data_ptr(), None, gm.data_ptr(), bt.data_ptr(), yl.data_ptr(), y2.data_ptr()],
+                       i={0: 200, 1: 1, 3: 256, 5: 0, 6: 2}, f={0: 1e-5}))
+    _sync()
+
+    def conv(xc, wc, bc):
+        pb = PlanBuilder(DEV, L.F32)
+        xv = _nhwc(xc, torch.float32)
+        ov = View(torch.zeros(1, xc.shape[2], xc.shape[3], wc.shape[0], device=DEV), 0, wc.shape[0])
+        pb.conv(xv, pb.pack_weight(wc), bc, ov, wc.shape[2], act=L.ACT_SILU)
+        for op in pb.ops:
+            L.launch(op)
+        _sync()
+        return ov.t.cpu()
+
+    xc = torch.randn(1, 128, 12, 12, generator=g)
+    wc = torch.randn(64, 128, 3, 3, generator=g) / 34.0
+    conv(xc, wc, torch.zeros(64))
+    out["healthy"] = L.overflow_count(reset=True)
+    assert out["healthy"] == 0, out
+    # (b) the clamp bites inside split_convert
+    xb = x.clone(); xb[17, 5] = 7.0e4
+    gemm(xb, w, b, False)
+    out["split_convert_input_7e4"] = L.overflow_count(reset=True)
+    # (c) the GEMM's own output leaves the range and is written in format B
+    got = gemm(x, w * 4.0e4, b, True)
+    out["gemm_split_output"] = L.overflow_count(reset=True)
+    assert float(split_decode(got).abs().max()) <= 65504.0            # what the clamp stores
+    # (d) format-A path: a convolution output beyond the range (the next conv's loader could not split it)
+    yc = conv(xc * 3.0e3, wc * 30.0, torch.zeros(64))
+    out["conv_f32_output"] = L.overflow_count(reset=True)
+    out["conv_out_max"] = float(yc.abs().max())
+    assert out["conv_out_max"] > 65504.0, out
+    assert out["split_convert_input_7e4"] >= 1 and out["gemm_split_output"] >= 1 and out["conv_f32_output"] >= 1, out
+    assert L.overflow_count(reset=True) == 0
+    return out
+
+
 def check_mlp_fused(seed=0, cases=((300, 128, 0, 128, 0), (128, 128, 0, 128, 0), (517, 192, 48, 160, 16), (33, 128, 0, 128, 0)), inplace=True):
     """OMNI_OP_MLP_FUSED (csrc/gemm_dma.hip::mlp_fused_kernel, C = 128, hidden = 512): y = res + fc2(GELU(fc1(x))) vs an f64
     evaluation of the SAME (decoded) operands, and vs the two-launch composition it replaces (fc1 with GELU + format-B output, fc2
@@ -1335,6 +1400,100 @@ def _pad_to(ids, T, pad):
     return torch.cat([ids, torch.full((ids.shape[0], T - ids.shape[1]), pad, dtype=ids.dtype)], 1)
 
 
+
+# ------------------------------------------------------------------------------------------ caption-id tally
+CAPTION_MARGIN = 2e-4      # 5x the measured GPU-vs-oracle logit difference (3.9e-5: smoke, logit_margins).  Round 5 used 1e-3 and SKIPPED
+#                            the crops below it; since round 6 EVERY crop is compared and recorded, and the margin only decides what a
+#                            mismatch means (CaptionTally below).
+_F64 = {}
+
+
+def oracle_ids_f64(model, pv_rows, max_new_tokens=20):
+    """greedy ids of the oracle evaluated in float64 on the same crop tensors (numpy [n, R, R, 3] f32) — the referee for a crop
+    whose f32 arg-max is decided by less than CAPTION_MARGIN: the f32 oracle is then within its OWN rounding of the other token."""
+    import copy
+    from omniparser_amd.florence import PROMPT_IDS
+    if id(model) not in _F64:
+        _F64[id(model)] = copy.deepcopy(model).double().eval()
+    m64 = _F64[id(model)]
+    pix = torch.from_numpy(np.stack(pv_rows)).permute(0, 3, 1, 2).contiguous().double()
+    R = pix.shape[-1]
+    ids = torch.tensor([[m64.config.image_token_id] * ((R // 32) ** 2 + 1) + PROMPT_IDS] * pix.shape[0])
+    with torch.inference_mode():
+        seq = m64.generate(input_ids=ids, pixel_values=pix, max_new_tokens=max_new_tokens, num_beams=1, do_sample=False)
+    out = []
+    for row in seq.tolist():
+        eos = next((t for t in range(1, len(row)) if row[t] == 2), len(row) - 1)
+        out.append(row[:eos + 1])
+    return out
+
+
+class CaptionTally:
+    """Token-exactness bookkeeping shared by the end-to-end checks.  EVERY compared crop is recorded, whatever its margin:
+      * oracle margin >= CAPTION_MARGIN and ids differ           -> a failure;
+      * oracle margin <  CAPTION_MARGIN and ids equal            -> `below_margin_match`;
+      * oracle margin <  CAPTION_MARGIN and ids differ           -> `below_margin_mismatch`, sent to the f64 referee
+        (`oracle_ids_f64`): accepted only if the f64 oracle sides with the device or itself leaves the f32 oracle at or before the
+        first differing token (`below_margin_mismatch_excused`); anything else is a failure."""
+
+    def __init__(self, model, R, pad=1, margin=CAPTION_MARGIN):
+        self.model, self.R, self.pad, self.margin = model, R, pad, margin
+        self.compared = self.below = self.below_match = 0
+        self.bad, self.pending, self.excused = [], [], 0
+
+    @staticmethod
+    def _trim(ids, pad):
+        ids = [int(v) for v in (ids.tolist() if hasattr(ids, "tolist") else ids)]
+        while ids and ids[-1] == pad:
+            ids.pop()
+        return ids
+
+    def add(self, tag, got, ref, margin, image=None, box=None):
+        g, r = self._trim(got, self.pad), self._trim(ref, self.pad)
+        self.compared += 1
+        if margin < self.margin:
+            self.below += 1
+            if g == r:
+                self.below_match += 1
+            else:
+                self.pending.append((tag, g, r, float(margin), image, box))
+        elif g != r:
+            self.bad.append((tag, round(float(margin), 6), g, r))
+
+    def finish(self):
+        from oracle import preprocess_ref as PR
+        from omniparser_amd.florence import CLIP_MEAN, CLIP_STD
+        unresolved = []
+        for tag, g, r, margin, image, box in self.pending:
+            if image is None:
+                unresolved.append((tag, margin, g, r)); continue
+            img = image.numpy() if isinstance(image, torch.Tensor) else image
+            f64 = oracle_ids_f64(self.model, [PR.caption_pixel_values(img, box, self.R, CLIP_MEAN, CLIP_STD)])[0]
+            first = next((t for t in range(max(len(g), len(r))) if t >= len(g) or t >= len(r) or g[t] != r[t]), None)
+            if f64 == g or f64[:first + 1] != r[:first + 1]:
+                self.excused += 1
+            else:
+                unresolved.append((tag, margin, g, r))
+        stats = {"caption_crops_compared": self.compared, "below_margin": self.below, "below_margin_match": self.below_match,
+                 "below_margin_mismatch": len(self.pending), "below_margin_mismatch_excused": self.excused, "caption_margin": self.margin}
+        problems = []
+        if self.bad:
+            problems.append(f"caption ids differ on {len(self.bad)} of {self.compared} crops above the margin {self.margin}: {self.bad[:2]}")
+        if unresolved:
+            problems.append(f"{len(unresolved)} below-margin crops differ and the f64 oracle sides with the f32 oracle: {unresolved[:2]}")
+        return stats, problems
+
+
+def record_counters(name, out):
+    """parity counters of the end-to-end checks -> gpurun_out/parity_counters.jsonl (copied to profiles/ per session)."""
+    import json
+    from pathlib import Path
+    d = Path(__file__).resolve().parents[1] / "gpurun_out"
+    if d.exists():
+        with open(d / "parity_counters.jsonl", "a") as f:
+            f.write(json.dumps({"check": name, **{k: v for k, v in out.items() if isinstance(v, (int, float, str, list, bool, type(None)))}}) + "\n")
+
+
 # ------------------------------------------------------------------------------------------ end to end
 class _OracleCaptioner:
     """CPU reference of the caption stage: oracle crop pre-processing + transformers Florence-2."""
@@ -1481,10 +1640,11 @@ def check_end_to_end(width=0.5, R=64, image_seed=1, max_crops_checked=None, iw=1
             assert a["content"] == b["content"]
     assert min_iou >= 0.999, f"min IoU {min_iou}"
     out.update(min_iou=min_iou, captioned=caps, identical_crops_token_exact=same_caps)
+    record_counters("end_to_end", out)
     return out
 
 
-def check_tiled_captions(width=0.5, R=64, image_seed=4, iw=3840, ih=2160, micro_batch=64, min_margin=1e-3):
+def check_tiled_captions(width=0.5, R=64, image_seed=4, iw=3840, ih=2160, micro_batch=64, min_margin=CAPTION_MARGIN):
     """BASELINE configs[4] end to end: a 3840x2160 frame through ScreenParser(tile_large=True) — tiled detection + global NMS, host
     hand-off, ~200 crops captioned in 64-crop micro-batches — (a) elements and crop rectangles = the reference hand-off
     (`ScreenParser.glue`, pinned by the reference fixtures) of the tiled detector's own boxes, (b) caption ids of EVERY crop = the CPU
@@ -1513,16 +1673,19 @@ def check_tiled_captions(width=0.5, R=64, image_seed=4, iw=3840, ih=2160, micro_
         assert (a["type"], a["bbox"], a["source"], a["interactivity"]) == (b["type"], b["bbox"], b["source"], b["interactivity"])
         assert b["content"] is None or a["content"] == b["content"]
     assert len(ids) == len(crops)
-    # (b) every crop against the CPU oracle
-    ocap = _OracleCaptioner(build_random_captioner(0), R)
+    # (b) every crop against the CPU oracle — all of them, whatever the oracle's margin (CaptionTally)
+    model = build_random_captioner(0)
+    ocap = _OracleCaptioner(model, R)
     ref = ocap.caption_crops(img, crops, max_new_tokens=20, batch_size=micro_batch)
-    T = ref.shape[1]
-    got = torch.stack([_pad_to(r.view(1, -1).long(), T, 1)[0, :T] for r in ids]) if ids else torch.zeros(0, T, dtype=torch.long)
-    decided = [k for k, m in enumerate(ocap.margins) if m >= min_margin]
-    bad = [k for k in decided if not torch.equal(got[k], ref[k])]
-    assert not bad, f"caption ids differ on {len(bad)} of {len(decided)} crops, e.g. crop {bad[0]} {crops[bad[0]]}: {got[bad[0]].tolist()} vs {ref[bad[0]].tolist()}"
-    return {"crops": len(crops), "micro_batches": -(-len(crops) // micro_batch), "compared": len(decided), "elements": len(elems),
-            "min_margin_compared": min((ocap.margins[k] for k in decided), default=None), "tiled_boxes": int(gb.shape[0])}
+    tally = CaptionTally(model, R, margin=min_margin)
+    for k in range(len(crops)):
+        tally.add(k, ids[k], ref[k], ocap.margins[k], img, crops[k])
+    stats, problems = tally.finish()
+    out = {"crops": len(crops), "micro_batches": -(-len(crops) // micro_batch), "compared": stats["caption_crops_compared"], "elements": len(elems),
+           "min_margin": min(ocap.margins, default=None), "tiled_boxes": int(gb.shape[0]), "R": R, **stats}
+    record_counters("tiled_captions", out)
+    assert not problems, (problems, out)
+    return out
 
 
 def ratio_box_iou(rbx, gbx):
@@ -1593,13 +1756,13 @@ def bench_path_chosen(crop_counts, batch_size, caption_pairs=((0, 1), (2, 3)), p
 
 
 def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)), per_side=4, boundary=4, min_exact=1, seeds=None,
-                     detector_only=False):
+                     detector_only=False, all_crops=True):
     """Parity of the EXACT composition bench.py times (BASELINE configs[2]): ScreenParser.parse_batch on a batch of
     1920x1080 screenshots — batch detector plan, full-width YOLOv9-E, product glue, crops of all frames packed into 128-crop
     caption micro-batches at RxR, deferred id read-back — against the oracle pipeline (oracle.detector_ref.predict per frame
     -> the same glue -> oracle crop preprocessing -> transformers Florence-2 on the CPU).  Boxes / classes / element order
-    are compared on EVERY frame; caption ids on crops that sit on both sides of frame boundaries inside one packed
-    micro-batch and on both sides of a micro-batch boundary (CPU Florence-2 at 768x768 costs seconds per crop)."""
+    are compared on EVERY frame; caption ids on EVERY crop (`all_crops`; with all_crops=False: the crops that sit on both sides of
+    frame boundaries inside one packed micro-batch and on both sides of a micro-batch boundary)."""
     from PIL import Image
     from oracle import detector_ref as D
     from oracle import preprocess_ref as PR
@@ -1671,33 +1834,23 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     out["seeds"] = list(seeds)
     if detector_only:           # the non-curated frame set: detector + hand-off statements only (captions are checked on the benched set)
         return out
-    # ---- caption ids: crops on both sides of frame boundaries inside one micro-batch, and around a micro-batch boundary
+    # ---- caption ids: EVERY crop of the benched batch (round 6; rounds 3-5 compared 16-24 crops around the seams) — the oracle rows
+    #      come from the committed cache (tests/golden/gen_oracle_cache.py bench: 345 rows, ~10 CPU-minutes in the build container)
     flat, chosen = bench_path_chosen([len(c) for c in crops_g], sp.batch_size, caption_pairs, per_side, boundary)
+    if all_crops:
+        chosen = list(flat)
     mb = {flat.index(c) // sp.batch_size for c in chosen}
     model = build_random_captioner(0)
     ocap = _OracleCaptioner(model, R)
-    T = cap.max_new_tokens + 1
-    bad, weak, checked = [], 0, 0
-    MARGIN = 1e-3            # a crop whose oracle arg-max is decided by less than this is reported, not asserted (GPU logit error ~1e-5)
+    tally = CaptionTally(model, R, pad=cap.w.pad)
     for f in sorted({c[0] for c in chosen}):
         ks = [k for (ff, k) in chosen if ff == f]
         ref = ocap.caption_crops(imgs[f], [crops_g[f][k] for k in ks], max_new_tokens=20, batch_size=8)
         for row, k, margin in zip(ref, ks, ocap.margins):
-            got = ids[f][k]
-            a = torch.full((T,), cap.w.pad, dtype=torch.long); a[: got.shape[0]] = got
-            b = torch.full((T,), cap.w.pad, dtype=torch.long); b[: row.shape[0]] = row
-            checked += 1
-            if margin < MARGIN:
-                weak += 1
-            elif not torch.equal(a, b):
-                bad.append((f, k, round(margin, 5), a.tolist(), b.tolist()))
-    out.update(caption_crops_checked=checked, caption_crops_below_margin=weak, micro_batches_touched=sorted(mb),
-               frames_touched=sorted({c[0] for c in chosen}))
-    problems = []
-    if bad:
-        problems.append(f"caption ids differ on {len(bad)} of {checked} crops: {bad[:2]}")
-    if weak > checked // 4:
-        problems.append(f"{weak} of {checked} checked crops have an oracle arg-max margin below {MARGIN}")
+            tally.add((f, k), ids[f][k], row, margin, imgs[f], crops_g[f][k])
+    stats, problems = tally.finish()
+    out.update(caption_crops_checked=stats["caption_crops_compared"], caption_crops_total=len(flat), micro_batches_touched=sorted(mb),
+               frames_touched=sorted({c[0] for c in chosen}), **stats)
     # ---- the RxR crop tensor of the last micro-batch is the oracle's pixel_values (bicubic-to-R -> DaViT seam): same u8 resampling
     #      result for every pixel (a difference of one u8 step would be 1.4e-2), bitwise equality recorded
     n_last = len(flat) % sp.batch_size or min(len(flat), sp.batch_size)
@@ -1729,6 +1882,7 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     out["stream_batches_equal_parse_batch"] = n_stream
     if n_stream != 3:
         problems.append(f"parse_stream yielded {n_stream} of 3 batches")
+    record_counters("bench_path", out)
     assert not problems, (problems, out)
     return out
 
@@ -1847,13 +2001,14 @@ def stream_parity_cases():
     return [(seed, w, h) for (w, h, seed) in STREAM_FRAMES]
 
 
-def check_stream_parity(R=64, batch=2, chunk=4, min_margin=1e-3, n_frames=None):
+def check_stream_parity(R=64, batch=2, chunk=4, min_margin=CAPTION_MARGIN, n_frames=None):
     """`omniparser_amd.stream.run_stream` (the configs[3] path: plan by size, equal-resolution device batches through
     ScreenParser.parse_batch with padded plans, packed records, per-chunk gather) on frames of 1920x1080 ... 5120x2880 vs the oracle
     pipeline per frame (ref:eval/ss_pro_gpt4o_omniv2.py:37-51 calls get_som_labeled_img per screenshot: oracle detector -> the
     fixture-pinned hand-off -> oracle crops -> transformers Florence-2): the gathered record of EVERY frame holds the oracle's elements
     one for one (IoU >= 0.999 in ratio units, same text / icon class, same order up to exchanges of equal-score neighbours) and the
-    oracle's caption ids on every captioned icon whose arg-max margin is above `min_margin`."""
+    oracle's caption ids on EVERY captioned icon whose integer crop rectangle equals the oracle's (a mismatch below `min_margin` goes
+    to the f64 referee, CaptionTally)."""
     from PIL import Image
     from oracle import detector_ref as D
     from omniparser_amd import dist as OD
@@ -1886,9 +2041,11 @@ def check_stream_parity(R=64, batch=2, chunk=4, min_margin=1e-3, n_frames=None):
     rec = res["records"]
     assert rec.shape[0] == len(cases) and res["items"] == len(cases) and max(seen) == min(2, len(cases)), (rec.shape, res["items"], seen)
     cpu_model = torch.jit.load(str(blob), map_location="cpu").eval()
-    ocap = _OracleCaptioner(build_random_captioner(0), R)
+    model = build_random_captioner(0)
+    ocap = _OracleCaptioner(model, R)
+    tally = CaptionTally(model, R, margin=min_margin)
     out = {"frames": len(cases), "batches": res["batches"], "sizes": sizes, "elements": [], "captioned": 0, "compared": 0, "rank_swaps": 0,
-           "min_iou": 1.0, "below_margin": 0}
+           "min_iou": 1.0, "R": R}
     problems = []
     for i, (seed, w, h) in enumerate(cases):
         iid, gbx, conf, gcls, gcap = OD.unpack_record(rec[i])
@@ -1914,21 +2071,21 @@ def check_stream_parity(R=64, batch=2, chunk=4, min_margin=1e-3, n_frames=None):
         if not torch.equal(gcls[arg], rcls):
             problems.append(f"frame {i} ({w}x{h}): text / icon classes differ")
         captioned = [k for k, e in enumerate(el_r) if e.get("source") == "box_yolo_content_yolo"][: OD.MAX_DET]
+        from omniparser_amd.util.utils import crop_boxes_px
         for j, k in enumerate(captioned):
             out["captioned"] += 1
-            if ocap.margins[j] < min_margin:
-                out["below_margin"] += 1
-                continue
             # the caption of an icon is a function of its INTEGER crop rectangle (int(ratio * size), ref:util/utils.py:97-100): a box that
             # differs from the oracle's by 1e-4 px can land one pixel apart when the product sits at an integer — another crop, another
             # caption, in any implementation.  Captions are compared where the rectangles are identical (as in check_end_to_end).
-            from omniparser_amd.util.utils import crop_boxes_px
             pg, pr = crop_boxes_px([gbx[int(arg[k])].tolist()], w, h), crop_boxes_px([rbx[k].tolist()], w, h)
             if pg != pr:
                 out["crop_one_pixel_apart"] = out.get("crop_one_pixel_apart", 0) + 1
                 continue
             out["compared"] += 1
-            if not torch.equal(gcap[int(arg[k])], rcap[k]):
-                problems.append(f"frame {i} ({w}x{h}) element {k}: caption ids {gcap[int(arg[k])].tolist()} vs oracle {rcap[k].tolist()} (margin {ocap.margins[j]:.4f})")
+            tally.add((i, k), gcap[int(arg[k])], rcap[k], ocap.margins[j], imgs[i], cr_r[j])
+    stats, cap_problems = tally.finish()
+    out.update(stats)
+    problems += cap_problems
+    record_counters("stream_parity", out)
     assert not problems, (problems[:6], out)
     return out

@@ -23,6 +23,14 @@ def test_bad_pointers_are_errors_not_faults():
     assert "not inside any device allocation" in seen["wild/launch"] and "runs past its allocation" in seen["past_end/plan"], seen
 
 
+def test_split_range_guard_counts_values_beyond_f16():
+    """|x| > 65504 cannot be held by the split-f16 GEMM operands (the fp32 reference has no such limit, ref:util/utils.py:66): every
+    producing kernel counts it, `omni_overflow_count` reads it; 0 on healthy tensors."""
+    import gpu_checks as G
+    out = G.check_range_guard()
+    assert out["healthy"] == 0 and out["split_convert_input_7e4"] >= 1 and out["gemm_split_output"] >= 1 and out["conv_f32_output"] >= 1, out
+
+
 def test_mfma_fragment_layout():
     import gpu_checks as G
     G.check_mfma_layout()

@@ -11,7 +11,7 @@ def test_end_to_end_get_som_labeled_img():
     import gpu_checks as G
     out = G.check_end_to_end(width=0.5, R=64, image_seed=1)
     assert out["n_gpu"] == out["n_ref"] and out["min_iou"] >= 0.999
-    assert out["identical_crops_token_exact"] >= 0.8 * out["captioned"]
+    assert out["identical_crops_token_exact"] >= 0.95 * out["captioned"], out      # the rest: integer crop rectangles one pixel apart (counted)
 
 
 def test_tiled_4k_end_to_end_captions_token_exact():
@@ -19,7 +19,7 @@ def test_tiled_4k_end_to_end_captions_token_exact():
     reference hand-off of the tiled boxes, caption ids of every crop = the CPU oracle's (greedy, token-exact)."""
     import gpu_checks as G
     out = G.check_tiled_captions(width=0.5, R=64)
-    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] >= 0.95 * out["crops"], out
+    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] == out["crops"], out       # every crop, whatever its margin
     print(out)
 
 
@@ -29,7 +29,7 @@ def test_tiled_4k_end_to_end_captions_token_exact_r768():
     generated in the CPU container: tests/golden/gen_oracle_cache.py `tiled`)."""
     import gpu_checks as G
     out = G.check_tiled_captions(width=0.5, R=768)
-    # every crop whose oracle arg-max margin is >= 1e-3 is compared and must be identical (check_tiled_captions asserts it); first run on
-    # the MI355X: 129 of 137 compared, all identical, 8 below the margin (profiles/r5_s10_closing_gpu_suite.txt)
-    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] >= 0.9 * out["crops"], out
+    # EVERY crop is compared (round 5 skipped the 8 of 137 whose oracle margin is below 1e-3); a mismatch is a failure unless the crop's
+    # margin is below 2e-4 AND the f64 oracle does not side with the f32 oracle (gpu_checks.CaptionTally)
+    assert out["crops"] >= 130 and out["micro_batches"] >= 3 and out["compared"] == out["crops"], out
     print(out)

@@ -14,7 +14,7 @@ def test_stream_mixed_resolutions_elements_and_captions_vs_oracle():
     out = G.check_stream_parity(R=64)
     print(out)
     assert out["frames"] >= 7 and out["batches"] >= 6 and out["min_iou"] >= 0.999, out
-    assert out["compared"] >= 0.9 * out["captioned"] and out["captioned"] >= 100, out
+    assert out["compared"] >= 0.97 * out["captioned"] and out["captioned"] >= 100, out      # not compared = integer crop rectangle one pixel apart
 
 
 def test_stream_768_crops_first_frames_vs_oracle():
@@ -23,4 +23,4 @@ def test_stream_768_crops_first_frames_vs_oracle():
     import gpu_checks as G
     out = G.check_stream_parity(R=768, n_frames=2)
     print(out)
-    assert out["frames"] == 2 and out["min_iou"] >= 0.999 and out["compared"] >= 0.9 * out["captioned"] and out["captioned"] >= 20, out
+    assert out["frames"] == 2 and out["min_iou"] >= 0.999 and out["compared"] >= 0.97 * out["captioned"] and out["captioned"] >= 20, out

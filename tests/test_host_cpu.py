@@ -488,3 +488,23 @@ def test_tie_statistics_count_only_decisions_that_can_reach_the_final_list():
     # the unabridged call without a floor counts every decision, as rounds 2-4 did
     stats = {}
     assert D.batched_nms(boxes, scores, cls, 0.5, stats).tolist() == full.tolist() and stats["near_ties"] == 1
+
+
+def test_range_guard_reading_reaches_stats_and_is_fatal_in_strict_mode(monkeypatch):
+    """`ScreenParser._check_range` (round 6): what `omni_overflow_count` returns is accumulated and surfaced; OMNI_STRICT_RANGE=1 — the
+    setting of this test suite (tests/conftest.py) — turns a non-zero reading into an error."""
+    from omniparser_amd.pipeline import ScreenParser
+    sp = ScreenParser.__new__(ScreenParser)
+    readings = iter([0, 5])
+    monkeypatch.setattr(L, "overflow_count", lambda reset=True: next(readings))
+    monkeypatch.setenv("OMNI_STRICT_RANGE", "0")
+    sp._check_range()
+    assert sp.range_overflow_last == 0 and sp.range_overflow_total == 0
+    sp._check_range()
+    assert sp.range_overflow_last == 5 and sp.range_overflow_total == 5
+    monkeypatch.setattr(L, "overflow_count", lambda reset=True: 3)
+    monkeypatch.setenv("OMNI_STRICT_RANGE", "1")
+    with pytest.raises(L.OmniError, match="range guard"):
+        sp._check_range()
+    import os
+    assert os.environ.get("OMNI_STRICT_RANGE") == "1"

@@ -54,6 +54,14 @@ def test_gemm_dma_presplit_every_tile(emu):
     assert r["cases"] == 3 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
 
 
+def test_split_range_guard_counts_values_beyond_f16(emu):
+    """the split formats clamp / lose |x| > 65504 and the fp32 reference does not — the producing kernels count it
+    (omni_overflow_count), the pipeline surfaces it in stats["split_overflow"] and raises under OMNI_STRICT_RANGE=1."""
+    import gpu_checks as G
+    out = G.check_range_guard()
+    assert out["healthy"] == 0 and out["gemm_split_output"] >= 1
+
+
 def test_greedy_step_never_emits_an_out_of_range_id(emu):
     import gpu_checks as G
     G.check_greedy_degenerate_rows()

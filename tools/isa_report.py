@@ -67,7 +67,9 @@ def report(stem: str, flt: str = ""):
     rows = []
     for st in starts:
         name = asm[st].split(":")[0]
-        en = next(i for i in range(st, len(asm)) if ".end_amdhsa_kernel" in asm[i])
+        en = next((i for i in range(st, len(asm)) if ".end_amdhsa_kernel" in asm[i]), None)
+        if en is None:          # a _Z label that is not a kernel entry (device data, e.g. the range-guard counter's section)
+            continue
         body = asm[st:en]
         meta = {}
         for l in body:
