@@ -125,7 +125,10 @@ enum {
    *  i0 cap i1 max_det i2 img_w i3 img_h ; f0 iou
    *  i4 frames (0 = 1): frame f reads cand + f*cap records, count[f], sorted + f*(cap+1) records, writes out_* + f*max_det, out_count[f]
    *  (the mask scratch is shared: frames that need it run one after another); i5 = 1: force the tiled kernels (tests).
-   *  Frames with <= 2048 candidates are sorted and suppressed by one workgroup out of LDS; the result is the same list either way. */
+   *  Frames with <= 2048 candidates are sorted and suppressed by one workgroup out of LDS; the result is the same list either way.
+   *  omni_cand_t.anchor (the tie-break of equal scores = torch's stable sort over anchor order) must lie in [0, 2^21) on that path —
+   *  true of everything OMNI_OP_DETECT_DECODE writes; values outside are saturated (never mis-sorted against the score) and tie-break
+   *  by slot.  A caller with larger anchor ids sets i5 = 1. */
   OMNI_OP_NMS = 7,
   /* x + depthwise3x3(x) + bias (DaViT conv1/conv2, hf:models/florence2/modeling_florence2.py:432-436).
    *  p0 x [B,H,W,C] p1 w [3][3][C] p2 bias f32[C] p4 y; i0 B i1 H i2 W i3 C */

@@ -322,7 +322,10 @@ __global__ __launch_bounds__(1024) void nms_block_kernel(NmsArgs a) {
     if (i < n) {
       Cand c = cand[i];
       m = fmaxf(m, fmaxf(fmaxf(c.x1, c.y1), fmaxf(c.x2, c.y2)));
-      k = ((unsigned long long)(~f32_bits(c.score)) << 32) | ((unsigned long long)(unsigned)c.anchor << 11) | (unsigned)i;
+      // anchor is caller-supplied through the ABI (OMNI_OP_NMS p0): saturated into its 21 key bits so that a value outside
+      // [0, 2^21) — which OMNI_OP_DETECT_DECODE never produces — cannot spill into the score bits; such candidates order by slot
+      const unsigned an = min((unsigned)c.anchor, (1u << NMS_FAST_ANCHOR_BITS) - 1u);
+      k = ((unsigned long long)(~f32_bits(c.score)) << 32) | ((unsigned long long)an << 11) | (unsigned)i;
     }
     key[i] = k;
     dead[i] = 0;

@@ -692,8 +692,12 @@ class Florence2Captioner:
 
     @staticmethod
     def decode_bucket(n: int) -> int:
-        """row capacity of the merged decode plan for n crops: multiples of 128 (the unused tail rows are computed and ignored)."""
-        return max(128, (n + 127) // 128 * 128)
+        """row capacity of the merged decode plan for n crops: multiples of 32 (the unused tail rows are computed and ignored).  Rounds
+        3-5 rounded to 128: at the benched load (345 crops) that decoded 384 rows, i.e. 11 % of every per-row decode kernel —
+        cross-attention streams 21.6 MB of K / V per row and step — was padding (50.4 vs 48.0 ms per batch measured in
+        round 3's probe).  The micro-batches copy exactly their own n rows into the plan (`_encode_into`), so any capacity >= n works;
+        32 keeps the number of distinct plans (8 GB each at 384 rows) small on a stream with varying crop counts."""
+        return max(128, (n + 31) // 32 * 32)
 
     # ---- resident plan sets: ONE cache for encode and decode plans, bounded by BYTES (and, secondarily, by count), LRU, never
     # evicting what the batch being issued has already taken.  A 128-row plan set at 768x768 crops holds ~25 GB of activations (60 GB without activation reuse), a

@@ -49,12 +49,17 @@ def _precision_from_env(precision):
 _CONV_TUNING = "unset"
 
 
-def conv_tuning():
+def conv_tuning(device=None):
     """The committed tuning table of the detector's split-f16 convolutions (`omniparser_amd/conv_tuning_gfx950.json`, written by
     tools/conv_autotune.py from serialized graph replays on the MI355X): {shape key: [tile code, split-K count]}.  OMNI_CONV_TUNING=0
     turns it off (A/B), a missing file means the launcher's heuristic everywhere.  Tuning changes which K partials are summed in which
-    order, nothing else; it is applied to the detector only (the captioner's plans of different capacities stay bit-identical)."""
+    order, nothing else; it is applied to the detector only (the captioner's plans of different capacities stay bit-identical).
+    `device`: a cuda device whose architecture is not gfx950 gets the heuristic (the table is a measurement of that chip)."""
     global _CONV_TUNING
+    if device is not None and torch.device(device).type == "cuda":
+        arch = getattr(torch.cuda.get_device_properties(device), "gcnArchName", "")
+        if not arch.startswith("gfx950"):
+            return None
     if _CONV_TUNING == "unset":
         import json
         path = Path(__file__).resolve().parents[1] / "conv_tuning_gfx950.json"
@@ -74,7 +79,7 @@ class _DetectPlan:
         pad_left, pad_top = (tw - rw) // 2, (th - rh) // 2
         self.geom = (tw, th, scale, rw, rh, pad_left, pad_top)
         pb = PlanBuilder(det.device, det.dtype)
-        pb.conv_tuning = conv_tuning()               # per-shape tile / split-K choices measured on the MI355X (None: the launcher's heuristic)
+        pb.conv_tuning = conv_tuning(det.device)               # per-shape tile / split-K choices measured on the MI355X (None: the launcher's heuristic)
         self.pb = pb
         self.batch = batch
         V = pb.V

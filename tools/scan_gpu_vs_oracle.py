@@ -46,6 +46,23 @@ def run_oracle(lo, hi):
     CACHE.write_text(json.dumps(out))
 
 
+def provenance():
+    """what the scan was measured WITH: bench.py quotes a scan only while these still describe the tree (the round-5 scan
+    predated the conv tuning table, which changes the summation order of 84 conv shapes)."""
+    import hashlib
+    import subprocess
+    def sha16(p):
+        return hashlib.sha256(p.read_bytes()).hexdigest()[:16] if p.exists() else None
+    try:
+        rev = subprocess.run(["git", "rev-parse", "--short=12", "HEAD"], cwd=ROOT, capture_output=True, text=True).stdout.strip() or None
+    except OSError:
+        rev = None
+    import os
+    return {"git_rev": rev, "conv_tuning_sha16": sha16(ROOT / "omniparser_amd" / "conv_tuning_gfx950.json"),
+            "conv_tuning_applied": os.environ.get("OMNI_CONV_TUNING", "1") != "0",
+            "kernel_sources_sha16": hashlib.sha256(b"".join(p.read_bytes() for p in sorted((ROOT / "omniparser_amd" / "csrc").glob("*.h*")))).hexdigest()[:16]}
+
+
 def run_device():
     from omniparser_amd.pipeline import ScreenParser
     from omniparser_amd.synth import synthetic_ocr, synthetic_screenshot
@@ -82,9 +99,21 @@ def run_device():
             max(abs(x - y) for x, y in zip(a["bbox"], b["bbox"])) < 1e-5 for a, b in zip(el_g, el_r))
         tf = g["near_ties"] == 0 and g["score_ties"] == 0
         n_boxes_exact += boxes_ok; n_exact += elems_ok; tie_free += tf; tie_free_exact += (tf and elems_ok)
-        rows.append({"seed": s, "boxes": [len(rb), len(gb)], "elements": [len(el_r), len(el_g)], "oracle_ties": [g["near_ties"], g["score_ties"]],
-                     "boxes_identical": bool(boxes_ok), "elements_identical": bool(elems_ok)})
-    print(json.dumps({"frames": len(rows), "final_boxes_identical": n_boxes_exact, "elements_and_crops_identical": n_exact,
+        row = {"seed": s, "boxes": [len(rb), len(gb)], "elements": [len(el_r), len(el_g)], "oracle_ties": [g["near_ties"], g["score_ties"]],
+               "boxes_identical": bool(boxes_ok), "elements_identical": bool(elems_ok)}
+        if boxes_ok and not elems_ok:
+            # boxes pair one to one and the hand-off still differs (round 5: seed 63, unexplained): record WHICH decision — the first
+            # element that differs, the largest box difference of the frame in pixels, and the hand-off's own margins for that element
+            # (overlap-removal compares IoU / area ratios of ratio-coordinate boxes against fixed thresholds: a 1e-4 px difference can flip one)
+            d = (rb[:, None, :] - gb[None, :, :]).abs().amax(2).min(1).values
+            row["max_box_diff_px"] = float(d.max())
+            for k, (a, b) in enumerate(zip(el_g, el_r)):
+                if (a["type"], a["source"], a["content"]) != (b["type"], b["source"], b["content"]) or max(abs(x - y) for x, y in zip(a["bbox"], b["bbox"])) >= 1e-5:
+                    row["first_difference"] = {"index": k, "device": {kk: a[kk] for kk in ("type", "source", "bbox")}, "oracle": {kk: b[kk] for kk in ("type", "source", "bbox")}}
+                    break
+            row["crop_rects_differ"] = [list(c) for c in cr_r] != [list(c) for c in cr_g]
+        rows.append(row)
+    print(json.dumps({"provenance": provenance(), "frames": len(rows), "final_boxes_identical": n_boxes_exact, "elements_and_crops_identical": n_exact,
                       "oracle_tie_free_frames": tie_free, "tie_free_and_identical": tie_free_exact,
                       "definition": "identical = same count, one-to-one pairing at IoU >= 0.999 (zero-area boxes by coordinates), then the same element "
                                     "list (type / source / content / order, bbox within 1e-5 in ratio units) and the same integer crop rectangles",
