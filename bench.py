@@ -47,6 +47,8 @@ def parse_args():
     ap.add_argument("--caption-res", type=int, default=768, choices=[64, 768])
     ap.add_argument("--imgsz", default="640", help="'640' (reference default) or 'native' (1088x1920 network input)")
     ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--micro-batch", type=int, default=int(os.environ.get("OMNI_CAPTION_MICRO_BATCH", "128")), choices=[32, 64, 96, 128],
+                    help="crops per caption micro-batch (plan capacity; the reference's batch_size = 128, ref:util/utils.py:89)")
     ap.add_argument("--no-extra", action="store_true", help="skip the `extra` object (configs[1], 64x64 crops, tiled 4K)")
     ap.add_argument("--no-pipeline", dest="pipeline", action="store_false",
                     help="time K synchronous parse_batch calls instead of the K steps through ScreenParser.parse_stream (the default: "
@@ -134,7 +136,8 @@ def main():
         from omniparser_amd.florence import Florence2Captioner
         from omniparser_amd.pipeline import ScreenParser
         cap = Florence2Captioner(caption_dir(0), dev, precision=args.precision, resolution=args.caption_res)
-        parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz)
+        parser = ScreenParser(det, cap, box_threshold=CONF, iou_threshold=OVERLAP_IOU, nms_iou=NMS_IOU, max_det=MAX_DET, imgsz=imgsz,
+                              batch_size=args.micro_batch)
         parser.encode_lanes = args.lanes
     else:
         dp = det.get_plan(IW, IH, imgsz, CONF, NMS_IOU, MAX_DET, batch=B)
@@ -192,6 +195,13 @@ def main():
     sync_all()
     crop_counts.clear()
     step_done.clear()
+    import gc
+    gc_mode = os.environ.get("OMNI_BENCH_GC", "on")          # diagnostic for the one-step-in-twenty +40 ms outlier: off | freeze | on
+    if gc_mode == "off":
+        gc.disable()
+    elif gc_mode == "freeze":
+        gc.collect(); gc.freeze()
+    gc_before = [g["collections"] for g in gc.get_stats()]
     t0 = time.perf_counter()
     if args.pipeline and args.mode == "e2e":
         # the same K steps as a software pipeline over batches (ScreenParser.parse_stream): detector + hand-off of step i+1 overlap
@@ -210,7 +220,10 @@ def main():
         allr = OD.gather_records(recs, n_items, rank, world)
     sync_all()
     elapsed = time.perf_counter() - t0
-    note(f"timed region done: {elapsed:.2f} s for {args.steps} steps")
+    gc_runs = [g["collections"] - b for g, b in zip(gc.get_stats(), gc_before)]
+    if gc_mode == "off":
+        gc.enable()
+    note(f"timed region done: {elapsed:.2f} s for {args.steps} steps (gc {gc_mode}: collections per generation {gc_runs})")
     if world > 1:
         t = torch.tensor([elapsed], dtype=torch.float64, device=dev)
         dist.all_reduce(t, op=dist.ReduceOp.MAX)
@@ -245,13 +258,14 @@ def main():
     }
     if args.mode == "e2e":
         out["config"]["mean_crops_per_screenshot"] = round(sum(crop_counts) / max(len(crop_counts), 1) / B, 2)
-        out["config"]["caption_micro_batch"] = 128
+        out["config"]["caption_micro_batch"] = args.micro_batch
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
         out["config"]["steps_pipelined"] = bool(args.pipeline)
         # wall time between consecutive steps' results inside the timed region (pipelined: step i's results arrive while step i+1 runs)
         out["config"]["step_wall_ms"] = [round(1000.0 * (b - a), 1) for a, b in zip([t0] + step_done[:-1], step_done)][:40]
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
+        out["config"]["python_gc"] = {"mode": gc_mode, "collections_in_timed_region": gc_runs}
         if args.pipeline:
             out["config"]["pipeline"] = ("parse_stream: detector + hand-off graph of step i+1 on the detector's stream, caption micro-batches alternating "
                                          "over %d encode stream(s), the 20 decode steps of step i on their own stream (two decode plans)" % args.lanes)
@@ -351,18 +365,31 @@ def main():
 
 def pack_records(recs, B, dev, step_id, li, elems, ids):
     """the parsed elements of one step's B screenshots -> rows li*B .. li*B+B-1 of the job's record table (what the all_gather moves):
-    boxes in ratio coordinates, caption ids on the rows of the icons that were captioned, in element order."""
+    boxes in ratio coordinates, caption ids on the rows of the icons that were captioned, in element order.  Same layout as
+    `dist.pack_record` (the tests unpack it with `dist.unpack_record`), assembled in ONE host array and ONE upload per step: round 5
+    built 8 records with ~50 small torch ops each and uploaded them one by one — 15 ms of host time per step, in the open after the
+    last step of a pipelined run (K = 3: 2 % of the line)."""
+    import numpy as np
     import torch
     from omniparser_amd import dist as OD
+    MD, CT = OD.MAX_DET, OD.CAP_TOK
+    host = np.zeros((B, OD.REC_W), dtype=np.int32)
     for j in range(B):
-        boxes = torch.tensor([e["bbox"] for e in elems[j]], dtype=torch.float32).reshape(-1, 4)[:MAX_DET]
-        k = boxes.shape[0]
-        capt = torch.zeros(k, OD.CAP_TOK, dtype=torch.long)
+        el = elems[j][:MD]
+        k = len(el)
+        r = host[j]
+        r[0], r[1] = step_id * B + j, k
+        if k:
+            r[2:2 + 4 * k] = np.asarray([e["bbox"] for e in el], dtype=np.float32).reshape(-1).view(np.int32)
+            r[2 + 4 * MD:2 + 4 * MD + k] = np.ones(k, dtype=np.float32).view(np.int32)
+        # cls stays 0; caption ids on the rows of the captioned icons
+        cap = r[2 + 6 * MD:].reshape(MD, CT)
         ic = [i for i, e in enumerate(elems[j]) if e["source"] == "box_yolo_content_yolo"][:len(ids[j])]
         for row, i in zip(ids[j], ic):
             if i < k:
-                capt[i, : row.shape[0]] = row
-        recs[li * B + j] = OD.pack_record(step_id * B + j, boxes, torch.ones(k), torch.zeros(k, dtype=torch.long), capt).to(dev)
+                v = row.numpy() if hasattr(row, "numpy") else np.asarray(row)
+                cap[i, :min(len(v), CT)] = v[:CT]
+    recs[li * B:li * B + B].copy_(torch.from_numpy(host), non_blocking=True)
 
 
 def child_json(cmd, env, limit_s, keep=None):

@@ -320,7 +320,7 @@ class ScreenParser:
                 lane = self._mb_count = (getattr(self, "_mb_count", -1) + 1) % len(lanes)
             stream = lanes[lane]
             bucket = cap.bucket(n)
-            cp = cap.plans(bucket, R, max_new_tokens, slot=lane if bucket == 128 else 0)
+            cp = cap.plans(bucket, R, max_new_tokens, slot=lane if n == self.batch_size else 0)    # full micro-batches: one plan per lane
             with torch.cuda.stream(stream):
                 if cp.free_evt is not None:
                     stream.wait_event(cp.free_evt)
@@ -377,6 +377,22 @@ class ScreenParser:
             self._ev["capE"] = cap.stream.record_event(torch.cuda.Event(enable_timing=True))
         return (list(frames), flat, ids_all, ids_stream)
 
+    def _settle_gc(self):
+        """Python's generational collector, not the GPU, produced the one-step-in-twenty +40...70 ms of the round-5 bench lines
+        (profiles/r6_s2_gc_*.json: one gen-2 collection inside the driver's 20 steps = the one 733 ms step; none with the collector off
+        or frozen).  The plans of a parser are tens of thousands of long-lived Python objects (op descriptors, views, tensors): every
+        full collection walks them all while the GPU pipeline waits for the host to queue the next batch.  After each of the first
+        batches (all plan sets of the steady state exist by then: two encode lanes, the remainder plan, two decode plans) the survivors
+        are moved to the permanent generation (`gc.freeze`), so later collections only look at what a batch allocates.  The collector
+        stays on; OMNI_GC_FREEZE=0 turns this off."""
+        n = getattr(self, "_gc_settled", 0)
+        if n >= 3 or os.environ.get("OMNI_GC_FREEZE", "1") == "0":
+            return
+        import gc
+        gc.collect()
+        gc.freeze()
+        self._gc_settled = n + 1
+
     def _check_range(self):
         """Range guard of the split-f16 GEMM operands (include/omni_amd.h::omni_overflow_count), read where the host has just waited for
         a batch's ids anyway: a value beyond the f16 range was clamped (format B) or lost (format A) somewhere in the last batch(es) —
@@ -399,6 +415,7 @@ class ScreenParser:
             ids_all = [t.cpu() for t in ids_all]
         ids_all = [cap._finish_ids(t.long()) for t in ids_all]
         self._check_range()
+        self._settle_gc()
         out = [[] for _ in frames]
         k = 0
         for ids in ids_all:

@@ -71,7 +71,7 @@ def run_device():
     gold = json.loads(CACHE.read_text())
     det = YOLOv9Detector(model_path=ensure_blob(seed=0, nc=1, width=1.0), device="cuda", precision="f32")
     sp = ScreenParser(det, None, box_threshold=0.05, iou_threshold=0.7, nms_iou=0.1, max_det=300, imgsz=640)
-    rows, n_exact, n_boxes_exact, tie_free, tie_free_exact = [], 0, 0, 0, 0
+    rows, n_exact, n_boxes_exact, tie_free, tie_free_exact, n_sets = [], 0, 0, 0, 0, 0
     for s in sorted(map(int, gold)):
         g = gold[str(s)]
         rb, rs = unbits(g["boxes"], 4), unbits(g["conf"])
@@ -112,8 +112,17 @@ def run_device():
                     row["first_difference"] = {"index": k, "device": {kk: a[kk] for kk in ("type", "source", "bbox")}, "oracle": {kk: b[kk] for kk in ("type", "source", "bbox")}}
                     break
             row["crop_rects_differ"] = [list(c) for c in cr_r] != [list(c) for c in cr_g]
+            # round 6 (seeds 60 / 63 of the round-5 scan, "one hand-off decision differs"): both were RANK EXCHANGES — two non-overlapping
+            # boxes whose oracle scores differ by 4e-7 / 6e-7 (an f32 ulp or two) leave the two NMS implementations in the other order, and the
+            # element list follows the score order.  Same elements, same crop rectangles, as SETS; counted separately from real differences.
+            key = lambda e: (e["type"], e["source"], e["content"], tuple(round(v, 5) for v in e["bbox"]))
+            row["identical_as_sets"] = sorted(map(key, el_g)) == sorted(map(key, el_r)) and sorted(map(tuple, cr_g)) == sorted(map(tuple, cr_r))
+            gaps = (rs[:-1] - rs[1:]).abs()
+            row["oracle_adjacent_score_gaps_below_4e-6"] = int((gaps < 4e-6).sum())
+            n_sets += bool(row["identical_as_sets"])
         rows.append(row)
     print(json.dumps({"provenance": provenance(), "frames": len(rows), "final_boxes_identical": n_boxes_exact, "elements_and_crops_identical": n_exact,
+                      "identical_up_to_exchanges_of_equal_score_neighbours": n_exact + n_sets,
                       "oracle_tie_free_frames": tie_free, "tie_free_and_identical": tie_free_exact,
                       "definition": "identical = same count, one-to-one pairing at IoU >= 0.999 (zero-area boxes by coordinates), then the same element "
                                     "list (type / source / content / order, bbox within 1e-5 in ratio units) and the same integer crop rectangles",
