@@ -115,8 +115,16 @@ def run_device():
             # round 6 (seeds 60 / 63 of the round-5 scan, "one hand-off decision differs"): both were RANK EXCHANGES — two non-overlapping
             # boxes whose oracle scores differ by 4e-7 / 6e-7 (an f32 ulp or two) leave the two NMS implementations in the other order, and the
             # element list follows the score order.  Same elements, same crop rectangles, as SETS; counted separately from real differences.
-            key = lambda e: (e["type"], e["source"], e["content"], tuple(round(v, 5) for v in e["bbox"]))
-            row["identical_as_sets"] = sorted(map(key, el_g)) == sorted(map(key, el_r)) and sorted(map(tuple, cr_g)) == sorted(map(tuple, cr_r))
+            left = list(el_g)
+            same = len(el_g) == len(el_r)
+            for b in el_r:                  # order-free pairing with the in-order comparison's own tolerance (1e-5 in ratio units)
+                j = next((j for j, a in enumerate(left) if (a["type"], a["source"], a["interactivity"], a["content"]) ==
+                          (b["type"], b["source"], b["interactivity"], b["content"]) and max(abs(x - y) for x, y in zip(a["bbox"], b["bbox"])) < 1e-5), None)
+                if j is None:
+                    same = False
+                    break
+                left.pop(j)
+            row["identical_as_sets"] = bool(same and not left and sorted(map(tuple, cr_g)) == sorted(map(tuple, cr_r)))
             gaps = (rs[:-1] - rs[1:]).abs()
             row["oracle_adjacent_score_gaps_below_4e-6"] = int((gaps < 4e-6).sum())
             n_sets += bool(row["identical_as_sets"])
