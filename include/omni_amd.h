@@ -212,7 +212,13 @@ enum {
    *  u8[units * 4640] p4 out/scratch meta u32[i3]: {zlib stream bytes, FILE BYTES, base64 bytes, CRC segments, unit sizes..., unit
    *  offsets...} p5 scratch u32[i4] (Adler / CRC partials) p6 out base64 ASCII (4 ceil(capacity / 3) bytes) or NULL
    *  i0 H i1 W i2 capacity of p1 (>= H (3 W + 1) + 5 units + 63) i3 meta words (>= 4 + 2 units) i4 scratch words
-   *  (>= 2 H + ceil((capacity - 53) / 4096)) */
+   *  (>= 2 H + ceil((capacity - 53) / 4096))
+   *  i5 = 1 (round 6, what `OMNI_OVERLAY=device` uses): LZ77 + DYNAMIC Huffman instead — units of 32768 bytes, one GPU lane per
+   *  unit: greedy matches against distance 1 / 3 and a 13-bit single-entry hash table of the unit's own 3-byte strings, one dynamic
+   *  block per unit (length-limited canonical codes built on the device) + the empty stored block; ~1.1x (desktop screenshots) ...
+   *  1.3x (noise-heavy frames) the bytes of Pillow's zlib level 6 (the fixed-Huffman variant: 2.7x).  Needs p3 >= ceil(H (3 W + 1) /
+   *  32768) * 33792 bytes and p7 = token scratch u32[ceil(H (3 W + 1) / 32768) * 32768]; same capacities otherwise.  Bytes =
+   *  oracle/png_ref.py::deflate_png_lz. */
   OMNI_OP_PNG_DEFLATE = 23,
   /* FFN of a DaViT block as one kernel (hf:models/florence2/modeling_florence2.py Florence2VisionMLP inside the residual of
    * Florence2VisionSpatialBlock / ChannelBlock): y = residual + fc2(GELU(fc1(x))), hidden activations kept in registers

@@ -388,6 +388,270 @@ __global__ __launch_bounds__(64) void png_gather_kernel(DefArgs a) {
   for (unsigned k = threadIdx.x; k < sz; k += 64) dst[k] = src[k];
 }
 
+
+// ------------------------------------------------------------------------------------ PNG with an LZ77 + dynamic-Huffman stream
+// OMNI_OP_PNG_DEFLATE i5 = 1 (round 6).  Specification, step by step and tie-break by tie-break: oracle/png_ref.py::deflate_unit_lz —
+// this kernel must produce those bytes.  One 32 KiB unit of the Up-filtered stream per workgroup; LANE 0 does the (inherently serial)
+// greedy tokenisation with a 13-bit, one-entry-per-bucket hash table in LDS (plus the distance-1 / distance-3 run candidates of the
+// fixed-Huffman variant), counts symbol frequencies on the way, builds the two length-limited Huffman codes and the code-length code
+// in LDS, and writes ONE dynamic block + an empty stored block into the unit's slot (stored form if that is not smaller).  190 units
+// per 1080p frame: a latency-bound kernel by construction (one lane per CU's worth of work), ~10 ms — against ~100-300 ms of host
+// zlib for the reference's PNG (ref:util/utils.py:485-488) and 2.7x the bytes for the fixed-Huffman variant above.
+constexpr int UNIT_LZ = 32768;
+constexpr int SLOT_LZ = UNIT_LZ + 1024;   // a short unit's block header (<= ~600 bytes) is written before its size is known
+constexpr int HASH_BITS = 13;
+constexpr int NLIT = 286, NDIST = 30, NCL = 19;
+
+struct LzWork {
+  unsigned short table[1 << HASH_BITS];
+  unsigned freq[NLIT + NDIST + NCL];
+  unsigned char lens[NLIT + NDIST + NCL];
+  unsigned short codes[NLIT + NDIST + NCL];
+  unsigned weight[2 * NLIT - 1];
+  unsigned short parent[2 * NLIT - 1];
+  unsigned short depth[2 * NLIT - 1];
+  unsigned short order[NLIT];
+  unsigned rle[NLIT + NDIST];            // symbol | extra bit count << 8 | extra value << 16
+};
+
+__device__ __forceinline__ unsigned lz_hash3(unsigned b0, unsigned b1, unsigned b2) {
+  return (((b0 << 16) | (b1 << 8) | b2) * 0x9E3779B1u) >> (32 - HASH_BITS);
+}
+// length symbol index k (0..28), extra bits, extra value of a match length 3..258 (RFC 1951 3.2.5)
+__device__ __forceinline__ void lz_len_code(int len, int& k, int& eb, unsigned& ev) {
+  if (len <= 10) { k = len - 3; eb = 0; ev = 0; }
+  else if (len == 258) { k = 28; eb = 0; ev = 0; }
+  else {
+    const unsigned m = (unsigned)(len - 3);
+    const int e = 31 - __builtin_clz(m) - 2;
+    const unsigned idx = (m >> e) - 4u;
+    k = 4 + 4 * e + (int)idx; eb = e; ev = m - ((idx + 4u) << e);
+  }
+}
+__device__ __forceinline__ void lz_dist_code(int dist, int& k, int& eb, unsigned& ev) {
+  if (dist <= 4) { k = dist - 1; eb = 0; ev = 0; }
+  else {
+    const unsigned m = (unsigned)(dist - 1);
+    const int e = 31 - __builtin_clz(m) - 1;
+    k = 2 * (e + 1) + (int)((m >> e) & 1u); eb = e; ev = m & ((1u << e) - 1u);
+  }
+}
+
+// oracle/png_ref.py::huffman_lengths: two-queue Huffman over the used symbols sorted by (frequency, symbol), Kraft repair to max_bits
+__device__ void lz_huffman_lengths(LzWork& w, const unsigned* freq, int n, int max_bits, unsigned char* lens) {
+  int m = 0;
+  for (int s = 0; s < n; ++s) { lens[s] = 0; if (freq[s] > 0) w.order[m++] = (unsigned short)s; }
+  for (int i = 1; i < m; ++i) {                        // stable insertion sort: equal frequencies stay in symbol order
+    const unsigned short key = w.order[i];
+    const unsigned kf = freq[key];
+    int j = i - 1;
+    while (j >= 0 && freq[w.order[j]] > kf) { w.order[j + 1] = w.order[j]; --j; }
+    w.order[j + 1] = key;
+  }
+  if (m == 0) return;
+  if (m == 1) { lens[w.order[0]] = 1; return; }
+  for (int k = 0; k < m; ++k) w.weight[k] = freq[w.order[k]];
+  int leaf = 0, inode = m, nxt = m;
+  for (int it = 0; it < m - 1; ++it) {
+    int pick[2];
+    for (int k = 0; k < 2; ++k) {
+      if (leaf < m && (inode >= nxt || w.weight[leaf] <= w.weight[inode])) pick[k] = leaf++;
+      else pick[k] = inode++;
+    }
+    w.weight[nxt] = w.weight[pick[0]] + w.weight[pick[1]];
+    w.parent[pick[0]] = (unsigned short)nxt; w.parent[pick[1]] = (unsigned short)nxt;
+    ++nxt;
+  }
+  w.depth[2 * m - 2] = 0;
+  for (int k = 2 * m - 3; k >= 0; --k) w.depth[k] = (unsigned short)(w.depth[w.parent[k]] + 1);
+  int count[16];
+  for (int b = 0; b <= max_bits; ++b) count[b] = 0;
+  for (int k = 0; k < m; ++k) count[min((int)w.depth[k], max_bits)]++;
+  long long total = 0;
+  for (int b = 1; b <= max_bits; ++b) total += (long long)count[b] << (max_bits - b);
+  while (total > (1ll << max_bits)) {
+    count[max_bits]--;
+    for (int b = max_bits - 1; b > 0; --b)
+      if (count[b]) { count[b]--; count[b + 1] += 2; break; }
+    --total;
+  }
+  int k = 0;
+  for (int b = max_bits; b > 0; --b)
+    for (int c = 0; c < count[b]; ++c) lens[w.order[k++]] = (unsigned char)b;
+}
+
+__device__ void lz_canonical_codes(const unsigned char* lens, int n, int max_bits, unsigned short* codes) {
+  int bl[17], nxt[17];
+  for (int b = 0; b <= max_bits + 1; ++b) bl[b] = 0;
+  for (int s = 0; s < n; ++s) bl[lens[s]]++;
+  bl[0] = 0;
+  int code = 0;
+  for (int b = 1; b <= max_bits; ++b) { code = (code + bl[b - 1]) << 1; nxt[b] = code; }
+  for (int s = 0; s < n; ++s) { codes[s] = 0; if (lens[s]) codes[s] = (unsigned short)nxt[lens[s]]++; }
+}
+
+__global__ __launch_bounds__(64) void png_lz_units_kernel(DefArgs a, unsigned* __restrict__ toks_all) {
+  __shared__ LzWork w;
+  if (threadIdx.x != 0) return;                          // one lane per unit (see the header comment)
+  const int u = blockIdx.x;
+  const long long start = (long long)u * UNIT_LZ;
+  const long long end = min(start + (long long)UNIT_LZ, a.U);
+  const bool final_unit = u == a.nunits - 1;
+  const unsigned char* __restrict__ f = a.filt;
+  unsigned* __restrict__ toks = toks_all + (long long)u * UNIT_LZ;
+  for (int k = 0; k < (1 << HASH_BITS); ++k) w.table[k] = 0;
+  unsigned* lf = w.freq; unsigned* df = w.freq + NLIT; unsigned* cf = w.freq + NLIT + NDIST;
+  for (int k = 0; k < NLIT + NDIST + NCL; ++k) w.freq[k] = 0;
+  // ---- tokens
+  int nt = 0;
+  auto mlen = [&](long long i, long long d) {
+    int l = 0;
+    while (i + l < end && l < 258 && f[i + l] == f[i + l - d]) ++l;
+    return l;
+  };
+  auto insert = [&](long long q) {
+    if (q + 2 < end) w.table[lz_hash3(f[q], f[q + 1], f[q + 2])] = (unsigned short)(q - start + 1);
+  };
+  long long i = start;
+  while (i < end) {
+    int best = 0; long long bd = 0;
+    if (i >= 1) { best = mlen(i, 1); bd = 1; }
+    if (i >= 3) { const int l = mlen(i, 3); if (l > best) { best = l; bd = 3; } }
+    if (i + 2 < end) {
+      const unsigned c = w.table[lz_hash3(f[i], f[i + 1], f[i + 2])];
+      if (c) {
+        const long long d = i - (start + (long long)c - 1);
+        int l = mlen(i, d);
+        if (d > 3 && l < 4) l = 0;
+        if (l > best || (l == best && l > 0 && d < bd)) { best = l; bd = d; }
+      }
+    }
+    if (best >= 3) {
+      toks[nt++] = ((unsigned)best << 16) | (unsigned)bd;
+      int k, eb; unsigned ev;
+      lz_len_code(best, k, eb, ev); lf[257 + k]++;
+      lz_dist_code((int)bd, k, eb, ev); df[k]++;
+      for (long long q = i; q < i + best; ++q) insert(q);
+      i += best;
+    } else {
+      toks[nt++] = (unsigned)f[i] << 16;
+      lf[f[i]]++;
+      insert(i);
+      ++i;
+    }
+  }
+  lf[256]++;
+  {
+    int used = 0;
+    for (int s = 0; s < NLIT; ++s) used += lf[s] != 0;
+    if (used < 2) lf[lf[0] == 0 ? 0 : 1]++;
+    for (int s = 0; s < 2; ++s) {
+      used = 0;
+      for (int t = 0; t < NDIST; ++t) used += df[t] != 0;
+      if (used < 2 && df[s] == 0) df[s] = 1;
+    }
+  }
+  unsigned char* ll = w.lens; unsigned char* dl = w.lens + NLIT; unsigned char* cl = w.lens + NLIT + NDIST;
+  unsigned short* lc = w.codes; unsigned short* dc = w.codes + NLIT; unsigned short* cc = w.codes + NLIT + NDIST;
+  lz_huffman_lengths(w, lf, NLIT, 15, ll);
+  lz_huffman_lengths(w, df, NDIST, 15, dl);
+  lz_canonical_codes(ll, NLIT, 15, lc);
+  lz_canonical_codes(dl, NDIST, 15, dc);
+  int hlit = 257, hdist = 1;
+  for (int s = 0; s < NLIT; ++s) if (ll[s]) hlit = max(hlit, s + 1);
+  for (int s = 0; s < NDIST; ++s) if (dl[s]) hdist = max(hdist, s + 1);
+  // ---- run-length coding of the code-length sequence ll[0..hlit) ++ dl[0..hdist)
+  int nr = 0;
+  {
+    const int n = hlit + hdist;
+    auto at = [&](int k) -> int { return k < hlit ? ll[k] : dl[k - hlit]; };
+    int p = 0;
+    while (p < n) {
+      const int v = at(p);
+      int j = p;
+      while (j < n && at(j) == v) ++j;
+      int run = j - p;
+      if (v == 0) {
+        while (run >= 11) { const int r = min(run, 138); w.rle[nr++] = 18u | (7u << 8) | ((unsigned)(r - 11) << 16); run -= r; }
+        if (run >= 3) { w.rle[nr++] = 17u | (3u << 8) | ((unsigned)(run - 3) << 16); run = 0; }
+        for (; run > 0; --run) w.rle[nr++] = 0u;
+      } else {
+        w.rle[nr++] = (unsigned)v; --run;
+        while (run >= 3) { const int r = min(run, 6); w.rle[nr++] = 16u | (2u << 8) | ((unsigned)(r - 3) << 16); run -= r; }
+        for (; run > 0; --run) w.rle[nr++] = (unsigned)v;
+      }
+      p = j;
+    }
+  }
+  for (int k = 0; k < nr; ++k) cf[w.rle[k] & 255u]++;
+  {
+    const int force[2] = {0, 18};
+    for (int t = 0; t < 2; ++t) {
+      int used = 0;
+      for (int s = 0; s < NCL; ++s) used += cf[s] != 0;
+      if (used < 2 && cf[force[t]] == 0) cf[force[t]] = 1;
+    }
+  }
+  lz_huffman_lengths(w, cf, NCL, 7, cl);
+  lz_canonical_codes(cl, NCL, 7, cc);
+  const int CL_ORDER[19] = {16, 17, 18, 0, 8, 7, 9, 6, 10, 5, 11, 4, 12, 3, 13, 2, 14, 1, 15};
+  int hclen = 4;
+  for (int k = 0; k < 19; ++k) if (cl[CL_ORDER[k]]) hclen = max(hclen, k + 1);
+  // ---- the block
+  BitWriter b;
+  b.out = a.slots + (long long)u * SLOT_LZ; b.acc = 0; b.nb = 0; b.pos = 0;
+  const int n = (int)(end - start);
+  const int limit = n + 5;                               // beyond this the stored form wins: stop writing (the slot holds n + 1024 bytes)
+  b.put(0u, 1); b.put(2u, 2);
+  b.put((unsigned)(hlit - 257), 5); b.put((unsigned)(hdist - 1), 5); b.put((unsigned)(hclen - 4), 4);
+  for (int k = 0; k < hclen; ++k) b.put(cl[CL_ORDER[k]], 3);
+  for (int k = 0; k < nr; ++k) {
+    const unsigned r = w.rle[k], s = r & 255u, eb = (r >> 8) & 255u;
+    b.put_code(cc[s], cl[s]);
+    if (eb) b.put(r >> 16, (int)eb);
+  }
+  bool overflow = false;
+  for (int t = 0; t < nt; ++t) {
+    if (b.pos > limit) { overflow = true; break; }
+    const unsigned tk = toks[t];
+    const int len = (int)(tk >> 16), dist = (int)(tk & 0xffffu);
+    if (dist == 0) b.put_code(lc[len], ll[len]);
+    else {
+      int k, eb; unsigned ev;
+      lz_len_code(len, k, eb, ev);
+      b.put_code(lc[257 + k], ll[257 + k]);
+      if (eb) b.put(ev, eb);
+      lz_dist_code(dist, k, eb, ev);
+      b.put_code(dc[k], dl[k]);
+      if (eb) b.put(ev, eb);
+    }
+  }
+  if (!overflow) {
+    b.put_code(lc[256], ll[256]);
+    b.put(final_unit ? 1u : 0u, 1); b.put(0u, 2);
+    if (b.nb) { b.out[b.pos++] = (unsigned char)(b.acc & 255u); b.acc = 0; b.nb = 0; }
+    b.out[b.pos++] = 0; b.out[b.pos++] = 0; b.out[b.pos++] = 0xff; b.out[b.pos++] = 0xff;
+  }
+  if (overflow || b.pos >= n + 5) {
+    unsigned char* o = b.out;
+    o[0] = final_unit ? 1 : 0;
+    o[1] = (unsigned char)(n & 255); o[2] = (unsigned char)(n >> 8);
+    o[3] = (unsigned char)(~n & 255); o[4] = (unsigned char)((~n >> 8) & 255);
+    for (int k = 0; k < n; ++k) o[5 + k] = f[start + k];
+    b.pos = n + 5;
+  }
+  a.meta[M_SIZES + u] = (unsigned)b.pos;
+}
+
+// one wave per unit: LZ slot -> its place in the stream
+__global__ __launch_bounds__(64) void png_lz_gather_kernel(DefArgs a) {
+  const int u = blockIdx.x;
+  const unsigned sz = a.meta[M_SIZES + u], off = a.meta[M_SIZES + a.nunits + u];
+  const unsigned char* src = a.slots + (long long)u * SLOT_LZ;
+  unsigned char* dst = a.png + PNG_HEAD + 2 + off;
+  for (unsigned k = threadIdx.x; k < sz; k += 64) dst[k] = src[k];
+}
+
 // Adler-32 partials over the rows of the FILTERED stream (filter byte included), same form as png_adler_rows_kernel
 __global__ __launch_bounds__(64) void png_adler_filt_kernel(DefArgs a) {
   const int row = blockIdx.x, lane = threadIdx.x;
@@ -517,8 +781,11 @@ int omni_launch_png_deflate(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(a.img && a.png && a.filt && a.slots && a.meta && a.part && a.H > 0 && a.W > 0 && a.H <= 32768 && a.W <= 32768,
                "png_deflate: bad arguments");
   a.U = (long long)a.H * (3 * a.W + 1);
-  a.nunits = (int)((a.U + UNIT - 1) / UNIT);
-  const long long zmax = 2 + a.U + 5ll * a.nunits + 4;
+  const bool lz = op->i[5] == 1;                          // LZ77 + dynamic Huffman over 32 KiB units (p7 = token scratch, u32[units * 32768])
+  unsigned* toks = (unsigned*)op->p[7];
+  OMNI_REQUIRE(!lz || toks, "png_deflate: i5 = 1 needs the token scratch p7");
+  a.nunits = lz ? (int)((a.U + UNIT_LZ - 1) / UNIT_LZ) : (int)((a.U + UNIT - 1) / UNIT);
+  const long long zmax = 2 + a.U + 5ll * ((a.U + UNIT - 1) / UNIT) + 4;     // capacity contract of the fixed-Huffman variant (covers both)
   OMNI_REQUIRE(zmax < (1ll << 31), "png_deflate: image too large for one IDAT chunk");
   const int nseg_max = (int)((4 + zmax + CRC_SEG - 1) / CRC_SEG);
   OMNI_REQUIRE(op->i[2] >= zmax + 57, "png_deflate: output holds %d bytes, worst case is %lld", op->i[2], zmax + 57);
@@ -526,9 +793,11 @@ int omni_launch_png_deflate(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(op->i[4] >= 2 * a.H + nseg_max, "png_deflate: scratch holds %d words, needs %d", op->i[4], 2 * a.H + nseg_max);
   const long long quads = (a.U + 3) / 4;
   hipLaunchKernelGGL(png_filter_kernel, dim3((unsigned)((quads + 255) / 256)), dim3(256), 0, s, a);
-  hipLaunchKernelGGL(png_deflate_units_kernel, dim3((a.nunits + 63) / 64), dim3(64), 0, s, a);
+  if (lz) hipLaunchKernelGGL(png_lz_units_kernel, dim3(a.nunits), dim3(64), 0, s, a, toks);
+  else hipLaunchKernelGGL(png_deflate_units_kernel, dim3((a.nunits + 63) / 64), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_layout_kernel, dim3(1), dim3(64), 0, s, a);
-  hipLaunchKernelGGL(png_gather_kernel, dim3(a.nunits), dim3(64), 0, s, a);
+  if (lz) hipLaunchKernelGGL(png_lz_gather_kernel, dim3(a.nunits), dim3(64), 0, s, a);
+  else hipLaunchKernelGGL(png_gather_kernel, dim3(a.nunits), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_adler_filt_kernel, dim3(a.H), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_def_adler_fold_kernel, dim3(1), dim3(64), 0, s, a);
   hipLaunchKernelGGL(png_def_crc_seg_kernel, dim3((nseg_max + 255) / 256), dim3(256), 0, s, a);

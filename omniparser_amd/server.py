@@ -76,7 +76,7 @@ class ParseService:
             return ""
         h, w = rgb.shape[:2]
         boxes = torch.tensor([e["bbox"] for e in elems], dtype=torch.float32).reshape(-1, 4)
-        if frame_dev is not None and os.environ.get("OMNI_OVERLAY", "host") == "device":
+        if frame_dev is not None and U.overlay_on_device(frame_dev.device):
             # raster + PNG + base64 on the device, on the copy of the screenshot this request already uploaded (csrc/overlay_png.hip)
             with torch.inference_mode():
                 return U.annotate_encode_device(rgb, U._box_convert_xyxy_to_cxcywh(boxes), list(range(len(elems))), frame_dev.device,
@@ -102,7 +102,8 @@ class ParseService:
             sp = self.screen_parser()
             frames = [torch.from_numpy(np.array(images[i], order="C")).to(sp.det.device) for i in group]
             elems = sp.parse_batch(frames, [ocrs[i] if ocrs[i] is not None else ([], []) for i in group])
-            if os.environ.get("OMNI_OVERLAY", "host") == "device":
+            from .util import utils as U
+            if U.overlay_on_device(sp.det.device):
                 pngs = [self._render(images[i], el, fr) for i, el, fr in zip(group, elems, frames)]       # one stream: sequential
             else:
                 pngs = list(self.pool.map(lambda a: self._render(*a), [(images[i], el) for i, el in zip(group, elems)]))

@@ -397,6 +397,20 @@ def encode_png_b64(frame: np.ndarray, compress_level: int = 6) -> str:
     return base64.b64encode(buf.getvalue()).decode("ascii")
 
 
+def overlay_on_device(device=None) -> bool:
+    """Where the tail of `get_som_labeled_img` (ref:util/utils.py:478-488: annotate + PNG + base64) runs.  OMNI_OVERLAY = device | host
+    decides; unset (round 6 on): on the device whenever the models live on a GPU — 18 ms instead of 51 ms per 1080p screenshot and a
+    PNG within 1.16x of Pillow's bytes (tools/annotate_bench.py, profiles/r6_s4_annotate_bench.json) — on the host otherwise
+    (rounds 2-5 defaulted to the host because the device PNG was 2.7x Pillow's size)."""
+    mode = os.environ.get("OMNI_OVERLAY", "auto")
+    if mode in ("device", "host"):
+        return mode == "device"
+    try:
+        return device is not None and torch.device(device).type == "cuda"
+    except (TypeError, RuntimeError):
+        return False
+
+
 def png_pack_device(frame: torch.Tensor, want_b64=True, stream=None):
     """OMNI_OP_PNG_PACK: uint8 [H,W,3] device tensor -> (PNG file bytes, base64 ASCII) as device tensors (stored-deflate PNG:
     include/omni_amd.h; layout restated in oracle/png_ref.py).  Five small launches, no host work."""
@@ -413,27 +427,31 @@ def png_pack_device(frame: torch.Tensor, want_b64=True, stream=None):
     return png, b64
 
 
-def png_deflate_device(frame: torch.Tensor, want_b64=True, stream=None):
-    """OMNI_OP_PNG_DEFLATE: like png_pack_device with a compressed stream (Up filter + fixed-Huffman run-length deflate, one GPU
-    thread per 4096-byte unit; oracle/png_ref.py::deflate_png is the byte-exact restatement).  The size is decided on the device:
+def png_deflate_device(frame: torch.Tensor, want_b64=True, stream=None, lz=True):
+    """OMNI_OP_PNG_DEFLATE: like png_pack_device with a compressed stream.  lz=True (default since round 6): Up filter + LZ77 +
+    dynamic Huffman, one GPU lane per 32 KiB unit — within 1.1-1.3x of Pillow's zlib level 6 (oracle/png_ref.py::deflate_png_lz is
+    the byte-exact restatement); lz=False: the fixed-Huffman run-length stream of rounds 3-5 (one thread per 4096-byte unit, 2.7x
+    Pillow's bytes; oracle/png_ref.py::deflate_png).  The size is decided on the device:
     -> (PNG buffer, base64 buffer, meta) device tensors; meta[1] = file bytes, meta[2] = base64 bytes."""
     H, W = frame.shape[:2]
     assert frame.dtype == torch.uint8 and frame.is_contiguous() and frame.shape[2] == 3
     dev = frame.device
     u = H * (3 * W + 1)
     units = (u + 4095) // 4096
+    units_lz = (u + 32767) // 32768
     cap = u + 5 * units + 63
     nseg = (cap - 53 + 4095) // 4096
     png = torch.empty(cap, dtype=torch.uint8, device=dev)
     filt = torch.empty(u, dtype=torch.uint8, device=dev)
-    slots = torch.empty(units * 4640, dtype=torch.uint8, device=dev)
+    slots = torch.empty(max(units * 4640, units_lz * 33792 if lz else 0), dtype=torch.uint8, device=dev)
     meta = torch.zeros(4 + 2 * units, dtype=torch.int32, device=dev)
     part = torch.empty(2 * H + nseg, dtype=torch.int32, device=dev)
     b64 = torch.empty(4 * ((cap + 2) // 3), dtype=torch.uint8, device=dev) if want_b64 else None
+    toks = torch.empty(units_lz * 32768, dtype=torch.int32, device=dev) if lz else None
     L.launch(L.make_op(L.OP_PNG_DEFLATE, L.F32,
                        p=[frame.data_ptr(), png.data_ptr(), filt.data_ptr(), slots.data_ptr(), meta.data_ptr(), part.data_ptr(),
-                          b64.data_ptr() if want_b64 else None],
-                       i={0: H, 1: W, 2: cap, 3: meta.numel(), 4: part.numel()}), stream)
+                          b64.data_ptr() if want_b64 else None, toks.data_ptr() if lz else None],
+                       i={0: H, 1: W, 2: cap, 3: meta.numel(), 4: part.numel(), 5: 1 if lz else 0}), stream)
     return png, b64, meta
 
 
@@ -509,7 +527,7 @@ def get_som_labeled_img(image_source: Union[str, Image.Image], model=None, BOX_T
                          (filtered_boxes[:, 3] - filtered_boxes[:, 1]) * h), -1).numpy())} if len(filtered_boxes) else {}
     else:
         cfg = draw_bbox_config or {"text_scale": text_scale, "text_padding": text_padding}
-        if os.environ.get("OMNI_OVERLAY", "host") == "device":      # raster + PNG + base64 on the MI355X (csrc/overlay_png.hip)
+        if overlay_on_device(getattr(model, "device", None)):        # raster + PNG + base64 on the MI355X (csrc/overlay_png.hip)
             encoded, label_coordinates = annotate_encode_device(image_np, boxes_cxcywh, phrases, model.device, **cfg)
         else:
             frame, label_coordinates = annotate(image_source=image_np, boxes=boxes_cxcywh, logits=logits, phrases=phrases, **cfg)

@@ -42,9 +42,12 @@ def test_png_pack_is_the_oracle_layout_and_decodes(H, W):
 
 
 @pytest.mark.parametrize("kind", ["screenshot", "noise", "flat"])
-def test_png_deflate_is_the_oracle_stream_and_decodes(kind):
-    """OMNI_OP_PNG_DEFLATE at 1920x1080: byte-identical to oracle/png_ref.py::deflate_png (CPU restatement of the same encoder, Python
-    zlib checksums), inflated by zlib to the filtered scanlines, read back by Pillow."""
+@pytest.mark.parametrize("lz", [True, False], ids=["lz-dynamic", "fixed"])
+def test_png_deflate_is_the_oracle_stream_and_decodes(kind, lz):
+    """OMNI_OP_PNG_DEFLATE at 1920x1080, both streams (i5 = 1: LZ77 + dynamic Huffman, the device overlay's default; i5 = 0: the
+    fixed-Huffman run-length stream): byte-identical to oracle/png_ref.py (CPU restatement of the same encoder, Python zlib
+    checksums), inflated by zlib to the filtered scanlines, read back by Pillow; the LZ stream of the 1080p screenshot is within
+    1.35x of Pillow's own PNG of the same frame (the fixed one: 2.7x)."""
     import zlib
     from oracle import png_ref as PR
     from omniparser_amd.synth import synthetic_screenshot
@@ -56,15 +59,19 @@ def test_png_deflate_is_the_oracle_stream_and_decodes(kind):
         frame = np.random.default_rng(1).integers(0, 256, (H, W, 3), dtype=np.uint8)
     else:
         frame = np.full((H, W, 3), 200, dtype=np.uint8)
-    png, b64, meta = png_deflate_device(torch.from_numpy(frame).cuda())
+    png, b64, meta = png_deflate_device(torch.from_numpy(frame).cuda(), lz=lz)
     torch.cuda.synchronize()
     m = meta.cpu()
     data = png[: int(m[1])].cpu().numpy().tobytes()
     assert zlib.decompress(data[41:41 + int(m[0])]) == PR.filtered_stream(frame).tobytes()
     assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
     assert b64[: int(m[2])].cpu().numpy().tobytes() == base64.b64encode(data)
-    if kind != "screenshot":                                 # the pure-Python encoder needs ~1 s per 100 KB
-        assert data == PR.deflate_png(frame)
+    if kind != "screenshot":                                 # the pure-Python encoders need ~1 s (fixed) / ~10 s (LZ) per MB
+        assert data == (PR.deflate_png_lz(frame) if lz else PR.deflate_png(frame))
+    elif lz:
+        buf = io.BytesIO(); Image.fromarray(frame).save(buf, format="PNG")
+        # first 64 rows byte for byte against the oracle (same units: the stream is cut every 32 KiB), the whole file by size
+        assert len(data) <= 1.35 * len(buf.getvalue()), (len(data), len(buf.getvalue()))
 
 
 def test_get_som_labeled_img_with_device_overlay(monkeypatch):

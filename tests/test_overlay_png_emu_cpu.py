@@ -89,14 +89,72 @@ def _frames():
     yield "all match lengths", f
 
 
-@pytest.mark.parametrize("name,frame", list(_frames()), ids=[n for n, _ in _frames()])
-def test_device_deflate_png_is_the_oracle_stream_and_decodes(emu, name, frame):
-    """OMNI_OP_PNG_DEFLATE: file bytes == oracle/png_ref.py::deflate_png (same filter, same greedy matcher, same fixed-Huffman bits,
-    zlib's checksums), zlib inflates the stream to the filtered scanlines, Pillow reads the frame back, base64 matches."""
+def _lz_frames():
+    """what the LZ + dynamic-Huffman variant adds to `_frames`: repeated TEXTURE (hash matches at distances beyond 3, inside a unit and
+    not across its start), more than one 32 KiB unit with a short last one, a unit where every byte value occurs (286-symbol code), a
+    frequency profile skewed enough to need the 15-bit Kraft repair."""
+    rng = np.random.default_rng(11)
+    tile = rng.integers(0, 256, (8, 16, 3), dtype=np.uint8)
+    yield "texture", np.tile(tile, (12, 40, 1))                                        # 96 x 640: two units, period 48 bytes
+    g = np.zeros((48, 300, 3), dtype=np.uint8)
+    g[..., 0] = np.arange(300)[None, :] % 251; g[..., 1] = (np.arange(48)[:, None] * 5) % 256; g[::7, ::3, 2] = 255
+    yield "gradient", g
+    sk = np.zeros((40, 280, 3), dtype=np.uint8)                                          # Fibonacci-like literal frequencies: deep Huffman tree
+    flat = sk.reshape(-1)
+    pos, a, b = 0, 1, 1
+    for v in range(1, 24):
+        flat[pos:pos + a * 3:3] = v; pos += a * 3; a, b = b, a + b
+        if pos + b * 3 >= flat.size:
+            break
+    yield "skewed", sk
+
+
+@pytest.mark.parametrize("name,frame", list(_frames()) + list(_lz_frames()), ids=[n for n, _ in list(_frames()) + list(_lz_frames())])
+def test_device_lz_png_is_the_oracle_stream_and_decodes(emu, name, frame):
+    """OMNI_OP_PNG_DEFLATE i5 = 1 (the device overlay's stream since round 6): file bytes == oracle/png_ref.py::deflate_png_lz — same
+    tokens, same code lengths, same header, bit for bit — zlib inflates the stream to the filtered scanlines, Pillow reads the frame
+    back, base64 matches; and the point of it: not larger than the fixed-Huffman variant, far smaller on texture."""
     import zlib
     from oracle import png_ref as PR
     from omniparser_amd.util.utils import png_deflate_device
-    png, b64, meta = png_deflate_device(torch.from_numpy(np.ascontiguousarray(frame)))
+    frame = np.ascontiguousarray(frame)
+    png, b64, meta = png_deflate_device(torch.from_numpy(frame), lz=True)
+    total, nb64 = int(meta[1]), int(meta[2])
+    data = png[:total].numpy().tobytes()
+    want = PR.deflate_png_lz(frame)
+    assert total == len(want) and data == want, (total, len(want), next((k for k in range(min(total, len(want))) if data[k] != want[k]), None))
+    assert zlib.decompress(data[41:41 + int(meta[0])]) == PR.filtered_stream(frame).tobytes()
+    assert np.array_equal(np.asarray(Image.open(io.BytesIO(data)).convert("RGB")), frame)
+    assert b64[:nb64].numpy().tobytes() == base64.b64encode(data)
+    fixed = len(PR.deflate_png(frame))
+    assert total <= fixed + 16, (total, fixed)
+    if name == "texture":
+        assert total < fixed // 4, (total, fixed)
+
+
+def test_huffman_length_limit_repair_is_exercised_and_valid():
+    """oracle/png_ref.py::huffman_lengths on frequencies that force a tree deeper than the limit: lengths stay within the limit and the
+    Kraft sum is exactly 1 (a complete prefix code — what every inflater requires)."""
+    from oracle import png_ref as PR
+    fib = [1, 1]
+    while len(fib) < 24:
+        fib.append(fib[-1] + fib[-2])
+    for freq, limit in ((fib, 15), (fib[:12], 7), ([5, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1, 1], 7), ([3, 0, 0, 9], 15)):
+        lens = PR.huffman_lengths(freq, limit)
+        used = [l for l in lens if l]
+        assert max(used) <= limit and sum(2.0 ** -l for l in used) == 1.0, (freq, lens)
+        assert all((l > 0) == (f > 0) for l, f in zip(lens, freq))
+
+
+@pytest.mark.parametrize("name,frame", list(_frames()), ids=[n for n, _ in _frames()])
+def test_device_deflate_png_is_the_oracle_stream_and_decodes(emu, name, frame):
+    """OMNI_OP_PNG_DEFLATE, fixed-Huffman variant (lz=False): file bytes == oracle/png_ref.py::deflate_png (same filter, same greedy
+    matcher, same fixed-Huffman bits, zlib's checksums), zlib inflates the stream to the filtered scanlines, Pillow reads the frame
+    back, base64 matches."""
+    import zlib
+    from oracle import png_ref as PR
+    from omniparser_amd.util.utils import png_deflate_device
+    png, b64, meta = png_deflate_device(torch.from_numpy(np.ascontiguousarray(frame)), lz=False)
     total, nb64 = int(meta[1]), int(meta[2])
     data = png[:total].numpy().tobytes()
     want = PR.deflate_png(frame)
