@@ -548,7 +548,8 @@ def roofline(args, det, parser, dp, crop_counts, B):
     if split:
         # every algorithmic MAC issues 3 f16 MFMA products (hi*hi + hi*lo + lo*hi): the matrix pipe is busy 3 * achieved / peak
         out.update(mfma_products_per_mac=3, matrix_pipe_utilisation=round(3 * achieved / peak, 4), vs_f32_mfma_peak=round(achieved / 157.3, 3))
-    tfile = next((f for f in (ROOT / "profiles" / "r5_pmc_traffic.json", ROOT / "profiles" / "r4_pmc_traffic.json", ROOT / "profiles" / "r3_pmc_traffic.json")
+    tfile = next((f for f in (ROOT / "profiles" / "r6_pmc_traffic.json", ROOT / "profiles" / "r5_pmc_traffic.json", ROOT / "profiles" / "r4_pmc_traffic.json",
+                              ROOT / "profiles" / "r3_pmc_traffic.json")
                   if f.exists()), None)
     if split and args.mode == "e2e" and args.caption_res == 768 and tfile is not None:
         t = json.loads(tfile.read_text())

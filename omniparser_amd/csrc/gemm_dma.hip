@@ -173,9 +173,13 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   // issuing wave supplies row 8p + l/8, 16-byte slot l%8, whose SOURCE chunk is slot ^ ((row >> 1) & 7).
   const int rsub = lane >> 3, slot = lane & 7;
   unsigned voffA[A_DMA], voffB[B_DMA];
+  // which 8-row piece of the activation tile wave `wave` stages as its i-th: contiguous bands (SCHED 0 / 1), or — SCHED 2 — strided by
+  // the wave count, so that every wave's pieces 0, 2 are rows of the FIRST 64-token half of a wave tile (wm * 128 + [0, 64)) and its
+  // pieces 1, 3 rows of the second half: the ping-pong schedule stages the halves at different times (see `slice_pp` below)
+  auto pieceA = [&](int i) { return SCHED == 2 ? wave + NW * i : wave * A_DMA + i; };
 #pragma unroll
   for (int i = 0; i < A_DMA; ++i) {
-    const int rl = (wave * A_DMA + i) * 8 + rsub;
+    const int rl = pieceA(i) * 8 + rsub;
     const int rr = min(rl, a.M - 1 - m0);                  // M tail: re-read the last row (its results are never stored)
     voffA[i] = (unsigned)rr * (unsigned)(a.ldi * 4) + (unsigned)((slot ^ ((rl >> 1) & 7)) * 16);
   }
@@ -193,7 +197,7 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
   auto issue_piece = [&](int kt, int stage, int i) {
     const int so = kt * 128;
     if (i < A_DMA)
-      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(lds + stage * STAGE + (wave * A_DMA + i) * 1024), 16, voffA[i], so, 0, 0);
+      __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcA, (lds_void*)(lds + stage * STAGE + pieceA(i) * 1024), 16, voffA[i], so, 0, 0);
     else
       __builtin_amdgcn_raw_ptr_buffer_load_lds(rsrcB, (lds_void*)(lds + stage * STAGE + BM * 128 + (wave * B_DMA + i - A_DMA) * 1024), 16,
                                                voffB[i - A_DMA], so, 0, 0);
@@ -312,11 +316,73 @@ __global__ __launch_bounds__(WM * WN * 64, 2) void gemm_dma_kernel(GemmArgs a) {
     stage = stage + 1 == NSTAGE ? 0 : stage + 1;
     nstage = nstage + 1 == NSTAGE ? 0 : nstage + 1;
   };
+  // ---- SCHED 2 (round 6): PING-PONG.  The two waves of a SIMD (wave w and w + 4 = the two M halves of the tile) run HALF A PHASE
+  // apart: a K slice is four (load segment | barrier | 12 MFMAs | barrier) phases, and while waves 0-3 issue their MFMAs waves 4-7
+  // issue the fragment reads and LDS-DMA pieces of THEIR next phase — the matrix pipe of a SIMD is fed by one wave at a time, the
+  // other wave's LDS / DMA issue never competes with MFMA issue (MI355X_MICROARCH "two waves per SIMD", the guide's 8-phase GEMM
+  // template).  Units are token-half major: u0 = (K group 0, tokens 0-63), u1 = (g1, 0-63), u2 = (g0, 64-127), u3 = (g1, 64-127);
+  // the weight fragments of both K groups stay in registers after u0 / u1.  Staging of slice kt + 1 during slice kt, per wave:
+  // u0 its two FIRST-half activation pieces, u1 / u2 two weight pieces each, u3 its two SECOND-half activation pieces;
+  // `vmcnt(2)` in u3 retires everything but those last two, which are retired by `vmcnt(4)` in u1 of the NEXT slice — two barriers
+  // before u2 reads them (an LDS-DMA is ordered for another wave's ds_read only by the issuer's vmcnt followed by a barrier both
+  // have passed).  Nothing is restaged earlier than four phases after its last read.  Same products in the same order per
+  // accumulator as SCHED 0 / 1: bit-identical results.
+  if constexpr (SCHED == 2) {
+    static_assert(BM == 256 && BN == 256 && WM == 2 && WN == 4 && NSTAGE == 2 && TM == 4 && TN == 2 && A_DMA == 4 && B_DMA == 4, "ping-pong: 256x256 tile, 8 waves");
+    // prologue of the generic path issued slice 0 (all eight pieces per wave): land it, publish it, then stagger the M halves
+    OMNI_WAIT_VMCNT(0);
+    __builtin_amdgcn_s_barrier();
+    if (wm == 1) __builtin_amdgcn_s_barrier();
+    auto phase_barrier = [&]() {
+      __builtin_amdgcn_sched_barrier(0);
+      __builtin_amdgcn_s_barrier();
+      __builtin_amdgcn_sched_barrier(0);
+    };
+    {
+      AF afp;
+      auto slice_pp = [&](int kt, auto more_tag) {
+        constexpr bool MORE = decltype(more_tag)::value;
+        const unsigned char* st = lds + stage * STAGE;
+#pragma unroll
+        for (int u = 0; u < 4; ++u) {
+          const int g = u & 1, ip = u >> 1;
+          if (u < 2) loadW(st, g, wf[g]);
+          loadA(st, g, ip, afp);
+          if constexpr (MORE) {
+            if (u == 0) { issue_piece(kt + 1, nstage, 0); issue_piece(kt + 1, nstage, 2); }
+            if (u == 1) { issue_piece(kt + 1, nstage, A_DMA + 0); issue_piece(kt + 1, nstage, A_DMA + 1); }
+            if (u == 2) { issue_piece(kt + 1, nstage, A_DMA + 2); issue_piece(kt + 1, nstage, A_DMA + 3); }
+            if (u == 3) { issue_piece(kt + 1, nstage, 1); issue_piece(kt + 1, nstage, 3); }
+            if (u == 1) OMNI_WAIT_VMCNT(4);          // this slice's second-half activation pieces (issued in u3 of the previous slice)
+            if (u == 3) OMNI_WAIT_VMCNT(2);          // everything of the next slice but its second-half activation pieces
+          } else {
+            if (u == 1) OMNI_WAIT_VMCNT(0);
+          }
+          phase_barrier();
+          __builtin_amdgcn_s_setprio(1);
+          mma(afp, wf[g], ip);
+          __builtin_amdgcn_s_setprio(0);
+          phase_barrier();
+        }
+        stage ^= 1;
+        nstage ^= 1;
+      };
+      int ktp = 0;
+      for (; ktp + 1 < nk; ++ktp) slice_pp(ktp, std::true_type{});
+      for (; ktp < nk; ++ktp) slice_pp(ktp, std::false_type{});
+    }
+    // Measured and not kept (round 6, profiles/r6_s5_gemm_sched.jsonl): the same ping-pong with TWO phases per slice (one per token half,
+    // both K groups, 24 MFMAs between barriers) — 1.619 / 1.923 / 1.253 ms on fc2 / fc1 / qkv against 1.524 / 1.878 / 1.215 for the
+    // four-phase form and 1.578 / 1.926 / 1.268 for the lockstep schedule: half the barriers, but sixteen fragment reads to wait for at
+    // the head of every MFMA segment.
+    if (wm == 0) __builtin_amdgcn_s_barrier();
+  } else {
   // slices with a successor to issue: kt + NSTAGE - 1 < nk.  The NSTAGE > 2 counted wait needs the full ring in flight, which
   // holds exactly for those iterations.
   int kt = 0;
   for (; kt + NSTAGE - 1 < nk; ++kt) slice(kt, std::true_type{});
   for (; kt < nk; ++kt) slice(kt, std::false_type{});
+  }
 
   // ---- epilogue (gemm_epilogue above): bias / activation / 2^-k in registers, rows transposed through the idle LDS ring
   gemm_epilogue<BM, BN, WM, WN, TM, TN, NSTAGE * STAGE, ACT, OSPLIT, RES>(acc, a, lds, m0, n0, wave, lane);
@@ -516,8 +582,19 @@ int launch_tile(GemmArgs& a, int act, int osplit, hipStream_t s) {
   a.xcd_n = a.xcd_order ? choose_xcd_n(a.ntiles, 4ll * a.N * a.K) : 1;
   dim3 grid(tile_grid(a.mtiles, a.ntiles, a.xcd_order, a.xcd_n)), block(WM * WN * 64);
   const bool res = a.res != nullptr;
-  constexpr int SCHED = (BM == 256 && BN == 256) ? 1 : 0;      // front-loaded DMA issue on the 256x256 tile (see gemm_dma_kernel)
-#define OMNI_GD(ACT_, OS_, RES_) hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED>), grid, block, 0, s, a)
+  constexpr int SCHED1 = (BM == 256 && BN == 256) ? 1 : 0;     // front-loaded DMA issue on the 256x256 tile (see gemm_dma_kernel)
+  // 256x256 tile: the ping-pong schedule (SCHED 2, round 6: -3.4 / -2.5 / -4.2 % on fc2 / fc1 / qkv of DaViT stage 2, bit-identical
+  // results; 641 instead of 654-662 ms per bench step) unless OMNI_GEMM_SCHED=1 asks for the lockstep schedule (the A/B knob of
+  // tools/gemm_exp.py sched and of tests/gpu_checks.py::check_gemm_schedules_bitwise)
+  const char* sched_e = getenv("OMNI_GEMM_SCHED");
+  const bool lockstep = sched_e && atoi(sched_e) == 1;
+#define OMNI_GD(ACT_, OS_, RES_)                                                                                                   \
+  do {                                                                                                                             \
+    if constexpr (BM == 256 && BN == 256) {                                                                                        \
+      if (!lockstep) { hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, 2>), grid, block, 0, s, a); break; }  \
+    }                                                                                                                              \
+    hipLaunchKernelGGL((gemm_dma_kernel<BM, BN, WM, WN, NSTAGE, ACT_, OS_, RES_, SCHED1>), grid, block, 0, s, a);                  \
+  } while (0)
   if (act == OMNI_ACT_NONE && !osplit && !res) OMNI_GD(OMNI_ACT_NONE, false, false);
   else if (act == OMNI_ACT_NONE && !osplit && res) OMNI_GD(OMNI_ACT_NONE, false, true);
   else if (act == OMNI_ACT_NONE && osplit && !res) OMNI_GD(OMNI_ACT_NONE, true, false);

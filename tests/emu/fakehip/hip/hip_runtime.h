@@ -282,6 +282,7 @@ void launch(dim3 grid, dim3 block, size_t shmem, F&& body) {
 #define __builtin_amdgcn_s_barrier() emu::block_barrier()
 #define __builtin_amdgcn_sched_barrier(m) ((void)0)
 #define __builtin_amdgcn_sched_group_barrier(a, b, c) ((void)0)
+#define __builtin_amdgcn_s_setprio(p) ((void)0)
 #define OMNI_WAIT_VMCNT(n) emu::wait_vmcnt(n)
 #define OMNI_WAIT_LGKM0() ((void)0)                  // LDS reads are synchronous here
 #define OMNI_WAVE_SYNC() ((void)__shfl(0, 0))        // work-items are fibers: lanes of a wave need a real rendezvous

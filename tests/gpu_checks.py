@@ -271,6 +271,54 @@ def check_range_guard(seed=0):
     return out
 
 
+def check_gemm_schedules_bitwise(M=70000, cases=((512, 512, False, L.ACT_NONE, True), (2048, 512, False, L.ACT_NONE, False), (512, 1024, True, L.ACT_GELU, False),
+                                                  (64, 256, False, L.ACT_NONE, False), (32, 256, True, L.ACT_NONE, False)), seed=0):
+    """The K-loop schedules of the 256x256 `gemm_dma_kernel` tile — lockstep (OMNI_GEMM_SCHED=1: one barrier per slice) and the
+    ping-pong form that ships (four phases per slice; the two M halves of the tile run half a phase apart, LDS-DMA pieces staged by token
+    half with counted `vmcnt`) — issue the same MFMAs in the same order per accumulator: outputs must be BIT-IDENTICAL, on every row of a
+    launch large enough to fill the chip (ragged last row block, 1 ... 64 K slices), and within 2e-6 of an f64 product on sampled rows.
+    A staging race (a fragment read before its LDS-DMA piece was retired and published) shows as a mismatch here."""
+    import os
+    from plan_interp import split_decode
+    g = torch.Generator().manual_seed(seed)
+    out = {}
+    for K, N, osplit, act, use_res in cases:
+        x = torch.randn(M, K, generator=g)
+        w = torch.randn(N, K, generator=g) / math.sqrt(K)
+        b = torch.randn(N, generator=g)
+        res = torch.randn(M, N, generator=g) if use_res else None
+        got = {}
+        for sched in ("1", "2"):
+            pb = PlanBuilder(DEV, L.F32)
+            xv = View(x.clone().view(1, M, 1, K).to(DEV), 0, K)
+            pb.split_convert(xv)
+            ov = View(torch.zeros(1, M, 1, N, device=DEV), 0, N)
+            rv = View(res.view(1, M, 1, N).to(DEV), 0, N) if use_res else None
+            pb.conv(xv, pb.pack_weight_dma(w), b, ov, 1, act=act, res=rv, out_split=osplit)
+            os.environ["OMNI_GEMM_TILE"] = "256x256"; os.environ["OMNI_GEMM_SCHED"] = sched
+            try:
+                for _ in range(3):                                 # repeated launches: a race need not show on the first
+                    for op in pb.ops[1:] if _ else pb.ops:
+                        L.launch(op)
+                _sync()
+            finally:
+                os.environ.pop("OMNI_GEMM_TILE", None); os.environ.pop("OMNI_GEMM_SCHED", None)
+            got[sched] = ov.t.view(M, N).cpu()
+        assert torch.equal(got["1"].view(torch.int32), got["2"].view(torch.int32)), f"K {K} N {N}: the ping-pong schedule differs from the lockstep schedule"
+        rows = torch.randint(0, M, (256,), generator=g)
+        ref = x[rows].double() @ w.double().t() + b.double()
+        if act == L.ACT_GELU:
+            ref = F.gelu(ref)
+        if use_res:
+            ref = ref + res[rows].double()
+        y = got["2"][rows]
+        y = split_decode(y.contiguous()).double() if osplit else y.double()
+        e = rel_err(y, ref)
+        assert e < 4e-6, (K, N, e)
+        out[f"K{K}_N{N}"] = e
+    return out
+
+
 def check_mlp_fused(seed=0, cases=((300, 128, 0, 128, 0), (128, 128, 0, 128, 0), (517, 192, 48, 160, 16), (33, 128, 0, 128, 0)), inplace=True):
     """OMNI_OP_MLP_FUSED (csrc/gemm_dma.hip::mlp_fused_kernel, C = 128, hidden = 512): y = res + fc2(GELU(fc1(x))) vs an f64
     evaluation of the SAME (decoded) operands, and vs the two-launch composition it replaces (fc1 with GELU + format-B output, fc2

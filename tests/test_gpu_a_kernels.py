@@ -31,6 +31,13 @@ def test_split_range_guard_counts_values_beyond_f16():
     assert out["healthy"] == 0 and out["split_convert_input_7e4"] >= 1 and out["gemm_split_output"] >= 1 and out["conv_f32_output"] >= 1, out
 
 
+def test_gemm_k_loop_schedules_are_bit_identical():
+    """lockstep vs ping-pong K-loop schedule of the 256x256 LDS-DMA GEMM tile: same bits on 70 000 rows, five shapes."""
+    import gpu_checks as G
+    out = G.check_gemm_schedules_bitwise()
+    assert len(out) == 5, out
+
+
 def test_mfma_fragment_layout():
     import gpu_checks as G
     G.check_mfma_layout()

@@ -54,6 +54,17 @@ def test_gemm_dma_presplit_every_tile(emu):
     assert r["cases"] == 3 * len(SMALL_GEMM_DMA) and r["worst_rel_err"] < 2e-6
 
 
+def test_gemm_ping_pong_schedule_equals_the_lockstep_schedule_bit_for_bit(emu):
+    """the 256x256 tile's ping-pong K loop (round 6: the two M halves half a phase apart, LDS-DMA pieces staged by token half with counted
+    vmcnt) against the lockstep loop on the host emulation — where an LDS-DMA piece lands at the issuer's covering vmcnt and not before,
+    so a fragment read placed ahead of its wait + barrier reads stale bytes: 1, 2, 3, 5 and 16 K slices, ragged M, every epilogue."""
+    import gpu_checks as G
+    out = G.check_gemm_schedules_bitwise(M=700, cases=((96, 256, False, L.ACT_NONE, True), (32, 512, True, L.ACT_GELU, False),
+                                                       (64, 256, False, L.ACT_NONE, False), (160, 256, True, L.ACT_NONE, False),
+                                                       (512, 256, False, L.ACT_NONE, True)))
+    assert len(out) == 5, out
+
+
 def test_split_range_guard_counts_values_beyond_f16(emu):
     """the split formats clamp / lose |x| > 65504 and the fp32 reference does not — the producing kernels count it
     (omni_overflow_count), the pipeline surfaces it in stats["split_overflow"] and raises under OMNI_STRICT_RANGE=1."""

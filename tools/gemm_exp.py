@@ -128,11 +128,15 @@ def build():
     (ROOT / "tools" / "archive" / "r6_gemm_exp.patch").write_text(d)
 
 
-def run_variant(v: int, seconds: float):
+def run_variant(v, seconds: float):
     import torch
     from omniparser_amd import _lib as L
     from tools.power_trace import smi_sample
-    L._lib = L.bind(EXP / f"libomni_amd_exp{v}.so")
+    if str(v).startswith("s"):                    # "s1" / "s2": the SHIPPING library with OMNI_GEMM_SCHED unset / = 2 (ping-pong schedule A/B)
+        os.environ["OMNI_GEMM_SCHED"] = v[1:]
+        L.lib()
+    else:
+        L._lib = L.bind(EXP / f"libomni_amd_exp{v}.so")
     from omniparser_amd.planner import PlanBuilder, View
     dev = "cuda"
     stream = torch.cuda.Stream()
@@ -203,7 +207,13 @@ if __name__ == "__main__":
     if mode == "build":
         build()
     elif mode == "variant":
-        run_variant(int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 4.0)
+        run_variant(sys.argv[2] if sys.argv[2].startswith("s") else int(sys.argv[2]), float(sys.argv[3]) if len(sys.argv) > 3 else 4.0)
+    elif mode == "sched":                          # python tools/gemm_exp.py sched [seconds]: shipping vs ping-pong, interleaved twice
+        secs = sys.argv[2] if len(sys.argv) > 2 else "4"
+        for v in ("s1", "s2", "s3", "s1", "s2", "s3"):
+            r = subprocess.run([sys.executable, __file__, "variant", v, secs], capture_output=True, text=True, timeout=600)
+            line = next((l for l in r.stdout.splitlines() if l.startswith("{")), None)
+            print(line or json.dumps({"variant": v, "error": (r.stderr or r.stdout)[-600:]}), flush=True)
     else:
         secs = sys.argv[2] if len(sys.argv) > 2 else "4"
         for v in VARIANTS:
