@@ -5,6 +5,9 @@ CPU fp32 restatement of the reference detector adapter, ref:util/yolov9.py:52-13
 restatement of torchvision.ops.batched_nms / nms (torchvision is absent here and is unpinned in
 ref:requirements.txt:3 — algorithm restated from its published CPU source).
 
+The batched_nms / nms restatement itself is PARITY UNPINNED against torchvision (absent here); tests/test_third_party_pins_cpu.py holds the
+pin that activates by itself where torchvision is importable (clouds below and above the 4000-numel switch, exact score ties).
+
 Pinning: the reference has no tests for this path ("parity unpinned" by its own fixtures).  This
 restatement is pinned instead against the reference's literal YOLOv9Detector class executed from
 /root/reference under dependency shims (tests/golden/gen_golden.py, fixtures in tests/golden/).

@@ -8,7 +8,8 @@ cv2 (opencv-python, unpinned in ref:requirements.txt:11-12) is absent here: `cv2
 OpenCV's generic 8-bit INTER_LINEAR path (imgproc/resize.cpp: 11-bit fixed-point coefficients,
 horizontal pass in int32, vertical `(((b0*(S0>>4))>>16) + ((b1*(S1>>4))>>16) + 2) >> 2`).  PARITY UNPINNED
 for that function (no cv2 to compare with; IPP-enabled builds may differ in the last bit); the Pillow and
-transformers steps are the real libraries.
+transformers steps are the real libraries.  tests/test_third_party_pins_cpu.py holds the pin that activates by itself where
+opencv-python is importable (`pytest.importorskip("cv2")`: 19 crop shapes incl. the exact-2x case OpenCV routes to INTER_AREA).
 """
 import numpy as np
 from PIL import Image
