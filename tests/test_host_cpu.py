@@ -508,3 +508,33 @@ def test_range_guard_reading_reaches_stats_and_is_fatal_in_strict_mode(monkeypat
         sp._check_range()
     import os
     assert os.environ.get("OMNI_STRICT_RANGE") == "1"
+
+
+def test_overlay_default_follows_the_models_device(monkeypatch):
+    """round 6: with OMNI_OVERLAY unset the annotated image is produced on the device exactly when the models live on a GPU; the
+    variable still forces either path (util/utils.py::overlay_on_device)."""
+    from omniparser_amd.util import utils as U
+    monkeypatch.delenv("OMNI_OVERLAY", raising=False)
+    assert U.overlay_on_device(torch.device("cuda", 0)) and U.overlay_on_device("cuda:1")
+    assert not U.overlay_on_device(torch.device("cpu")) and not U.overlay_on_device(None) and not U.overlay_on_device(object())
+    monkeypatch.setenv("OMNI_OVERLAY", "host")
+    assert not U.overlay_on_device(torch.device("cuda", 0))
+    monkeypatch.setenv("OMNI_OVERLAY", "device")
+    assert U.overlay_on_device(torch.device("cpu"))
+
+
+def test_scan_provenance_describes_the_tree_it_was_measured_on():
+    """bench.py quotes `config.parity_scan` only from a scan whose recorded provenance (conv tuning table, kernel sources) equals the
+    tree's (advisor, round 5: the quoted scan predated the tuning table).  The committed round-6 scan must describe THIS tree — a kernel
+    edit after the closing session without a new scan fails here, in the CPU suite, instead of silently dropping the citation."""
+    import hashlib
+    import json
+    import re
+    scans = sorted((ROOT / "profiles").glob("r*_scan_gpu_vs_oracle.json"), key=lambda p: [int(t) if t.isdigit() else t for t in re.split(r"(\d+)", p.name)])
+    assert scans and scans[-1].name.startswith("r6_"), [p.name for p in scans]
+    sc = json.loads(scans[-1].read_text())
+    tune = ROOT / "omniparser_amd" / "conv_tuning_gfx950.json"
+    cur = {"conv_tuning_sha16": hashlib.sha256(tune.read_bytes()).hexdigest()[:16], "conv_tuning_applied": True,
+           "kernel_sources_sha16": hashlib.sha256(b"".join(p.read_bytes() for p in sorted((ROOT / "omniparser_amd" / "csrc").glob("*.h*")))).hexdigest()[:16]}
+    assert {k: sc["provenance"].get(k) for k in cur} == cur
+    assert sc["frames"] == 110 and sc["final_boxes_identical"] >= 109 and sc["identical_up_to_exchanges_of_equal_score_neighbours"] >= 109
