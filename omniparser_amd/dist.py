@@ -46,9 +46,14 @@ def self_launch(n: int, argv=None, env_extra=None) -> int:
     import sys
     import time
     argv = list(sys.argv if argv is None else argv)
-    with socket.socket() as s:
-        s.bind(("127.0.0.1", 0))
-        port = s.getsockname()[1]
+    # The rendezvous port: found by binding port 0.  Rounds 5 closed that socket before the children started, which left a window in
+    # which another process could take the port (advisor, round 5).  The socket now stays BOUND (never listening, SO_REUSEADDR) until
+    # the ranks have exited: Linux lets rank 0's store — which sets SO_REUSEADDR as well — bind and listen on the same address while no
+    # other LISTENING socket holds it, and routes connections to the listener only; nobody else can be handed the port by bind(0).
+    holder = socket.socket()
+    holder.setsockopt(socket.SOL_SOCKET, socket.SO_REUSEADDR, 1)
+    holder.bind(("127.0.0.1", 0))
+    port = holder.getsockname()[1]
     procs = []
     for r in range(n):
         env = dict(os.environ, RANK=str(r), LOCAL_RANK=str(r), WORLD_SIZE=str(n), LOCAL_WORLD_SIZE=str(n), MASTER_ADDR="127.0.0.1",
@@ -74,6 +79,7 @@ def self_launch(n: int, argv=None, env_extra=None) -> int:
                     except subprocess.TimeoutExpired:
                         q.kill()
         time.sleep(0.05)
+    holder.close()
     return rc
 
 
