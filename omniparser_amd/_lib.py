@@ -130,6 +130,18 @@ def overflow_count(reset=True) -> int:
     return int(n.value)
 
 
+def gc_after_eviction():
+    """A plan that was evicted from a model's plan cache must actually release its device buffers.  `ScreenParser._settle_gc` parks the
+    long-lived plan objects in the GC's permanent generation (`gc.freeze`); an evicted plan that sits in a reference cycle would stay
+    there — tens of GB of HBM — for ever.  So every eviction thaws, collects and re-freezes (an eviction already costs a device-wide
+    synchronise and a plan build: a full collection is noise next to that).  No-op when nothing was frozen."""
+    import gc
+    if gc.get_freeze_count():
+        gc.unfreeze()
+        gc.collect()
+        gc.freeze()
+
+
 def require_device(device, what):
     """The product runs on the MI355X only: anything but an available cuda device raises (no CPU fallback)."""
     import torch

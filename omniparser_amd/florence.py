@@ -755,6 +755,7 @@ class Florence2Captioner:
             self._plans.pop(victim)
             meta.pop(victim, None)
             self.plan_evictions = getattr(self, "plan_evictions", 0) + 1
+            L.gc_after_eviction()
         on_gpu = self.device.type == "cuda" and torch.cuda.is_available()
         before = torch.cuda.memory_allocated(self.device) if on_gpu else 0
         w_before = self._wcache_bytes()

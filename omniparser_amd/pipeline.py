@@ -96,6 +96,7 @@ class ScreenParser:
         and their results are ignored) — streams with ragged batches then need ONE plan per resolution."""
         ih, iw = frames[0].shape[:2]
         dp = self.det.get_plan(iw, ih, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=max(len(frames), pad_to or 0))
+        self.det.stream.wait_stream(torch.cuda.current_stream(frames[0].device))     # frames the caller is still producing on its stream
         with torch.cuda.stream(self.det.stream):
             for bi, f in enumerate(frames):
                 dp.img[bi].copy_(f, non_blocking=True)
@@ -122,9 +123,15 @@ class ScreenParser:
     def detect_tiled(self, frame: torch.Tensor):
         ih, iw = frame.shape[:2]
         origins, tw, th = self.tile_origins(iw, ih)
-        tiles = [frame[y:y + th, x:x + tw].contiguous() for (x, y) in origins]
-        dp = self.det.get_plan(tw, th, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=len(tiles))
+        dp = self.det.get_plan(tw, th, self.imgsz, self.box_threshold, self.nms_iou, self.max_det, batch=len(origins))
+        # The detector's stream is a NON-BLOCKING stream: nothing orders it behind work the caller queued on its own (current) stream.
+        # Rounds 2-5 cut the tiles with `.contiguous()` on the CALLER's stream and copied them into the plan on the detector's — a
+        # race a few microseconds wide that the round-6 closing check lost once in six suite runs (two `detect_tiled` calls on the same
+        # frame returned different boxes).  Now the detector's stream first waits for everything the caller has queued (the frame itself
+        # may still be in flight, e.g. a service's upload), and the tiles are cut ON it.
+        self.det.stream.wait_stream(torch.cuda.current_stream(frame.device))
         with torch.cuda.stream(self.det.stream):
+            tiles = [frame[y:y + th, x:x + tw].contiguous() for (x, y) in origins]
             for bi, t in enumerate(tiles):
                 dp.img[bi].copy_(t, non_blocking=True)
             dp.launch(self.det)
@@ -224,6 +231,7 @@ class ScreenParser:
                     tab[j, 1] = seen.get(cls, 0)
                     seen[cls] = seen.get(cls, 0) + 1
             gs.h_meta[fi, 0] = m
+        det.stream.wait_stream(torch.cuda.current_stream(frames[0].device))          # frames the caller is still producing on its stream
         with torch.cuda.stream(det.stream):
             self._ev["det0"] = det.stream.record_event(torch.cuda.Event(enable_timing=True))
             for bi, f in enumerate(frames):
@@ -389,6 +397,7 @@ class ScreenParser:
         if n >= 3 or os.environ.get("OMNI_GC_FREEZE", "1") == "0":
             return
         import gc
+        gc.unfreeze()                  # what an earlier parser of this process froze and has since died must be collectable (its plans hold HBM)
         gc.collect()
         gc.freeze()
         self._gc_settled = n + 1

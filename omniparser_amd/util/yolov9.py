@@ -248,6 +248,7 @@ class YOLOv9Detector:
         while len(self._plans) >= max_plans:                 # streams of mixed resolutions: bound the buffer pool (LRU)
             self.stream.synchronize()                        # the evicted plan's buffers may still be in use on our stream
             self._plans.pop(next(iter(self._plans)))
+            L.gc_after_eviction()
         with torch.cuda.device(self.device):
             self._plans[key] = _DetectPlan(self, iw, ih, imgsz, conf, iou, max_det, batch)
         return self._plans[key]
