@@ -262,6 +262,7 @@ class YOLOv9Detector:
 
     def _predict_locked(self, images_u8, iw, ih, conf, imgsz, iou, max_det):
         dp = self.get_plan(iw, ih, imgsz, conf, iou, max_det, batch=len(images_u8))
+        self.stream.wait_stream(torch.cuda.current_stream(self.device))    # device tensors the caller is still producing on its own stream
         with torch.cuda.stream(self.stream):
             for bi, im in enumerate(images_u8):
                 t = im if isinstance(im, torch.Tensor) else torch.from_numpy(np.ascontiguousarray(im))
