@@ -877,6 +877,8 @@ class Florence2Captioner:
             chunk = pixel_values[s:s + 128]
             n = chunk.shape[0]
             cp = self.plans(self.bucket(n), R, max_new_tokens)
+            if chunk.is_cuda:                                   # pixel_values the caller is still producing on its own stream
+                self.stream.wait_stream(torch.cuda.current_stream(chunk.device))
             with torch.cuda.stream(self.stream):
                 cp.reset()
                 cp.x_in.t[:n, :, :, :3] = chunk.to(self.device).permute(0, 2, 3, 1).to(cp.x_in.t.dtype)
@@ -907,6 +909,8 @@ class Florence2Captioner:
                 b, k = L.resample_coeffs(64, R, 1)
                 self._bic = (torch.from_numpy(b).to(self.device), torch.from_numpy(k).to(self.device), k.shape[1])
         batch_size = max(1, min(int(batch_size), 128))      # plan capacity: buckets stop at 128 crops (the reference's default batch)
+        if image_u8.is_cuda:                                 # a screenshot the caller is still uploading / drawing on its own stream
+            self.stream.wait_stream(torch.cuda.current_stream(image_u8.device))
         for s in range(0, n_all, batch_size):
             boxes = boxes_px[s:s + batch_size]
             n = len(boxes)
