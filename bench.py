@@ -261,6 +261,8 @@ def main():
         out["config"]["caption_micro_batch"] = args.micro_batch
         from omniparser_amd.florence import _BUCKETS
         out["config"]["caption_plan_capacities"] = list(_BUCKETS)
+        out["config"]["caption_remainder"] = ("exact rows: a second hipGraph over the first n rows of the lane's full-capacity plan set "
+                                              "(florence.py::_CaptionPlans.encode_rows)" if parser.cap.exact_rows else "padded to the next plan capacity")
         out["config"]["steps_pipelined"] = bool(args.pipeline)
         # wall time between consecutive steps' results inside the timed region (pipelined: step i's results arrive while step i+1 runs)
         out["config"]["step_wall_ms"] = [round(1000.0 * (b - a), 1) for a, b in zip([t0] + step_done[:-1], step_done)][:40]
@@ -500,24 +502,34 @@ def roofline(args, det, parser, dp, crop_counts, B):
         flops, gemm_ms, launches = float(ddp.net_flops), bk.get(1, 0.0), n
         parts["detector_batch%d" % B] = {"gemm_ms": round(bk.get(1, 0.0), 4), "gflop": round(ddp.net_flops / 1e9, 2)}
         crops = int(round(sum(crop_counts) / max(len(crop_counts), 1)))
-        mbs = [128] * (crops // 128) + ([cap.bucket(crops % 128)] if crops % 128 else [])
-        per_crop = 0.0
         merged = crops > 128 and os.environ.get("OMNI_MERGED_DECODE", "1") != "0"      # one decode over all crops (florence.py::_DecodePlans)
+        exact = merged and cap.exact_rows and crops % 128       # the remainder micro-batch: an exact-row graph in a 128-row plan's buffers
+        mbs = [128] * (crops // 128) + ([crops % 128 if exact else cap.bucket(crops % 128)] if crops % 128 else [])
+        per_crop = 0.0
         import torch
         for bucket in sorted(set(mbs)):
             cp = cap._plans.get((bucket, cap.resolution, 20))
+            if cp is None and exact and bucket == crops % 128:
+                owners = [p for k, p in cap._plans.items() if k[0] == 128 and k[1] == cap.resolution and bucket in getattr(p, "_row_plans", {})]
+                cp = owners[0]._row_plans[bucket] if owners else None
             if cp is None:
                 continue
             cnt = mbs.count(bucket)
-            with torch.inference_mode(), torch_stream(cap.stream):
-                cp.reset()
+            if cp.arena is None:
+                with torch.inference_mode(), torch_stream(cap.stream):
+                    cp.reset()
             real_rows = sum(min(128, crops - 128 * j) for j, mb in enumerate(mbs) if mb == bucket)
             be, ne = profile_plan(cp.encode_plan, cap.stream, per_kernel=pk, times=cnt, work_scale=real_rows / float(cnt * bucket))
             add(be, cnt)
             gemm_ms += cnt * gemm_of(be)
             launches += cnt * ne
             part = {"encode_gemm_ms": round(gemm_of(be), 3), "encode_gflop_per_crop": round(cp.encode_flops / cp.B / 1e9, 2),
-                    "step_gflop_per_crop": round(cp.step_flops / cp.B / 1e9, 4), "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
+                    "encode_gemm_bytes_per_crop": int(cp.pb.bytes / cp.B)}
+            if cp.arena is None:
+                part["step_gflop_per_crop"] = round(cp.step_flops / cp.B / 1e9, 4)
+                step_flops_per_crop = cp.step_flops / cp.B
+            else:
+                part["exact_rows_in_plan_of"] = cp.arena.B
             if not merged:
                 bs, ns = profile_plan(cp.step_plan, cap.stream, repeat=20, per_kernel=pk, times=cnt, work_scale=real_rows / float(cnt * bucket))
                 add(bs, cnt)
@@ -525,7 +537,8 @@ def roofline(args, det, parser, dp, crop_counts, B):
                 launches += cnt * ns
                 part["decode20_gemm_ms"] = round(bs.get(1, 0.0), 3)
             parts["caption_mb%d_x%d" % (bucket, cnt)] = part
-            per_crop = cp.encode_flops / cp.B + 20 * cp.step_flops / cp.B
+            if cp.arena is None:
+                per_crop = cp.encode_flops / cp.B + 20 * cp.step_flops / cp.B
         if merged:
             dec = cap._plans.get(("dec", cap.decode_bucket(crops), cap.resolution, 20))
             if dec is not None:

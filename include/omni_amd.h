@@ -88,7 +88,16 @@ enum {
    *           (OMNI_OP_LAYERNORM i6, this op's i21, OMNI_OP_SPLIT_CONVERT), w = split(W * 2^k) with f1 = 2^-k;
    *           i21 = 1: write y in format B as well (bias + activation applied first; no residual)
    *  i22 / i23 (i20 = 1 only; 0 = the launcher's heuristic): output tile (1 = 64x64, 2 = 128x64, 3 = 128x128) and split-K count
-   *           (1 = no split, no reduce launch) — the per-shape choices of a tuning table; the sums differ only in the order of the K partials */
+   *           (1 = no split, no reduce launch) — the per-shape choices of a tuning table; the sums differ only in the order of the K partials
+   *  i24 = n > 0 (i20 = 1 only; round 6): p6 = int32[n] ARRIVAL COUNTERS, all zero before the first launch that uses them.  A split-K
+   *           launch with at most n output tiles then combines its partials INSIDE the conv launch (each split publishes its tile
+   *           write-through and draws a ticket; the last arriver sums in split order, applies bias / act / residual and zeroes the
+   *           counter) instead of a second reduce launch: same sums in the same order, one launch less per conv.  Launches that share
+   *           counters (or the workspace p5) must not run concurrently: one plan = one stream.  i24 = 0: the reduce launch
+   *  i25 = 1 (i20 = 1 only; round 6): ROW-PATCH mode for a k x k convolution over ldi = 4 stored channels (k <= 8; the captioner's
+   *           first patch embedding): pass it as a k x 1 convolution over 8 consecutive pixels — i6 KH = k, i7 KW = 1, i3 Cin = 32,
+   *           i4 ldi = 4, i5 = 0, i8 / i9 stride / pad of BOTH axes, w = [Cout][k][8 pixels][4] with zero weights for pixel >= k (split
+   *           like any i20 = 1 weight).  Pixels outside the image read as zero one by one; nothing is read beyond a row */
   OMNI_OP_CONV = 1,
   /* avg_pool2d(k=2,s=1,p=0) (ADown, ref blob T1).  p0 x, p4 y.
    *  i0 B i1 H i2 W i3 C i4 ldi i5 in_coff i13 ldo i14 out_coff (Ho=H-1, Wo=W-1) */

@@ -104,12 +104,13 @@ static void op_extents(const omni_op_t* op, long long ext[8]) {
   switch (op->kind) {
     case OMNI_OP_CONV: {
       const long long B = i[0], H = i[1], W = i[2], Cin = i[3], Cout = i[12], M = B * i[10] * i[11], K = (long long)i[6] * i[7] * Cin;
-      ext[0] = span(B * H * W, i[4], i[5], Cin);
+      ext[0] = span(B * H * W, i[4], i[5], i[25] ? i[4] : Cin);    // row-patch mode: "Cin" = 8 pixels of ldi channels, never read beyond a row
       ext[1] = Cout * K * (i[20] ? 4 : esz);                       // split formats: two f16 halves per weight
       ext[2] = Cout * 4;
       ext[3] = span(M, i[16], i[17], Cout);
       ext[4] = span(M, i[13], i[14], Cout);
-      ext[5] = i[19] > 0 ? (long long)i[19] * 1024 : 1;      // p6 is ignored since ABI 2 (i22 = tile code, not a size): nothing to check
+      ext[5] = i[19] > 0 ? (long long)i[19] * 1024 : 1;
+      if (i[24] > 0) ext[6] = (long long)i[24] * 4;          // split-K arrival counters (in-launch combine); p6 is ignored when i24 == 0
       break;
     }
     case OMNI_OP_MLP_FUSED: {

@@ -41,8 +41,9 @@ struct ConvArgs {
   int M, K, ktiles, cin_tiles;
   int splits, kt_per_split, mtiles, ntiles, xcd_order, xcd_n;
   float* ws;
-  void* reserved;         // (kernel-argument layout kept: the slot held a host-only workspace size, then a round-4 candidate's pointer)
+  int* cnt;               // split-K arrival counters, one per output tile (in-launch combine, round 6), or nullptr = reduce launch
   float scale;
+  int vec_px;             // conv_split_kernel, row-patch mode (OMNI_OP_CONV i25): 16-byte vector v of a K slice is input pixel wi + v
 };
 
 
@@ -360,10 +361,62 @@ __device__ __forceinline__ void split_f16x4(const u32x4& raw, uint2& hi, uint2& 
   lo.x = __builtin_bit_cast(unsigned, l01); lo.y = __builtin_bit_cast(unsigned, l23);
 }
 
-// Measured and not kept (round 4, profiles/r4_s2_candidates_ab.txt): split-K without the second launch — the split that draws the last
-// ticket of an output tile adds up all partials inside the conv kernel.  Bit-identical, ~230 fewer launches per batch-1 detector
-// pass, and 4.5x SLOWER end to end (20.4 vs 4.5 ms per screenshot; caption bench 775 vs 692 ms per step): the fences and the
-// single block's serial walk over all splits cost far more than a 3 us reduce launch.
+// Split-K WITHOUT the second launch (round 6; OMNI_OP_CONV i24 / p6).  Round 4 built this with `__threadfence()` in every block and
+// measured it 4.5x slower than the reduce launch (profiles/r4_s2_candidates_ab.txt) — a device-scope fence is a write-back of the
+// XCD's whole L2 plus an invalidate.  This is the fence-free publish of the CDNA4 guide ("in-launch split-K reduction", sc1 form):
+//   every split writes its partial tile WRITE-THROUGH (relaxed agent-scope atomic stores = `global_store_dword ... sc1`: the bytes
+//   leave the XCD's L2 without a flush) -> each wave waits for its own stores (`s_waitcnt vmcnt(0)`) -> block barrier -> ONE lane
+//   draws a ticket from the tile's arrival counter (relaxed agent-scope fetch_add) -> the block that draws `splits - 1` is the
+//   tile's reducer: it reads all partials with agent-scope (sc1) loads — they bypass its XCD's L2 lines — sums them in split order
+//   (the reduce kernel's order: bit-identical results), applies the ordinary epilogue and resets the counter for the next launch.
+// Correct for any placement of a tile's splits over XCDs / CUs; no fence, no spinning (nobody waits for anybody).  The counters
+// are zero before the first launch (host) and zero again after every launch (the reducers).
+#ifndef OMNI_AGENT_ST_F32
+#define OMNI_AGENT_ST_F32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define OMNI_AGENT_LD_F32(p) __hip_atomic_load((p), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define OMNI_AGENT_ADD_I32(p, v) __hip_atomic_fetch_add((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#define OMNI_AGENT_ST_I32(p, v) __hip_atomic_store((p), (v), __ATOMIC_RELAXED, __HIP_MEMORY_SCOPE_AGENT)
+#endif
+
+// the split-order sum of one 32x32 accumulator tile's 16 elements of this lane: the partials of 2 splits in flight at a time.  Written
+// for a SMALL register footprint — the reducer must not raise the kernel's allocation (a first version with 64-bit offsets and four
+// splits in flight took conv_split_kernel<64,64,4> from 97 to 218 registers, i.e. from 4 to 2 waves per SIMD for every launch):
+// 32-bit element offsets (a split-K launch has M * Cout * splits * 4 B <= the 32 MiB workspace), one uniform base per split.
+__device__ __forceinline__ void combine_partials(const ConvArgs& a, int mb, int n, bool nok, float* sum) {
+#pragma unroll
+  for (int e = 0; e < 16; ++e) sum[e] = 0.0f;
+  if (!nok) return;
+  const int total = a.M * a.Cout;
+  // rows beyond M (ragged last tile) read the last valid row instead of branching around every load; the epilogue drops them
+  int off[16];
+#pragma unroll
+  for (int e = 0; e < 16; ++e) {
+    const int m = mb + (e & 3) + 8 * (e >> 2);
+    off[e] = (m < a.M ? m : a.M - 1) * a.Cout + n;
+  }
+  const float* __restrict__ base = a.ws;
+  int z = 0;
+  for (; z + 2 <= a.splits; z += 2, base += 2 * (long long)total) {
+    float v0[16], v1[16];
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v0[e] = OMNI_AGENT_LD_F32(base + off[e]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) v1[e] = OMNI_AGENT_LD_F32(base + total + off[e]);
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum[e] = (sum[e] + v0[e]) + v1[e];
+  }
+  if (z < a.splits) {
+#pragma unroll
+    for (int e = 0; e < 16; ++e) sum[e] += OMNI_AGENT_LD_F32(base + off[e]);
+  }
+}
+
+// Row-patch mode (round 6, OMNI_OP_CONV i25 = 1): a k x k convolution over a FEW input channels (the captioner's first patch embedding:
+// 7 x 7, stride 4 over 3 channels stored as 4) has no 32-channel K slices — it ran on the exact-f32 MFMA kernel at 81 TF/s.  In NHWC
+// with ld = 4 the k taps of one kernel ROW are k * 4 contiguous floats, so the layer is also a k x 1 convolution over "32 channels" =
+// 8 consecutive pixels (k <= 8) whose weights are zero beyond tap k - 1: K = 32 k instead of 4 k^2, on the f16 matrix pipe.  The only
+// difference to an ordinary slice is the bounds check — a vector of the slice is a pixel of its own (left / right image border, and
+// the zero-weight pixel behind the last tap must not be read beyond the row: 0 x NaN) — hence `vec_px`.
 template <int BM, int BN, int NW, bool PW>
 __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
   // NW waves as 2 (M) x NW/2 (N)
@@ -432,10 +485,11 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
       int r = w_r, s = w_s, c = w_c + vec * 4;
       w_c += BKE;
       if (w_c >= a.Cin) { w_c = 0; if (++w_s == a.KW) { w_s = 0; ++w_r; } }
+      const int dpx = vec * a.vec_px;          // row-patch mode: this vector IS pixel wi + vec (its own bounds); 0 otherwise
 #pragma unroll
       for (int it = 0; it < A_IT; ++it) {
         int hi = a_hi0[it] + r, wi = a_wi0[it] + s;
-        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi >= 0 && wi < a.W;
+        bool ok = a_ok[it] && hi >= 0 && hi < a.H && wi + dpx >= 0 && wi + dpx < a.W;
         ra[it] = ok ? *reinterpret_cast<const u32x4*>(X + a_base[it] + ((long long)hi * a.W + wi) * a.ldi + c) : zero4;
       }
     }
@@ -513,6 +567,7 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
   const float inv = 1.0f / 2048.0f;
   if (a.splits > 1) {
     float* __restrict__ P = a.ws + (long long)blockIdx.z * a.M * a.Cout;
+    const bool combine = a.cnt != nullptr;
 #pragma unroll
     for (int j = 0; j < TN; ++j) {
       int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
@@ -523,10 +578,42 @@ __global__ __launch_bounds__(NW * 64, 2) void conv_split_kernel(ConvArgs a) {
 #pragma unroll
         for (int e = 0; e < 16; ++e) {
           int m = mb + (e & 3) + 8 * (e >> 2);
-          if (m < a.M) P[(long long)m * a.Cout + n] = accM[i][j][e] + accC[i][j][e] * inv;
+          if (m < a.M) {
+            const float v = accM[i][j][e] + accC[i][j][e] * inv;
+            if (combine) OMNI_AGENT_ST_F32(&P[(long long)m * a.Cout + n], v);      // write-through: published without a fence
+            else P[(long long)m * a.Cout + n] = v;
+          }
         }
       }
     }
+    if (!combine) return;                                  // the reduce launch sums the partials
+    // ---- in-launch combine: publish, draw the tile's ticket, the last arriver reduces
+    OMNI_WAIT_VMCNT(0);                                    // this wave's partial stores have left
+    __syncthreads();                                       // ... and every other wave's of this block
+    int* const flag = reinterpret_cast<int*>(lds);         // (the K loop ended with a barrier: the ring is free; ONE __shared__ object)
+    if (tid == 0) *flag = OMNI_AGENT_ADD_I32(&a.cnt[mt * a.ntiles + nt], 1);
+    __syncthreads();
+    if (*flag != a.splits - 1) return;
+    if (tid == 0) OMNI_AGENT_ST_I32(&a.cnt[mt * a.ntiles + nt], 0);               // every split has arrived: ready for the next launch
+    auto fin = [&](auto tag) {
+      constexpr int ACT = decltype(tag)::value;
+#pragma unroll
+      for (int j = 0; j < TN; ++j) {
+        const int n = n0 + wn * (BN / WN) + j * 32 + (lane & 31);
+        const bool nok = n < a.Cout;
+        const float bias = (nok && a.bias) ? a.bias[n] : 0.0f;
+#pragma unroll
+        for (int i = 0; i < TM; ++i) {
+          const int mb = m0 + wm * (BM / 2) + i * 32 + 4 * (lane >> 5);
+          float sum[16];
+          combine_partials(a, mb, n, nok, sum);
+          epilogue_tile<float, ACT>(a, mb, n, nok, bias, [&](int e) { return sum[e]; });
+        }
+      }
+    };
+    if (a.act == OMNI_ACT_SILU) fin(std::integral_constant<int, OMNI_ACT_SILU>{});
+    else if (a.act == OMNI_ACT_GELU) fin(std::integral_constant<int, OMNI_ACT_GELU>{});
+    else fin(std::integral_constant<int, OMNI_ACT_NONE>{});
     return;
   }
   auto run = [&](auto tag) {
@@ -565,7 +652,7 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
     if (pw) hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, true>), grid, dim3(256), 0, s, a);
     else hipLaunchKernelGGL((conv_split_kernel<BM, BN, 4, false>), grid, dim3(256), 0, s, a);
   }
-  if (a.splits > 1) {
+  if (a.splits > 1 && !a.cnt) {
     long long total = (long long)a.M * a.Cout;
     hipLaunchKernelGGL((splitk_reduce_kernel<float>), dim3((unsigned)((total + 255) / 256)), dim3(256), 0, s, a);
   }
@@ -576,7 +663,7 @@ void launch_split_cfg(ConvArgs& a, hipStream_t s) {
 // aims at >= 512-768 workgroups; for the latency-bound layers of a batch-1 detector pass (M = 400 ... 6 400: a kernel costs 5-13 us
 // whatever it computes, and every split-K conv is followed by a ~5.5 us reduce launch — 24 % of the pass in round 5's kernel trace)
 // fewer, longer blocks without the reduce are often faster.  Any choice gives the same sums up to the order of the K partials.
-int launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s, int force_tile, int force_splits) {
+int launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s, int force_tile, int force_splits, int* cnt, int n_cnt) {
   a.cin_tiles = a.Cin / 32;
   a.ktiles = a.K / 32;
   // 128x128 at 2 waves/SIMD is the fastest split tile (measured 171-207 TF/s vs 128-165 for 128x64); the
@@ -607,6 +694,8 @@ int launch_split(ConvArgs& a, long long ws_bytes, hipStream_t s, int force_tile,
   }
   a.kt_per_split = (a.ktiles + a.splits - 1) / a.splits;
   a.splits = (a.ktiles + a.kt_per_split - 1) / a.kt_per_split;
+  // in-launch combine when the caller provided arrival counters for every output tile (else: the reduce launch)
+  a.cnt = (a.splits > 1 && cnt && nb <= n_cnt) ? cnt : nullptr;
   if (bm == 128 && bn == 128) launch_split_cfg<128, 128>(a, s);
   else if (bm == 128 && bn == 64) launch_split_cfg<128, 64>(a, s);
   else launch_split_cfg<64, 64>(a, s);
@@ -719,9 +808,16 @@ int omni_launch_conv(const omni_op_t* op, hipStream_t s) {
   OMNI_REQUIRE(M < (1ll << 31), "conv: M too large");
   a.M = (int)M;
   a.K = a.KH * a.KW * a.Cin;
+  a.vec_px = 0;
+  if (op->i[25]) {        // row-patch mode: see conv_split_kernel
+    OMNI_REQUIRE(op->i[25] == 1 && op->i[20] == 1 && a.KW == 1 && a.Cin == 32 && a.ldi == 4 && a.in_coff == 0 && a.KH <= 8,
+                 "conv: row-patch mode (i25) needs i20 = 1, KW = 1, Cin = 32 (8 pixels of 4 channels), ldi = 4, in_coff = 0, KH <= 8");
+    a.vec_px = 1;
+  }
   if (op->i[20]) {        // split-f16 weights ([Cout][K/16][16 hi | 16 lo]) + f32 activations
     OMNI_REQUIRE(op->dtype == OMNI_F32 && a.Cin % 32 == 0, "conv: split-f16 mode needs f32 activations and Cin %% 32 == 0");
-    int rc = launch_split(a, ws_bytes, s, op->i[22], op->i[23]);
+    OMNI_REQUIRE(op->i[24] >= 0 && (op->i[24] == 0 || op->p[6]), "conv: i24 arrival counters without p6");
+    int rc = launch_split(a, ws_bytes, s, op->i[22], op->i[23], op->i[24] > 0 ? (int*)op->p[6] : nullptr, op->i[24]);
     if (rc) return rc;
   } else if (op->dtype == OMNI_F32) launch_typed<float>(a, ws_bytes, s);
   else launch_typed<half_t>(a, ws_bytes, s);

@@ -357,14 +357,24 @@ class _DecodePlans(_StepPlans):
 
 
 class _CaptionPlans(_StepPlans):
-    """Static plans for B crops at resolution R."""
+    """Static plans for B crops at resolution R.
 
-    def __init__(self, cap: "Florence2Captioner", B: int, R: int, max_new: int):
+    arena: another _CaptionPlans of the same resolution and a capacity >= B whose BUFFERS this one uses (round 6).  Such a plan set is
+    encode-only: the same op list over the first B rows of every tensor of `arena` (PlanBuilder._from_arena), captured as its own
+    hipGraph — the last micro-batch of a caption batch then computes exactly its own rows instead of a padded bucket (89 rows instead
+    of 96 at the benched load), without a second set of activations (~19 GB at 96 rows).  Built on demand by `encode_rows`."""
+
+    def __init__(self, cap: "Florence2Captioner", B: int, R: int, max_new: int, arena: Optional["_CaptionPlans"] = None, stream=None):
         w, dev, dt = cap.w, cap.device, cap.dtype
         sd = w.sd
         self.B, self.R, self.T = B, R, max_new + 1
         pb = PlanBuilder(dev, dt)
         pb.reuse = bool(cap.reuse_activations)
+        if arena is not None:
+            assert arena.R == R and arena.B >= B and arena.arena is None
+            pb.arena = iter(arena.pb.alloc_log)
+        self.arena = arena
+        self._row_plans = {}      # n -> encode-only plan set of exactly n rows in THIS plan set's buffers (encode_rows), LRU
         self.pb = pb
         V = pb.V
         wc = cap._wcache
@@ -487,11 +497,20 @@ class _CaptionPlans(_StepPlans):
                 pb.release(xn, *([] if x is self.x_in else [x]))   # reuse_activations: the previous stage's output has had its last reader
             else:
                 t0 = pb.alloc(B, Ho, Ho, C)
-                ck2 = (conv_key, dt, "pad")
-                if ck2 not in wc:
-                    wc[ck2] = (pb.pack_weight(sd[conv_key + ".weight"], cin_pad=V), pb.upload(sd[conv_key + ".bias"].float()))
-                wp, bp = wc[ck2]
-                pb.conv(x, wp, bp, t0, k, st, pd)
+                if cap.patch_rows and dt == L.F32 and pb.split and V == 4 and k <= 8 and x is self.x_in:
+                    # the 7 x 7 / stride-4 patch embedding over the 3 (stored: 4) input channels as a 7 x 1 convolution over 8 consecutive
+                    # pixels on the split-f16 MFMA kernel (PlanBuilder.conv_patch) instead of K = 196 on the exact-f32 one (81 TF/s)
+                    ck2 = (conv_key, dt, "patch")
+                    if ck2 not in wc:
+                        wc[ck2] = (pb.pack_weight_patch(sd[conv_key + ".weight"], V), pb.upload(sd[conv_key + ".bias"].float()))
+                    wp, bp = wc[ck2]
+                    pb.conv_patch(x, wp, bp, t0, k, st, pd)
+                else:
+                    ck2 = (conv_key, dt, "pad")
+                    if ck2 not in wc:
+                        wc[ck2] = (pb.pack_weight(sd[conv_key + ".weight"], cin_pad=V), pb.upload(sd[conv_key + ".bias"].float()))
+                    wp, bp = wc[ck2]
+                    pb.conv(x, wp, bp, t0, k, st, pd)
                 cur = pb.alloc(B, Ho, Ho, C)
                 layernorm(f"{vt}convs.{s}.norm", t0, cur)
                 pb.release(t0)               # (x is the plan's input here: the crop kernels write it, never released)
@@ -623,6 +642,15 @@ class _CaptionPlans(_StepPlans):
         self.n_encode_ops = len(pb.ops)
         self.encode_flops = pb.flops
         self.encode_plan = pb.build()
+        if arena is not None:
+            # encode-only twin in the arena's buffers: every kernel of this op list has run before (the arena's own plan warmed it
+            # up), nothing was allocated, so the graph is captured straight away on the lane's stream (thread-local capture mode:
+            # work in flight on this and other streams is not disturbed, nothing executes here)
+            assert len(pb.alloc_log) == len(arena.pb.alloc_log) and self.n_encode_ops == arena.n_encode_ops, \
+                "arena replay: the two builds made different allocation / op sequences"
+            if cap.use_graph:
+                self.encode_plan.capture(stream or cap.stream)
+            return
         # ---------------- decoder step plan (for a single micro-batch; batches of several micro-batches decode through _DecodePlans)
         self._build_step(cap, B, max_new, S, self.cross_kv, pb.ws)
         if dev.type == "cuda":
@@ -634,6 +662,23 @@ class _CaptionPlans(_StepPlans):
             self.encode_plan.capture(cap.stream)
             self.step_plan.capture(cap.stream)
             cap.stream.synchronize()
+
+    def encode_rows(self, cap: "Florence2Captioner", n: int, stream=None) -> "_CaptionPlans":
+        """encode-only plan set of exactly n <= B rows in this plan set's buffers (built and captured on first use; the
+        `cap.row_graphs` most recently used row counts stay).  The caller issues it on the stream that orders this plan set's uses."""
+        assert self.arena is None and 1 <= n <= self.B
+        if n == self.B:
+            return self
+        cp = self._row_plans.pop(n, None)
+        if cp is None:
+            while len(self._row_plans) >= max(1, int(cap.row_graphs)):
+                if dev_sync := (cap.device.type == "cuda"):
+                    torch.cuda.synchronize(cap.device)                  # the evicted graph may still be executing (rare: `row_graphs` distinct counts)
+                self._row_plans.pop(next(iter(self._row_plans)))
+            cp = _CaptionPlans(cap, n, self.R, self.T - 1, arena=self, stream=stream)
+            cap.row_graph_builds = getattr(cap, "row_graph_builds", 0) + 1
+        self._row_plans[n] = cp                                         # most recently used last
+        return cp
 
 
 # ------------------------------------------------------------------------------------------ public objects
@@ -648,6 +693,11 @@ class Florence2Captioner:
     fuse_dwln = True          # x + dwconv(x) -> LayerNorm as one strip kernel (DaViT stages 0-2)
     attn_split_out = True     # attention kernels write format B for the projection GEMM themselves
     fuse_mlp = True           # fc1 + GELU + fc2 + residual of the C = 128 stage as ONE kernel (OMNI_OP_MLP_FUSED): no hidden tensor in HBM
+    exact_rows = os.environ.get("OMNI_EXACT_ROWS", "1") != "0"   # merged decode: the remainder micro-batch of a caption batch encodes exactly
+                              # its own rows, as a second hipGraph over the buffers of the lane's full-capacity plan (`_CaptionPlans.encode_rows`),
+                              # instead of a padded bucket plan with its own activations; `row_graphs` such graphs stay per plan set
+    row_graphs = int(os.environ.get("OMNI_CAPTION_ROW_GRAPHS", "24"))
+    patch_rows = os.environ.get("OMNI_PATCH_ROWS", "1") != "0"   # first patch embedding in row-patch form on the split-f16 kernel (f32 plans)
     reuse_activations = True  # scratch tensors of a DaViT stage are released at its end and back the tensors of the later stages
                               # (PlanBuilder.release): same kernels, same order, different addresses — a rank's plan sets hold 89 GB
                               # instead of 176 GB of HBM at the same speed (profiles/r4_s2_candidates_ab.txt).  With it `stage_out[:3]` are
@@ -788,6 +838,8 @@ class Florence2Captioner:
     def _encode_into(self, cp: _CaptionPlans, n: int, dec: _DecodePlans, row0: int, stream=None):
         """encode on `stream` (default: the captioner's first stream; the caller made it current)."""
         stream = stream or self.stream
+        if n < cp.B and self.exact_rows:
+            cp = cp.encode_rows(self, n, stream)     # exactly n rows in cp's buffers (cross_kv below: the first n rows of the same tensors)
         (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream)
         for src, dst in zip(cp.cross_kv, dec.cross_kv):
             dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)

@@ -20,6 +20,9 @@ def op_work(op, esz=4):
     k = op.kind
     if k == 1:
         M, N, K = i[0] * i[10] * i[11], i[12], i[6] * i[7] * i[3]
+        if i[25]:                                   # row-patch mode: algorithmic K = k x k taps x 4 stored channels (the op's 32 k holds zero weights)
+            K = i[6] * i[6] * i[4]
+            return 2 * M * N * K, esz * (i[0] * i[1] * i[2] * i[4] + N * K + M * N)
         return 2 * M * N * K, esz * (i[0] * i[1] * i[2] * i[3] + N * K + M * N * (2 if op.p[3] else 1))
     if k == 24:                                     # fc1 + GELU + fc2 + residual: h in, residual in, y out, both weight matrices
         rows, C, hid = i[0] * max(i[1], 1), i[3], i[12]

@@ -327,8 +327,13 @@ class ScreenParser:
             if overlap and merged:
                 lane = self._mb_count = (getattr(self, "_mb_count", -1) + 1) % len(lanes)
             stream = lanes[lane]
-            bucket = cap.bucket(n)
-            cp = cap.plans(bucket, R, max_new_tokens, slot=lane if n == self.batch_size else 0)    # full micro-batches: one plan per lane
+            # full micro-batches: one plan set per lane.  The remainder of a merged batch encodes exactly its n rows as a second graph over
+            # the buffers of ITS LANE's full-capacity plan set (florence.py::_CaptionPlans.encode_rows, taken inside `_encode_into`);
+            # otherwise (single micro-batch, OMNI_EXACT_ROWS=0) a padded bucket plan with buffers of its own
+            if merged and cap.exact_rows and n < self.batch_size:
+                cp = cap.plans(cap.bucket(self.batch_size), R, max_new_tokens, slot=lane)
+            else:
+                cp = cap.plans(cap.bucket(n), R, max_new_tokens, slot=lane if n == self.batch_size else 0)
             with torch.cuda.stream(stream):
                 if cp.free_evt is not None:
                     stream.wait_event(cp.free_evt)

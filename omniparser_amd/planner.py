@@ -107,32 +107,66 @@ class PlanBuilder:
         self.split = os.environ.get("OMNI_CONV_SPLIT", "1") == "1"
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
+        # split-K arrival counters of the in-launch combine (OMNI_OP_CONV i24 / p6): zero-initialised, shared by all convs of the plan
+        # like the workspace (a launch leaves them zero).  OMNI_SPLITK_COMBINE=0 keeps the separate reduce launch (A/B arm).
+        self.cnt = None
+        self.n_cnt = 4096 if os.environ.get("OMNI_SPLITK_COMBINE", "1") != "0" else 0
         self.conv_tuning = None  # {conv_key: (tile code, split-K count)} for the split-f16 conv kernel, or None = the launcher's heuristic
         self.reuse = False       # lifetime reuse of released scratch tensors (see `release`)
         self._free, self._released, self._pins = [], set(), []
         self.reused_bytes = 0    # bytes handed out from released tensors instead of fresh allocations
+        self.alloc_log = []      # every tensor `alloc` / `raw` handed out, in call order (what `arena` replays)
+        self.arena = None        # iterator over ANOTHER builder's `alloc_log`: this builder allocates nothing, its k-th tensor is a
+                                 # prefix view of that builder's k-th tensor (see `_from_arena`)
         self.flops = 0           # 2*MAC of all conv ops (algorithmic work, for the roofline)
         self.bytes = 0           # algorithmic HBM bytes (each operand read once, output written once)
 
     # ---- memory
     def alloc(self, B, H, W, C, zero=False) -> View:
         tdt = torch_dtype(self.dtype)
+        if self.arena is not None:
+            return View(self._from_arena((B, H, W, C), tdt), 0, C)
         if not zero:
             t = self._from_free((B, H, W, C), tdt)
             if t is not None:
+                self.alloc_log.append(t)
                 return View(t, 0, C)
         fn = torch.zeros if zero else torch.empty
         t = fn((B, H, W, C), dtype=tdt, device=self.device)
         self.keep.append(_register(t, "zero" if zero else "scratch"))
+        self.alloc_log.append(t)
         return View(t, 0, C)
 
     def raw(self, shape, dtype, zero=True) -> torch.Tensor:
+        if self.arena is not None:
+            return self._from_arena(tuple(shape), dtype)
         if not zero:
             t = self._from_free(tuple(shape), dtype)
             if t is not None:
+                self.alloc_log.append(t)
                 return t
         t = (torch.zeros if zero else torch.empty)(shape, dtype=dtype, device=self.device)
         self.keep.append(_register(t, "zero" if zero else "scratch"))
+        self.alloc_log.append(t)
+        return t
+
+    # A plan over FEWER ROWS in the buffers of an existing plan (florence.py::_CaptionPlans.encode_rows: the last micro-batch of a
+    # caption batch runs an encode graph of exactly its row count instead of a padded bucket).  The two builders make the same calls
+    # in the same order — the op list of a network does not depend on the batch size — so tensor k of this builder is the same logical
+    # tensor as tensor k of the arena's builder with a smaller leading dimension: it takes the FIRST bytes of that tensor.  Lifetimes
+    # are those of the arena's plan (two of its tensors overlap only where lifetime reuse let them, and then the same two logical
+    # tensors overlap here), zero-initialised tensors keep the arena's content (both plans write the same rows of them), nothing is
+    # allocated, registered or released.  The arena's plan and this one must not run concurrently: they are issued on one stream.
+    def _from_arena(self, shape, dtype):
+        src = next(self.arena, None)
+        if src is None:
+            raise RuntimeError("arena replay: more allocations than the plan that owns the buffers made")
+        need = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        have = src.numel() * src.element_size()
+        if need > have or not src.is_contiguous():
+            raise RuntimeError(f"arena replay: tensor of shape {tuple(shape)} ({need} B) does not fit the arena's {tuple(src.shape)} ({have} B)")
+        t = src.view(-1).view(torch.uint8)[:need].view(dtype).view(shape)
+        self.alloc_log.append(t)
         return t
 
     # Lifetime reuse of scratch tensors (`reuse = True`; off unless the plan's author turns it on).  Ops of a plan run in program
@@ -141,7 +175,7 @@ class PlanBuilder:
     # the rest of the block stays free).  Only whole registered tensors ever enter the list, so the registry above (plan export)
     # keeps seeing each address range once; a carved tensor is a view of the block it came from.
     def release(self, *tensors):
-        if not self.reuse:
+        if not self.reuse or self.arena is not None:
             return
         for t in tensors:
             t = t.t if isinstance(t, View) else t
@@ -263,6 +297,9 @@ class PlanBuilder:
             assert b.numel() == cout
         if self.ws is None and (self.device.type == "cuda" or self.workspace_on_host):
             self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
+        if self.cnt is None and self.ws is not None and self.n_cnt and wfmt == 1:
+            self.cnt = self.raw((self.n_cnt,), torch.int32, zero=True)
+        cnt = self.cnt if (wfmt == 1 and self.cnt is not None) else None
         # tile / split-K override of the split-f16 conv kernel from the plan's tuning table (None: the launcher's heuristic)
         tune = (0, 0)
         if wfmt == 1 and self.conv_tuning:
@@ -270,12 +307,13 @@ class PlanBuilder:
         op = L.make_op(
             L.OP_CONV, self.dtype,
             p=[x.ptr, w_packed.data_ptr(), b.data_ptr() if b is not None else None,
-               res.ptr if res is not None else None, out.ptr, self.ws.data_ptr() if self.ws is not None else None],
+               res.ptr if res is not None else None, out.ptr, self.ws.data_ptr() if self.ws is not None else None,
+               cnt.data_ptr() if cnt is not None else None],
             i={0: x.B, 1: x.H, 2: x.W, 3: x.C, 4: x.ld, 5: x.coff, 6: k, 7: k, 8: s, 9: p, 10: Ho, 11: Wo,
                12: cout, 13: out.ld, 14: out.coff, 15: act,
                16: res.ld if res is not None else 0, 17: res.coff if res is not None else 0,
                19: self.ws_kib if self.ws is not None else 0, 20: wfmt, 21: 1 if out_split else 0,
-               22: tune[0], 23: tune[1]},
+               22: tune[0], 23: tune[1], 24: cnt.numel() if cnt is not None else 0},
             f={0: scale, 1: getattr(w_packed, "omni_oscale", 0.0) if wfmt == 2 else 0.0})
         self.ops.append(op)
         self.keep.append(w_packed)
@@ -284,6 +322,42 @@ class PlanBuilder:
         esz = 4 if self.dtype == L.F32 else 2
         self.flops += 2 * M * cout * k * k * x.C
         self.bytes += esz * (x.B * x.H * x.W * x.C + w_packed.numel() // (2 if wfmt else 1) + M * cout * (2 if res is not None else 1))
+        return out
+
+    def pack_weight_patch(self, w: torch.Tensor, ld: int = 4) -> torch.Tensor:
+        """[Cout, Cin <= ld, k, k] f32 (k <= 8) -> split-f16 weight of the ROW-PATCH form of the convolution (conv_patch):
+        [Cout][k rows][8 pixels][ld channels], zero beyond tap k - 1 and beyond channel Cin - 1."""
+        w = w.detach().float()
+        cout, cin, kh, kw = w.shape
+        assert kh == kw and kh <= 8 and cin <= ld == 4
+        full = w.new_zeros(cout, kh, 8, ld)
+        full[:, :, :kw, :cin] = w.permute(0, 2, 3, 1)
+        t = self.upload(self.split_f16(full.reshape(cout, kh * 8 * ld)))
+        t.omni_fmt = 1
+        return t
+
+    def conv_patch(self, x: View, w_patch: torch.Tensor, bias: torch.Tensor, out: View, k: int, s: int, p: int, act: int = L.ACT_NONE):
+        """k x k convolution (stride s, padding p) over the ld = 4 stored channels of x on the split-f16 MFMA kernel, as a k x 1
+        convolution over 8 consecutive pixels (OMNI_OP_CONV i25 = 1; csrc/conv_igemm.hip "row-patch mode"): K = 32 k on the f16
+        matrix pipe instead of 4 k^2 on the exact-f32 one."""
+        assert self.dtype == L.F32 and x.fmt == "f32" and x.ld == 4 and x.coff == 0 and x.C == 4 and k <= 8
+        Ho = (x.H + 2 * p - k) // s + 1
+        Wo = (x.W + 2 * p - k) // s + 1
+        cout = out.C
+        assert (out.B, out.H, out.W) == (x.B, Ho, Wo) and w_patch.numel() == 2 * cout * k * 32 and getattr(w_patch, "omni_fmt", 0) == 1
+        assert bias.device == self.device and bias.dtype == torch.float32 and bias.numel() == cout
+        if self.ws is None and (self.device.type == "cuda" or self.workspace_on_host):
+            self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
+        self.ops.append(L.make_op(
+            L.OP_CONV, self.dtype,
+            p=[x.ptr, w_patch.data_ptr(), bias.data_ptr(), None, out.ptr, self.ws.data_ptr() if self.ws is not None else None],
+            i={0: x.B, 1: x.H, 2: x.W, 3: 32, 4: 4, 5: 0, 6: k, 7: 1, 8: s, 9: p, 10: Ho, 11: Wo, 12: cout, 13: out.ld, 14: out.coff,
+               15: act, 19: self.ws_kib if self.ws is not None else 0, 20: 1, 25: 1}))
+        self.keep += [w_patch, bias]
+        out.fmt = "f32"
+        M = x.B * Ho * Wo
+        self.flops += 2 * M * cout * k * k * x.C           # ALGORITHMIC work: the k x k x 4 taps, not the zero-padded 32 k
+        self.bytes += 4 * (x.B * x.H * x.W * x.C + cout * k * k * x.C + M * cout)
         return out
 
     def mlp_fused(self, x: View, w1: torch.Tensor, b1: torch.Tensor, w2: torch.Tensor, b2: torch.Tensor, res: View, out: View):

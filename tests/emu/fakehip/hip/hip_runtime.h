@@ -296,6 +296,16 @@ inline float rsqrtf(float x) { return 1.0f / sqrtf(x); }
 inline int __popcll(unsigned long long x) { return __builtin_popcountll(x); }
 inline int __ffsll(long long x) { return __builtin_ffsll(x); }
 
+// agent-scope publish / ticket / read of the in-launch split-K combine (csrc/conv_igemm.hip): blocks are concurrent host threads,
+// so the ticket carries the ordering the hardware recipe gets from write-through stores + vmcnt(0) + barrier (release on the way
+// in, acquire on the way out); the data accesses are relaxed atomics like on the device
+inline void emu_agent_st(float* p, float v) { __atomic_store(p, &v, __ATOMIC_RELAXED); }
+inline float emu_agent_ld(const float* p) { float v; __atomic_load(const_cast<float*>(p), &v, __ATOMIC_RELAXED); return v; }
+#define OMNI_AGENT_ST_F32(p, v) emu_agent_st((p), (v))
+#define OMNI_AGENT_LD_F32(p) emu_agent_ld((p))
+#define OMNI_AGENT_ADD_I32(p, v) __atomic_fetch_add((p), (v), __ATOMIC_ACQ_REL)
+#define OMNI_AGENT_ST_I32(p, v) __atomic_store_n((p), (v), __ATOMIC_RELAXED)
+
 inline void __threadfence() { __atomic_thread_fence(__ATOMIC_SEQ_CST); }       // blocks run on concurrent host threads: a real fence
 inline int atomicAdd(int* p, int v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }
 inline unsigned atomicAdd(unsigned* p, unsigned v) { return __atomic_fetch_add(p, v, __ATOMIC_RELAXED); }

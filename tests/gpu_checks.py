@@ -52,6 +52,42 @@ CONV_CASES = [
 ]
 
 
+def check_conv_patch(seed=0):
+    """PlanBuilder.conv_patch (OMNI_OP_CONV i25: the k x k patch embedding over 4 stored channels as a k x 1 convolution over 8 consecutive
+    pixels on the split-f16 kernel) against an f64 convolution and against the exact-f32 kernel it replaces: borders on every side
+    (images smaller than a tile, widths that are no multiple of the stride), NaN in the stored-but-unused 4th channel's NEIGHBOURHOOD is
+    not tested — the 4th channel is data here (its weights are zero only when Cin = 3)."""
+    g = torch.Generator().manual_seed(seed)
+    out = {"cases": 0, "worst_vs_f64": 0.0, "worst_vs_f32_kernel": 0.0}
+    for (B, H, W, cin, cout, k, s, p) in ((2, 64, 64, 3, 128, 7, 4, 3), (1, 13, 9, 3, 128, 7, 4, 3), (3, 37, 71, 4, 64, 7, 4, 3),
+                                          (1, 30, 33, 3, 128, 5, 2, 2), (1, 20, 20, 3, 192, 8, 4, 3), (1, 768, 96, 3, 128, 7, 4, 3)):
+        x = torch.randn(B, 4, H, W, generator=g)
+        if cin == 3:
+            x[:, 3] = 0.0
+        w = torch.randn(cout, cin, k, k, generator=g) / math.sqrt(cin * k * k)
+        b = torch.randn(cout, generator=g)
+        ref = F.conv2d(x[:, :cin].double(), w.double(), b.double(), stride=s, padding=p)
+        Ho, Wo = ref.shape[2:]
+        pb = PlanBuilder(DEV, L.F32)
+        xv = _nhwc(x, torch.float32, 4, 0)
+        ov = View(torch.full((B, Ho, Wo, cout + 4), 7.0, dtype=torch.float32, device=DEV), 4, cout)
+        pb.conv_patch(xv, pb.pack_weight_patch(w, 4), pb.upload(b), ov, k, s, p)
+        L.launch(pb.ops[0]); _sync()
+        got = ov.torch().cpu().double()
+        assert (ov.t.float().cpu()[..., :4] == 7.0).all(), "conv_patch wrote outside its channel slice"
+        e = rel_err(got, ref)
+        pb2 = PlanBuilder(DEV, L.F32)
+        o2 = View(torch.empty((B, Ho, Wo, cout), dtype=torch.float32, device=DEV), 0, cout)
+        pb2.conv(xv, pb2.pack_weight(w, cin_pad=4), b, o2, k, s, p)
+        assert pb2.ops[0].i[20] == 0
+        L.launch(pb2.ops[0]); _sync()
+        e2 = rel_err(got, o2.torch().cpu().double())
+        assert e < 2e-5 and e2 < 2e-5, ((B, H, W, cin, cout, k, s, p), e, e2)
+        out["cases"] += 1
+        out["worst_vs_f64"] = max(out["worst_vs_f64"], e); out["worst_vs_f32_kernel"] = max(out["worst_vs_f32_kernel"], e2)
+    return out
+
+
 def mask_of(ld, off, c):
     m = torch.ones(ld, dtype=torch.bool); m[off:off + c] = False
     return m
@@ -63,6 +99,7 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
     V = 4 if dtype == L.F32 else 8
     worst = 0.0
     details = []
+    combine_checked = 0
     for case in (cases or CONV_CASES):
         B, H, W, Cin, Cout, k, s, ild, ioff, old, ooff, use_res, act = case
         if Cin % V or ild % V or ioff % V:
@@ -103,6 +140,23 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
                 e2 = rel_err(ov.torch().cpu().double(), ref)
                 assert e2 < (2e-5 if dtype == L.F32 else 4e-3), f"conv case {case} with tile {tile} / splits {splits}: rel err {e2:.3e}"
                 assert (ov.t.float().cpu()[..., mask_of(old, ooff, Cout)] == 7.0).all(), f"override {tile}/{splits} wrote outside its slice: {case}"
+                # round 6: the in-launch split-K combine (i24 / p6 arrival counters; what the launch above ran when the planner provides
+                # them) against the separate reduce launch — the same partials summed in the same order: BIT-identical outputs; every
+                # counter is zero again after a launch, so the second launch (a graph replay) works like the first
+                if op.i[24] > 0:
+                    n_cnt = op.i[24]
+                    with_combine = ov.t.clone()
+                    assert int(pb.cnt.abs().sum()) == 0, f"arrival counters not reset after tile {tile} / splits {splits}: {case}"
+                    ov.t.fill_(7.0)
+                    L.launch(op); _sync()
+                    assert torch.equal(ov.t, with_combine) and int(pb.cnt.abs().sum()) == 0, f"second combine launch differs: {case} {tile}/{splits}"
+                    op.i[24] = 0
+                    ov.t.fill_(7.0)
+                    L.launch(op); _sync()
+                    op.i[24] = n_cnt
+                    assert torch.equal(ov.t, with_combine), (f"in-launch split-K combine differs from the reduce launch: {case} tile {tile} splits {splits}: "
+                                                             f"{int((ov.t != with_combine).sum())} values, max abs {(ov.t - with_combine).abs().max().item():.3e}")
+                    combine_checked += 1
             op.i[22], op.i[23] = 0, 0
         # untouched channels of the output buffer must keep their fill value
         full = ov.t.float().cpu()
@@ -112,7 +166,8 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
         details.append((case, e))
         assert e < tol, f"conv case {case}: rel err {e:.3e} >= {tol}"
         worst = max(worst, e)
-    return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), e) for c, e in details]}
+    return {"worst_rel_err": worst, "cases": len(details), "details": [(str(c), e) for c, e in details],
+            "splitk_combine_vs_reduce_bitwise": combine_checked}
 
 
 
@@ -1399,6 +1454,59 @@ def check_plan_capacity(R=768, n=16, small=8, large=128, seed=0, max_new=20, sta
     return out, cap
 
 
+def check_exact_rows(R=768, n=24, capacity=32, seed=0, small_vocab=False):
+    """The exact-row encode graph of round 6 (florence.py::_CaptionPlans.encode_rows: n rows of a `capacity`-row plan set's buffers,
+    what the remainder micro-batch of a merged caption batch runs) against the full plan on the same crops: (1) image features,
+    encoder output and the cross-attention K / V of the first n rows agree with the full-capacity run (capacity-invariance bar:
+    1e-5 relative; bitwise recorded), (2) the full plan, run again afterwards, reproduces its first run bit for bit (the twin left
+    nothing behind), (3) a second request for n rows returns the cached twin.  (Rows n.. of the shared result tensors are NOT
+    preserved by the twin: with lifetime reuse a late, small tensor of the full plan lies inside the bytes of an early, large one,
+    whose n-row prefix the twin writes — legitimately, both are dead or not yet born at that point of either plan.)"""
+    from omniparser_amd.florence import Florence2Captioner
+    from omniparser_amd.synth import synthetic_screenshot
+    from tools.make_weights import CAPTION_STANDIN, ensure_caption_checkpoint
+    if small_vocab:
+        from conftest import small_vocab_caption_checkpoint
+        d = small_vocab_caption_checkpoint(0)
+    else:
+        d = ensure_caption_checkpoint(0, CAPTION_STANDIN)
+    cap = Florence2Captioner(d, "cuda", precision="f32", resolution=R)
+    frame = torch.from_numpy(synthetic_screenshot(seed, 1920, 1080)).to(DEV)
+    boxes = real_crop_boxes(seed, capacity)
+    cp = cap.plans(capacity, R, 20)
+    _fill_rows(cap, cp, frame, boxes, list(range(capacity)))
+    run = (lambda p: p.replay(cap.stream)) if cap.use_graph else (lambda p: p.run(cap.stream))
+
+    def snap(c, rows):
+        cap.stream.synchronize()
+        d_ = {"img_feat": c.img_feat.t[rows].float().cpu().clone(), "enc_out": c.enc_out.t[rows].float().cpu().clone()}
+        for l, kv in enumerate(c.cross_kv):
+            d_[f"cross_kv{l}"] = kv.t[rows].float().cpu().clone()
+        return d_
+    with torch.inference_mode(), torch.cuda.stream(cap.stream):
+        run(cp.encode_plan)
+        full = snap(cp, slice(0, capacity))
+        # poison what the twin must produce itself (its outputs live in the same bytes as the full plan's)
+        for t in [cp.img_feat.t, cp.enc_out.t] + [kv.t for kv in cp.cross_kv]:
+            t[:n] = 7.0
+        tw = cp.encode_rows(cap, n, cap.stream)
+        assert tw is not cp and tw.arena is cp and tw.B == n and tw.x_in.ptr == cp.x_in.ptr
+        run(tw.encode_plan)
+        part = snap(tw, slice(0, n))
+        again = cp.encode_rows(cap, n, cap.stream)
+        run(cp.encode_plan)
+        full2 = snap(cp, slice(0, capacity))
+    out = {"R": R, "n": n, "capacity": capacity, "twin_cached": again is tw, "builds": getattr(cap, "row_graph_builds", 0),
+           "twin_ops": len(tw.encode_plan), "full_ops": len(cp.encode_plan), "twin_gflop_per_crop": tw.encode_flops / n / 1e9,
+           "full_gflop_per_crop": cp.encode_flops / capacity / 1e9}
+    for k in full:
+        a, b = part[k], full[k][:n]
+        d_ = (a - b).abs().max().item()
+        out[k] = {"rel": d_ / max(b.abs().max().item(), 1e-30), "bitwise": bool(torch.equal(a, b)),
+                  "full_again_bitwise": bool(torch.equal(full2[k], full[k]))}
+    return out, cap
+
+
 _REAL_CROPS_ORACLE = {}
 
 
@@ -1902,7 +2010,13 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
     # ---- the RxR crop tensor of the last micro-batch is the oracle's pixel_values (bicubic-to-R -> DaViT seam): same u8 resampling
     #      result for every pixel (a difference of one u8 step would be 1.4e-2), bitwise equality recorded
     n_last = len(flat) % sp.batch_size or min(len(flat), sp.batch_size)
-    cp = cap.plans(cap.bucket(n_last), R, cap.max_new_tokens)
+    if getattr(cap, "exact_rows", False) and len(flat) > sp.batch_size and n_last < sp.batch_size:
+        # merged batch: the remainder ran as an exact-row graph in the buffers of lane 0's full-capacity plan set (pipeline.py::caption_launch)
+        cp = cap.plans(cap.bucket(sp.batch_size), R, cap.max_new_tokens)
+        out["remainder_rows_exact"] = sorted(cp._row_plans)
+        assert n_last in cp._row_plans, (n_last, sorted(cp._row_plans))
+    else:
+        cp = cap.plans(cap.bucket(n_last), R, cap.max_new_tokens)
     first = len(flat) - n_last
     for j in (0, n_last // 2, n_last - 1):
         f, k = flat[first + j]

@@ -119,8 +119,19 @@ def run_op(op, m):
         m.at(p[4], torch.float32)[: rows * ldo].view(rows, ldo)[:, ocoff:ocoff + C] = split_encode(x)
     elif k == L.OP_CONV:
         B, H, W, Cin, ldi, icoff, KH, KW, s, pad, Ho, Wo, Cout, ldo, ocoff, act, ldr, rcoff = [i[j] for j in range(18)]
-        x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi)[..., icoff:icoff + Cin].permute(0, 3, 1, 2).float()
-        if i[20]:
+        if i[25]:
+            # row-patch mode (include/omni_amd.h): a KH x KH convolution over the ldi = 4 stored channels, weights [Cout][KH][8 pixels][4]
+            hl = m.at(p[1], torch.float16)[: 2 * Cout * KH * 32].view(Cout, KH * 2, 2, 16).float()
+            w = (hl[:, :, 0] + hl[:, :, 1] / 2048.0).reshape(Cout, KH, 8, ldi)
+            assert float(w[:, :, KH:].abs().max()) == 0.0
+            w = w[:, :, :KH].permute(0, 3, 1, 2)
+            x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi).permute(0, 3, 1, 2).float()
+            Cin, KW = ldi, KH
+        else:
+            x = m.at(p[0], dt)[: B * H * W * ldi].view(B, H, W, ldi)[..., icoff:icoff + Cin].permute(0, 3, 1, 2).float()
+        if i[25]:
+            pass
+        elif i[20]:
             hl = m.at(p[1], torch.float16)[: 2 * Cout * KH * KW * Cin].view(Cout, KH * KW * Cin // 16, 2, 16).float()
             w = (hl[:, :, 0] + hl[:, :, 1] / 2048.0).reshape(Cout, KH, KW, Cin).permute(0, 3, 1, 2)
         else:

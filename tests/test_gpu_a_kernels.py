@@ -49,6 +49,17 @@ def test_conv_igemm(dtype):
     import gpu_checks as G
     r = G.check_conv(dtype)
     assert r["cases"] >= 6
+    if dtype == L.F32:      # round 6: the in-launch split-K combine equals the reduce launch bit for bit, counters self-reset
+        assert r["splitk_combine_vs_reduce_bitwise"] >= 24, r
+
+
+def test_conv_patch_rows():
+    """round 6: the captioner's 7 x 7 / stride-4 patch embedding over 4 stored channels as a 7 x 1 convolution over 8 consecutive pixels on
+    the split-f16 MFMA kernel (OMNI_OP_CONV i25) vs an f64 convolution and vs the exact-f32 kernel it replaces, image borders included."""
+    import gpu_checks as G
+    r = G.check_conv_patch()
+    print(r)
+    assert r["cases"] == 6, r
 
 
 def test_conv_igemm_exact_f32_path(monkeypatch):

@@ -100,3 +100,17 @@ def test_captioner_f16_token_match_rate_r64():
     print({k: out[k] for k in ("tokens_match", "feat_rel_err", "enc_rel_err", "ids_equal")})
     assert out["enc_rel_err"] < 5e-2, out
     assert out["tokens_match"] >= 0.8, out          # measured 0.985 on the MI355X (profiles/r5_s3_f16_rate.txt); a broken f16 path scores < 0.2
+
+
+def test_exact_row_encode_twin_r768():
+    """Round 6: the remainder micro-batch of a merged caption batch encodes exactly its rows as a second hipGraph in the buffers of the
+    full-capacity plan set (florence.py::_CaptionPlans.encode_rows).  24 rows of a 32-row plan set at 768x768: features, encoder output
+    and every layer's cross-attention K / V equal the full plan's on those rows (capacity-invariance bar), the full plan is unharmed
+    afterwards, the twin is cached.  (The benched 89-of-128 case is covered token for token by test_gpu_z_bench_path.py.)"""
+    import gpu_checks as G
+    out, _ = G.check_exact_rows(R=768, n=24, capacity=32)
+    print(out)
+    assert out["twin_cached"] and out["builds"] == 1 and out["twin_ops"] == out["full_ops"]
+    for k, v in out.items():
+        if isinstance(v, dict):
+            assert v["rel"] <= 1e-5 and v["full_again_bitwise"], (k, out)

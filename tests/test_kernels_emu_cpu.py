@@ -39,6 +39,15 @@ def test_conv_igemm(emu, dtype):
     import gpu_checks as G
     r = G.check_conv(dtype, cases=SMALL_CONV)
     assert r["cases"] >= 6
+    if dtype == L.F32:      # split-f16 convs: in-launch split-K combine == reduce launch, bit for bit (blocks run on concurrent host threads)
+        assert r["splitk_combine_vs_reduce_bitwise"] >= 12, r
+
+
+def test_conv_patch_rows(emu):
+    """row-patch form of the first patch embedding (OMNI_OP_CONV i25) vs f64 and vs the exact-f32 kernel, borders included"""
+    import gpu_checks as G
+    r = G.check_conv_patch()
+    assert r["cases"] == 6, r
 
 
 def test_conv_igemm_exact_f32_path(emu, monkeypatch):

@@ -257,8 +257,23 @@ def test_merged_decode_equals_per_micro_batch_decode(emu, monkeypatch):
         out = sp.caption([frame, frame], rects)
         got[mode] = [[row.tolist() for _, row in f] for f in out]
     assert any(k[0] == "dec" for k in cap._plans)                                          # the merged path ran
+    # round 6: the 1-crop remainder of the merged batch ran as an exact-row twin in the buffers of the 2-row plan set, not as a bucket plan
+    assert cap.exact_rows and getattr(cap, "row_graph_builds", 0) == 1 and sorted(cap._plans[(2, 64, 2)]._row_plans) == [1]
     dec = next(v for k, v in cap._plans.items() if k[0] == "dec")
     assert int(dec.ids.min()) >= 0 and int(dec.ids.max()) < cap.w.vocab, "a padding row produced an out-of-range token id"
     assert [len(f) for f in got["1"]] == [3, 2]
     strip = lambda rows: [[t for t in r if t != cap.w.pad] for r in rows]
     assert [strip(f) for f in got["1"]] == [strip(f) for f in got["0"]]
+
+
+def test_exact_row_encode_twin_in_the_full_plans_buffers(emu):
+    """florence.py::_CaptionPlans.encode_rows on the emulation: 3 rows of a 4-row plan set's buffers — same features / encoder output /
+    cross-attention K and V as the full plan on those rows, the full plan unharmed afterwards, the twin cached."""
+    import gpu_checks as G
+    out, cap = G.check_exact_rows(R=64, n=3, capacity=4, small_vocab=True)
+    print(out)
+    assert out["twin_cached"] and out["builds"] == 1 and out["twin_ops"] == out["full_ops"]
+    assert abs(out["twin_gflop_per_crop"] - out["full_gflop_per_crop"]) < 1e-6 * out["full_gflop_per_crop"]
+    for k, v in out.items():
+        if isinstance(v, dict):
+            assert v["rel"] <= 1e-5 and v["full_again_bitwise"], (k, out)
