@@ -182,7 +182,9 @@ def main():
     if args.pipeline and args.mode == "e2e":
         # warm-up through the same pipeline (its second-lane encode plans and second decode plan are built here, not in the timed region)
         def warm_batches():
-            for w in range(max(args.warmup, 2)):
+            # (at least 4: the plan sets of the steady state exist after the second lane has seen the step's remainder micro-batch twice —
+            # two 128-row plan sets, their exact-row twins (florence.py::_CaptionPlans.rows_for), two decode plans; the driver passes 5)
+            for w in range(max(args.warmup, 4)):
                 idx = [(w * B + j) % 8 for j in range(B)]
                 yield [frames[f] for f in idx], [ocr[f] for f in idx]
         with torch.inference_mode():
@@ -512,6 +514,14 @@ def roofline(args, det, parser, dp, crop_counts, B):
             if cp is None and exact and bucket == crops % 128:
                 owners = [p for k, p in cap._plans.items() if k[0] == 128 and k[1] == cap.resolution and bucket in getattr(p, "_row_plans", {})]
                 cp = owners[0]._row_plans[bucket] if owners else None
+                if cp is None:          # no exact twin (yet): the remainder ran the twin of the next ladder capacity, or the full plan
+                    b2 = cap.bucket(bucket)
+                    owners = [p for k, p in cap._plans.items() if k[0] == 128 and k[1] == cap.resolution and b2 in getattr(p, "_row_plans", {})]
+                    if not owners:
+                        mbs[-1] = 128   # counted with the full micro-batches below (their real rows include the remainder's)
+                        continue
+                    cp = owners[0]._row_plans[b2]
+                    mbs[-1] = bucket = b2
             if cp is None:
                 continue
             cnt = mbs.count(bucket)

@@ -213,6 +213,28 @@ class FlorenceWeights:
         assert self.window == 12 and self.d_model // self.n_heads == 64
 
 
+_DECODE_TUNING = "unset"
+
+
+def decode_tuning(device=None):
+    """The committed tuning table of the decode step's GEMMs (`omniparser_amd/decode_tuning_gfx950.json`, written by
+    tools/decode_autotune.py on the MI355X): {shape key: (tile code, split-K count)} for the row counts a merged decode plan can have.
+    A decode step is launch-bound (~110 kernels of 5-15 us); the launcher's throughput heuristic cuts its GEMMs into 6 K splits of four
+    slices plus a reduce launch where fewer, longer blocks are faster.  Tuning changes the order in which K partials are summed, nothing
+    else (the logits' last bits already depend on the row count, see _DecodePlans); OMNI_DECODE_TUNING=0 turns it off; a device that is
+    not gfx950, or a missing file, means the heuristic."""
+    global _DECODE_TUNING
+    if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
+        if not getattr(torch.cuda.get_device_properties(device), "gcnArchName", "").startswith("gfx950"):
+            return None
+    if _DECODE_TUNING == "unset":
+        path = Path(__file__).resolve().parent / "decode_tuning_gfx950.json"
+        _DECODE_TUNING = None
+        if os.environ.get("OMNI_DECODE_TUNING", "1") != "0" and path.exists():
+            _DECODE_TUNING = {k: tuple(v) for k, v in json.loads(path.read_text())["choices"].items()}
+    return _DECODE_TUNING
+
+
 # ------------------------------------------------------------------------------------------ plans
 class _StepPlans:
     """The decoder-step plan over B rows (embedding, 6 BART decoder layers with self-KV cache and fixed cross-KV, lm_head, logits
@@ -240,6 +262,8 @@ class _StepPlans:
 
         pd_ = PlanBuilder(dev, dt)
         pd_.ws = ws
+        if isinstance(self, _DecodePlans):
+            pd_.conv_tuning = decode_tuning(dev)          # merged decode plans only: the per-micro-batch step plans keep the heuristic
         self.pd = pd_
         T = self.T
         self.B = B
@@ -663,6 +687,18 @@ class _CaptionPlans(_StepPlans):
             self.step_plan.capture(cap.stream)
             cap.stream.synchronize()
 
+    def rows_for(self, cap: "Florence2Captioner", n: int) -> int:
+        """Row count of the graph a micro-batch of n < B crops runs in this plan set's buffers.  Building a twin costs what building a
+        plan costs on the host (~900 op descriptors + a graph capture: a few hundred ms), so a stream whose remainder differs from batch
+        to batch must not build one per batch (measured: the mixed-resolution stream fell from 8.1 to 5.8 screenshots/s when every count
+        got its own graph).  Policy: a count that is cached, or that the captioner saw for the previous remainder too (a steady load:
+        the bench's 89, a service under constant traffic), runs EXACTLY; any other count runs the twin of the next capacity of the
+        ladder (8, 16, 32, 64, 96 — at most five twins per plan set, the old bucket plans without their buffers)."""
+        last, cap._last_remainder = getattr(cap, "_last_remainder", None), n
+        if n in self._row_plans or n == last:
+            return n
+        return min(cap.bucket(n), self.B)
+
     def encode_rows(self, cap: "Florence2Captioner", n: int, stream=None) -> "_CaptionPlans":
         """encode-only plan set of exactly n <= B rows in this plan set's buffers (built and captured on first use; the
         `cap.row_graphs` most recently used row counts stay).  The caller issues it on the stream that orders this plan set's uses."""
@@ -839,7 +875,8 @@ class Florence2Captioner:
         """encode on `stream` (default: the captioner's first stream; the caller made it current)."""
         stream = stream or self.stream
         if n < cp.B and self.exact_rows:
-            cp = cp.encode_rows(self, n, stream)     # exactly n rows in cp's buffers (cross_kv below: the first n rows of the same tensors)
+            cp = cp.encode_rows(self, cp.rows_for(self, n), stream)     # n rows (or the ladder capacity above n) in cp's buffers; cross_kv
+                                                                        # below: the first n rows of the same tensors
         (cp.encode_plan.replay if self.use_graph else cp.encode_plan.run)(stream)
         for src, dst in zip(cp.cross_kv, dec.cross_kv):
             dst.t[row0:row0 + n].copy_(src.t[:n], non_blocking=True)

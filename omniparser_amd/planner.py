@@ -108,9 +108,12 @@ class PlanBuilder:
         self.ws = None           # split-K workspace shared by all convs of the plan (ops run in order)
         self.ws_kib = 32 * 1024
         # split-K arrival counters of the in-launch combine (OMNI_OP_CONV i24 / p6): zero-initialised, shared by all convs of the plan
-        # like the workspace (a launch leaves them zero).  OMNI_SPLITK_COMBINE=0 keeps the separate reduce launch (A/B arm).
+        # like the workspace (a launch leaves them zero).  OPT-IN (OMNI_SPLITK_COMBINE=1): bit-identical to the reduce launch and 234
+        # launches instead of 431 per detector pass, but measured SLOWER on the MI355X in both sessions that compared them
+        # (profiles/r6_s10_splitk_combine_ab.txt: batch-1 pass 4.44 -> 4.83 ms, batch 8 +0.6 %, 1088x1920 +1 %, the 20 decode steps'
+        # GEMMs 17.2 -> 18.3 ms): the last arriver's serial ticket + write-through read-back costs more than a 5 us reduce launch.
         self.cnt = None
-        self.n_cnt = 4096 if os.environ.get("OMNI_SPLITK_COMBINE", "1") != "0" else 0
+        self.n_cnt = 4096 if os.environ.get("OMNI_SPLITK_COMBINE", "0") == "1" else 0
         self.conv_tuning = None  # {conv_key: (tile code, split-K count)} for the split-f16 conv kernel, or None = the launcher's heuristic
         self.reuse = False       # lifetime reuse of released scratch tensors (see `release`)
         self._free, self._released, self._pins = [], set(), []
@@ -345,7 +348,7 @@ class PlanBuilder:
         Wo = (x.W + 2 * p - k) // s + 1
         cout = out.C
         assert (out.B, out.H, out.W) == (x.B, Ho, Wo) and w_patch.numel() == 2 * cout * k * 32 and getattr(w_patch, "omni_fmt", 0) == 1
-        assert bias.device == self.device and bias.dtype == torch.float32 and bias.numel() == cout
+        assert bias.device.type == self.device.type and bias.dtype == torch.float32 and bias.numel() == cout
         if self.ws is None and (self.device.type == "cuda" or self.workspace_on_host):
             self.ws = self.raw((self.ws_kib * 256,), torch.float32, zero=False)
         self.ops.append(L.make_op(

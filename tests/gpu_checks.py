@@ -120,6 +120,7 @@ def check_conv(dtype=L.F32, seed=0, cases=None):
         if use_res:
             ref = ref + resq.double()
         pb = PlanBuilder(DEV, dtype)
+        pb.n_cnt = 4096        # arrival counters for the in-launch split-K combine (opt-in in the product: OMNI_SPLITK_COMBINE=1); compared below
         xv = _nhwc(x, tdt, ild, ioff)
         ov = View(torch.full((B, Ho, Wo, old), 7.0, dtype=tdt, device=DEV), ooff, Cout)
         rv = _nhwc(res, tdt, Cout + V, V) if use_res else None
@@ -2014,7 +2015,8 @@ def check_bench_path(R=768, width=1.0, n_frames=8, caption_pairs=((0, 1), (2, 3)
         # merged batch: the remainder ran as an exact-row graph in the buffers of lane 0's full-capacity plan set (pipeline.py::caption_launch)
         cp = cap.plans(cap.bucket(sp.batch_size), R, cap.max_new_tokens)
         out["remainder_rows_exact"] = sorted(cp._row_plans)
-        assert n_last in cp._row_plans, (n_last, sorted(cp._row_plans))
+        # (a count seen for the first time runs the twin of the next ladder capacity, a repeated one its exact twin: _CaptionPlans.rows_for)
+        assert n_last in cp._row_plans or cap.bucket(n_last) in cp._row_plans, (n_last, sorted(cp._row_plans))
     else:
         cp = cap.plans(cap.bucket(n_last), R, cap.max_new_tokens)
     first = len(flat) - n_last
