@@ -222,7 +222,9 @@ def decode_tuning(device=None):
     A decode step is launch-bound (~110 kernels of 5-15 us); the launcher's throughput heuristic cuts its GEMMs into 6 K splits of four
     slices plus a reduce launch where fewer, longer blocks are faster.  Tuning changes the order in which K partials are summed, nothing
     else (the logits' last bits already depend on the row count, see _DecodePlans); OMNI_DECODE_TUNING=0 turns it off; a device that is
-    not gfx950, or a missing file, means the heuristic."""
+    not gfx950, or a missing file, means the heuristic.  NO TABLE IS COMMITTED: measured in round 6 (profiles/r6_s13_decode_autotune.json),
+    the best choices beat the heuristic by 2.8 % of a step graph at 128 rows, 0.3-0.5 % at 160-320 rows and nothing at 352 / 384 rows
+    (the benched load) — the heuristic stays; the tool and this loader remain for other chips / row counts."""
     global _DECODE_TUNING
     if device is not None and torch.device(device).type == "cuda" and torch.cuda.is_available():
         if not getattr(torch.cuda.get_device_properties(device), "gcnArchName", "").startswith("gfx950"):
