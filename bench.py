@@ -266,6 +266,7 @@ def main():
         out["config"]["caption_remainder"] = ("exact rows: a second hipGraph over the first n rows of the lane's full-capacity plan set "
                                               "(florence.py::_CaptionPlans.encode_rows)" if parser.cap.exact_rows else "padded to the next plan capacity")
         out["config"]["steps_pipelined"] = bool(args.pipeline)
+        out["config"]["warmup_steps_run"] = max(args.warmup, 4) if args.pipeline else args.warmup     # pipelined: >= 4 untimed steps (plan sets of the steady state)
         # wall time between consecutive steps' results inside the timed region (pipelined: step i's results arrive while step i+1 runs)
         out["config"]["step_wall_ms"] = [round(1000.0 * (b - a), 1) for a, b in zip([t0] + step_done[:-1], step_done)][:40]
         out["config"]["hw_queues"] = os.environ.get("GPU_MAX_HW_QUEUES", "HIP runtime default (4)")
