@@ -538,3 +538,38 @@ def test_scan_provenance_describes_the_tree_it_was_measured_on():
            "kernel_sources_sha16": hashlib.sha256(b"".join(p.read_bytes() for p in sorted((ROOT / "omniparser_amd" / "csrc").glob("*.h*")))).hexdigest()[:16]}
     assert {k: sc["provenance"].get(k) for k in cur} == cur
     assert sc["frames"] == 110 and sc["final_boxes_identical"] >= 109 and sc["identical_up_to_exchanges_of_equal_score_neighbours"] >= 109
+
+
+def test_plan_builder_arena_replay_hands_out_prefixes_and_refuses_what_does_not_fit():
+    """PlanBuilder arena mode (round 6: the exact-row twins of florence.py::_CaptionPlans.encode_rows): tensor k of the replaying builder is
+    the first bytes of tensor k of the builder that owns the buffers — including tensors carved out of released ones — nothing is
+    allocated, released or zeroed; a larger tensor, a longer allocation sequence or a release are errors / no-ops, never a silent overrun."""
+    from omniparser_amd.planner import PlanBuilder
+    own = PlanBuilder("cpu", L.F32)
+    own.reuse = True
+    a = own.alloc(4, 6, 6, 8)
+    b = own.raw((4 * 100,), torch.float32, zero=False)
+    own.release(a)
+    c = own.alloc(4, 3, 3, 8)                                # carved out of a's bytes (lifetime reuse)
+    z = own.alloc(4, 2, 2, 4, zero=True)
+    z.t.fill_(3.0)
+    assert c.t.data_ptr() == a.t.data_ptr() and len(own.alloc_log) == 4
+    twin = PlanBuilder("cpu", L.F32)
+    twin.reuse = True
+    twin.arena = iter(own.alloc_log)
+    a2 = twin.alloc(3, 6, 6, 8)
+    b2 = twin.raw((3 * 100,), torch.float32, zero=False)
+    twin.release(a2)                                         # a no-op: lifetimes are the owner's
+    c2 = twin.alloc(3, 3, 3, 8)
+    z2 = twin.alloc(3, 2, 2, 4, zero=True)
+    assert (a2.t.data_ptr(), b2.data_ptr(), c2.t.data_ptr(), z2.t.data_ptr()) == (a.t.data_ptr(), b.data_ptr(), c.t.data_ptr(), z.t.data_ptr())
+    assert tuple(a2.t.shape) == (3, 6, 6, 8) and b2.numel() == 300 and not twin._free and not twin.keep
+    assert float(z2.t.min()) == 3.0                          # zero-initialised state keeps the owner's content
+    a2.t.fill_(5.0)
+    assert float(a.t[:3].min()) == 5.0 and float(c.t.view(-1)[0]) == 5.0
+    with pytest.raises(RuntimeError, match="more allocations"):
+        twin.alloc(1, 1, 1, 4)
+    big = PlanBuilder("cpu", L.F32)
+    big.arena = iter(own.alloc_log)
+    with pytest.raises(RuntimeError, match="does not fit"):
+        big.alloc(5, 6, 6, 8)
